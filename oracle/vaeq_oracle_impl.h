@@ -1,0 +1,539 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+ *
+ * CPU restatement (plain C) of the VAE blind-equalizer training inner loop of
+ * kit-cel/vae-equalizer.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product (vae_equalizer_amd) never
+ * imports, links or calls it.
+ *
+ * This header is the implementation body.  vaeq_oracle.c includes it twice, once
+ * with REAL=float (suffix _f32: the reference's own arithmetic type) and once
+ * with REAL=double (suffix _f64: the "truth" both the reference's goldens and
+ * the HIP kernels are measured against).
+ *
+ * Parity is PINNED: tests/test_oracle_golden.py checks every function below
+ * against vectors captured from the reference itself (tools/capture_golden.py,
+ * fixtures under tests/golden/).
+ *
+ * All file:line citations are relative to the reference tree:
+ *   DP   = optical_DP_channel/shared_funcs.py
+ *   LEDP = optical_DP_channel/func_VAELE_DP_MQAM_shaping.py
+ *   FLEX = optical_DP_channel/func_VAEflex_DP_MQAM_shaping.py
+ *   AWGN = AWGN_channel/func_VAELE_MQAM_shaping.py
+ *
+ * The backward pass is written the way autograd walks the reference's forward
+ * graph (explicit zero-stuffed Eq/Var grids, per-level dL/dq, softmin backward,
+ * channel-packed conv weight gradient).  The HIP kernels use an independently
+ * simplified closed form (central moments), so the two derivations check each
+ * other.
+ */
+
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+#define FN(name) CAT(name, SFX)
+
+#define MAXLEV 16
+
+/* ---------------------------------------------------------------- helpers */
+static inline REAL FN(r_exp)(REAL x) { return (REAL)exp((double)x); }
+static inline REAL FN(r_log)(REAL x) { return (REAL)log((double)x); }
+static inline REAL FN(r_sqrt)(REAL x) { return (REAL)sqrt((double)x); }
+static inline REAL FN(r_abs)(REAL x) { return x < 0 ? -x : x; }
+
+/* softmin over n levels of cost c_i (nn.Softmin(dim=0), DP:497 / AWGN:212): softmax(-c), max-subtracted */
+static void FN(softmin)(int n, const REAL *cost, REAL *q)
+{
+    REAL cmin = cost[0], s = 0;
+    for (int i = 1; i < n; i++) if (cost[i] < cmin) cmin = cost[i];
+    for (int i = 0; i < n; i++) { q[i] = FN(r_exp)(-(cost[i] - cmin)); s += q[i]; }
+    for (int i = 0; i < n; i++) q[i] = q[i] / s;
+}
+
+/* ------------------------------------------------------------------ R1+R2
+ * twoXtwoFIR.forward, DP:500-527.  x[2][2][L] (pol, I/Q, sample), W[2][4][M]
+ * (Conv1d(4->2,k=M,stride=sps,pad=M//2), DP:494), channel packing DP:505,507:
+ *   x_in_I = [xI0, xI1, -xQ0, -xQ1],  x_in_Q = [xQ0, xQ1, xI0, xI1].
+ * q[2][2n][B] rows 0..n-1 = I levels, n..2n-1 = Q levels; out[2][2][B]. */
+void FN(vaeq_oracle_dp_forward)(int B, int sps, int M, int n, const REAL *x, const REAL *W, const REAL *amp,
+                                const REAL *var, REAL nu_sc, REAL *q, REAL *out)
+{
+    const int L = B * sps, pad = M / 2;
+    for (int o = 0; o < 2; o++)
+        for (int nn = 0; nn < B; nn++) {
+            REAL accI = 0, accQ = 0;
+            for (int ch = 0; ch < 4; ch++) {
+                const int p = ch & 1, neg = ch >> 1;
+                for (int k = 0; k < M; k++) {
+                    const int s = nn * sps + k - pad;
+                    if (s < 0 || s >= L) continue;            /* zero padding, DP:494 */
+                    const REAL xi = x[(p * 2 + 0) * L + s], xq = x[(p * 2 + 1) * L + s];
+                    const REAL inI = neg ? -xq : xi;          /* DP:505 */
+                    const REAL inQ = neg ? xi : xq;           /* DP:507 */
+                    const REAL w = W[(o * 4 + ch) * M + k];
+                    accI += w * inI;
+                    accQ += w * inQ;
+                }
+            }
+            out[(o * 2 + 0) * B + nn] = accI;                 /* DP:518 */
+            out[(o * 2 + 1) * B + nn] = accQ;
+            for (int c = 0; c < 2; c++) {                     /* DP:521-523 */
+                const REAL y = c ? accQ : accI;
+                REAL cost[MAXLEV], qq[MAXLEV];
+                for (int i = 0; i < n; i++) {
+                    const REAL d = y - amp[i];
+                    cost[i] = d * d / 2 / var[o] + nu_sc * (amp[i] * amp[i]);
+                }
+                FN(softmin)(n, cost, qq);
+                for (int i = 0; i < n; i++) q[(o * 2 * n + c * n + i) * B + nn] = qq[i];
+            }
+        }
+}
+
+/* soft_dec, DP:529-542: the demapper alone on out[2][2][N] */
+void FN(vaeq_oracle_dp_soft_dec)(int N, int n, const REAL *out, const REAL *var, const REAL *amp, REAL nu_sc, REAL *q)
+{
+    for (int o = 0; o < 2; o++)
+        for (int c = 0; c < 2; c++)
+            for (int nn = 0; nn < N; nn++) {
+                const REAL y = out[(o * 2 + c) * N + nn];
+                REAL cost[MAXLEV], qq[MAXLEV];
+                for (int i = 0; i < n; i++) {
+                    const REAL d = y - amp[i];
+                    cost[i] = d * d / 2 / var[o] + nu_sc * (amp[i] * amp[i]);
+                }
+                FN(softmin)(n, cost, qq);
+                for (int i = 0; i < n; i++) q[(o * 2 * n + c * n + i) * N + nn] = qq[i];
+            }
+}
+
+/* --------------------------------------------------------------------- R3
+ * loss_function_shaping, DP:92-137.  q[2][2n][B], x[2][2][L], h[2][2][2][M]
+ * (chi, nu, re/im, tap).  Returns loss; var_est[2] = C/(N-Mh) (DP:137).
+ * Optional work arrays (may be NULL) expose the intermediates the backward needs. */
+static REAL FN(dp_loss_core)(int B, int sps, int M, int n, const REAL *q, const REAL *x, const REAL *h, const REAL *amp,
+                             const REAL *P, REAL *var_est, REAL *Eq /*[2][2][L]*/, REAL *Var /*[2][2][L]*/,
+                             REAL *Dre /*[2][nm]*/, REAL *Dim, REAL *C /*[2]*/)
+{
+    const int L = B * sps, mh = M / 2, Mh = 2 * mh, nm = L - Mh;
+    for (int i = 0; i < 2 * 2 * L; i++) { Eq[i] = 0; Var[i] = 0; }
+    /* DP:107-113: E_q[x], E_q[x^2] on the zero-stuffed grid, Var = E[x^2]-E[x]^2 */
+    for (int v = 0; v < 2; v++)
+        for (int c = 0; c < 2; c++)
+            for (int nn = 0; nn < B; nn++) {
+                REAL mu = 0, rho = 0;
+                for (int i = 0; i < n; i++) {
+                    const REAL qq = q[(v * 2 * n + c * n + i) * B + nn];
+                    mu += amp[i] * qq;
+                    rho += (amp[i] * amp[i]) * qq;
+                }
+                Eq[(v * 2 + c) * L + nn * sps] = mu;
+                Var[(v * 2 + c) * L + nn * sps] = rho - mu * mu;
+            }
+    REAL E[2] = {0, 0};
+    for (int i = 0; i < 2 * nm; i++) { Dre[i] = 0; Dim[i] = 0; }
+    /* DP:123-129 */
+    for (int j = 0; j <= Mh; j++) {
+        REAL vs[2] = {0, 0};
+        for (int v = 0; v < 2; v++)
+            for (int c = 0; c < 2; c++)
+                for (int t = 0; t < nm; t++) vs[v] += Var[(v * 2 + c) * L + t + Mh - j];   /* DP:128 */
+        for (int chi = 0; chi < 2; chi++) {
+            for (int v = 0; v < 2; v++) {
+                const REAL hr = h[((chi * 2 + v) * 2 + 0) * M + j], hi = h[((chi * 2 + v) * 2 + 1) * M + j];
+                for (int t = 0; t < nm; t++) {
+                    const REAL eI = Eq[(v * 2 + 0) * L + t + Mh - j], eQ = Eq[(v * 2 + 1) * L + t + Mh - j];
+                    Dre[chi * nm + t] += hr * eI - hi * eQ;    /* DP:124-125 */
+                    Dim[chi * nm + t] += hi * eI + hr * eQ;    /* DP:126-127 */
+                }
+                E[chi] += (hr * hr + hi * hi) * vs[v];         /* DP:115,129 */
+            }
+        }
+    }
+    /* DP:131-132: q log(q/P + 1e-12) over SYMBOL indices mh .. B-mh-1 */
+    REAL ent = 0;
+    for (int v = 0; v < 2; v++)
+        for (int r = 0; r < 2 * n; r++)
+            for (int nn = mh; nn < B - mh; nn++) {
+                const REAL qq = q[(v * 2 * n + r) * B + nn];
+                ent += -qq * FN(r_log)(qq / P[r % n] + (REAL)1e-12);
+            }
+    /* DP:133-134 */
+    REAL loss = 0;
+    for (int chi = 0; chi < 2; chi++) {
+        REAL s_xx = 0, s_xd = 0, s_dd = 0;
+        for (int t = 0; t < nm; t++) {
+            const REAL xr = x[(chi * 2 + 0) * L + mh + t], xi = x[(chi * 2 + 1) * L + mh + t];
+            s_xx += xr * xr + xi * xi;
+            s_xd += xr * Dre[chi * nm + t] + xi * Dim[chi * nm + t];
+            s_dd += Dre[chi * nm + t] * Dre[chi * nm + t] + Dim[chi * nm + t] * Dim[chi * nm + t];
+        }
+        C[chi] = s_xx - 2 * s_xd + s_dd + E[chi];
+        loss += (REAL)nm * FN(r_log)(C[chi]);                   /* DP:136 */
+        var_est[chi] = C[chi] / (REAL)nm;                       /* DP:137 */
+    }
+    return loss - ent;
+}
+
+REAL FN(vaeq_oracle_dp_loss)(int B, int sps, int M, int n, const REAL *q, const REAL *x, const REAL *h, const REAL *amp,
+                             const REAL *P, REAL *var_est)
+{
+    const int L = B * sps, nm = L - 2 * (M / 2);
+    REAL *buf = (REAL *)malloc(sizeof(REAL) * (8 * L + 4 * nm));
+    REAL C[2];
+    REAL loss = FN(dp_loss_core)(B, sps, M, n, q, x, h, amp, P, var_est, buf, buf + 4 * L, buf + 8 * L, buf + 8 * L + 2 * nm, C);
+    free(buf);
+    return loss;
+}
+
+/* --------------------------------------------------------------------- R4
+ * loss.backward() (LEDP:65) restated: forward DP:500-527 + DP:92-137, then the
+ * chain rule node by node.  Outputs q, out, loss, var_est and gW[2][4][M],
+ * gh[2][2][2][M]. */
+REAL FN(vaeq_oracle_dp_step_grads)(int B, int sps, int M, int n, const REAL *x, const REAL *W, const REAL *h,
+                                   const REAL *amp, const REAL *P, const REAL *var, REAL nu_sc, REAL *q, REAL *out,
+                                   REAL *var_est, REAL *gW, REAL *gh)
+{
+    const int L = B * sps, mh = M / 2, Mh = 2 * mh, nm = L - Mh, pad = M / 2;
+    REAL *buf = (REAL *)malloc(sizeof(REAL) * (16 * L + 4 * nm + 4 * B));
+    REAL *Eq = buf, *Var = buf + 4 * L, *gEq = buf + 8 * L, *gVar = buf + 12 * L;
+    REAL *Dre = buf + 16 * L, *Dim = Dre + 2 * nm, *gy = Dim + 2 * nm; /* gy[2][2][B] */
+    REAL C[2], gC[2];
+
+    FN(vaeq_oracle_dp_forward)(B, sps, M, n, x, W, amp, var, nu_sc, q, out);
+    REAL loss = FN(dp_loss_core)(B, sps, M, n, q, x, h, amp, P, var_est, Eq, Var, Dre, Dim, C);
+
+    for (int chi = 0; chi < 2; chi++) gC[chi] = (REAL)nm / C[chi];          /* d(nm log C)/dC */
+    for (int i = 0; i < 4 * L; i++) { gEq[i] = 0; gVar[i] = 0; }
+    for (int i = 0; i < 2 * 2 * 2 * M; i++) gh[i] = 0;
+
+    /* dC/dD = -2 (x - D)   (from  sum x^2 - 2 sum x.D + sum D^2, DP:133-134) */
+    for (int chi = 0; chi < 2; chi++)
+        for (int v = 0; v < 2; v++)
+            for (int j = 0; j <= Mh; j++) {
+                const REAL hr = h[((chi * 2 + v) * 2 + 0) * M + j], hi = h[((chi * 2 + v) * 2 + 1) * M + j];
+                REAL ghr = 0, ghi = 0, vs = 0;
+                for (int t = 0; t < nm; t++) {
+                    const int s = t + Mh - j;
+                    const REAL dDr = -2 * (x[(chi * 2 + 0) * L + mh + t] - Dre[chi * nm + t]) * gC[chi];
+                    const REAL dDi = -2 * (x[(chi * 2 + 1) * L + mh + t] - Dim[chi * nm + t]) * gC[chi];
+                    const REAL eI = Eq[(v * 2 + 0) * L + s], eQ = Eq[(v * 2 + 1) * L + s];
+                    /* D_re += hr*eI - hi*eQ ; D_im += hi*eI + hr*eQ   (DP:124-127) */
+                    ghr += dDr * eI + dDi * eQ;
+                    ghi += -dDr * eQ + dDi * eI;
+                    gEq[(v * 2 + 0) * L + s] += dDr * hr + dDi * hi;
+                    gEq[(v * 2 + 1) * L + s] += -dDr * hi + dDi * hr;
+                    /* E += |h|^2 * Var_sum  (DP:128-129) */
+                    gVar[(v * 2 + 0) * L + s] += gC[chi] * (hr * hr + hi * hi);
+                    gVar[(v * 2 + 1) * L + s] += gC[chi] * (hr * hr + hi * hi);
+                    vs += Var[(v * 2 + 0) * L + s] + Var[(v * 2 + 1) * L + s];
+                }
+                gh[((chi * 2 + v) * 2 + 0) * M + j] = ghr + gC[chi] * 2 * hr * vs;
+                gh[((chi * 2 + v) * 2 + 1) * M + j] = ghi + gC[chi] * 2 * hi * vs;
+            }
+    /* Var = Eq2 - Eq^2 (DP:113) */
+    for (int i = 0; i < 4 * L; i++) gEq[i] += -2 * Eq[i] * gVar[i];
+
+    /* per symbol: dL/dq_i -> softmin backward -> dL/dy  (DP:107-112, 131-132, 521-523) */
+    for (int o = 0; o < 2; o++)
+        for (int c = 0; c < 2; c++)
+            for (int nn = 0; nn < B; nn++) {
+                const REAL gmu = gEq[(o * 2 + c) * L + nn * sps], grho = gVar[(o * 2 + c) * L + nn * sps];
+                const REAL y = out[(o * 2 + c) * B + nn];
+                const int inr = (nn >= mh && nn < B - mh);
+                REAL gq[MAXLEV], dot = 0;
+                for (int i = 0; i < n; i++) {
+                    const REAL qq = q[(o * 2 * n + c * n + i) * B + nn];
+                    gq[i] = amp[i] * gmu + (amp[i] * amp[i]) * grho;
+                    if (inr) {
+                        const REAL r = qq / P[i], re = r + (REAL)1e-12;
+                        gq[i] += FN(r_log)(re) + r / re;        /* d/dq [ q log(q/P+eps) ] */
+                    }
+                    dot += qq * gq[i];
+                }
+                REAL g = 0;
+                for (int i = 0; i < n; i++) {
+                    const REAL qq = q[(o * 2 * n + c * n + i) * B + nn];
+                    const REAL gz = qq * (gq[i] - dot);          /* softmax backward wrt logits z=-cost */
+                    g += gz * (-(y - amp[i]) / var[o]);           /* dz_i/dy */
+                }
+                gy[(o * 2 + c) * B + nn] = g;
+            }
+    /* conv weight gradient through the channel packing DP:505,507 */
+    for (int o = 0; o < 2; o++)
+        for (int ch = 0; ch < 4; ch++) {
+            const int p = ch & 1, neg = ch >> 1;
+            for (int k = 0; k < M; k++) {
+                REAL acc = 0;
+                for (int nn = 0; nn < B; nn++) {
+                    const int s = nn * sps + k - pad;
+                    if (s < 0 || s >= L) continue;
+                    const REAL xi = x[(p * 2 + 0) * L + s], xq = x[(p * 2 + 1) * L + s];
+                    const REAL inI = neg ? -xq : xi, inQ = neg ? xi : xq;
+                    acc += gy[(o * 2 + 0) * B + nn] * inI + gy[(o * 2 + 1) * B + nn] * inQ;
+                }
+                gW[(o * 4 + ch) * M + k] = acc;
+            }
+        }
+    free(buf);
+    return loss;
+}
+
+/* --------------------------------------------------------------------- R5
+ * torch.optim.Adam single-tensor step (LEDP:28,31,66; AWGN:283 with amsgrad).
+ * Scalar prep in double like the Python side of torch.optim.adam; tensor math in REAL.
+ * step is the step count AFTER the increment (1 for the first update). */
+void FN(vaeq_oracle_adam)(int cnt, REAL *p, const REAL *g, REAL *m, REAL *v, REAL *vmax, int step, double lr, int amsgrad)
+{
+    const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
+    const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+    const REAL step_size = (REAL)(lr / bc1), bc2_sqrt = (REAL)sqrt(bc2);
+    const REAL w1 = (REAL)(1.0 - b1), w2 = (REAL)(1.0 - b2), fb2 = (REAL)b2, feps = (REAL)eps;
+    for (int i = 0; i < cnt; i++) {
+#if REAL_IS_FLOAT
+        m[i] = fmaf(g[i] - m[i], w1, m[i]);                      /* exp_avg.lerp_(grad, 1-beta1) */
+#else
+        m[i] = fma(g[i] - m[i], w1, m[i]);
+#endif
+        v[i] = v[i] * fb2;
+        v[i] = v[i] + w2 * g[i] * g[i];                          /* mul_(beta2).addcmul_(g,g,1-beta2) */
+        REAL vv = v[i];
+        if (amsgrad) { if (v[i] > vmax[i]) vmax[i] = v[i]; vv = vmax[i]; }
+        const REAL denom = FN(r_sqrt)(vv) / bc2_sqrt + feps;
+        p[i] = p[i] + (-step_size * m[i]) / denom;               /* addcdiv_(m, denom, -step_size) */
+    }
+}
+
+/* ------------------------------------------------------------------ R6/R7
+ * One frame of the DP minibatch loop for ONE run.
+ *   VAE-LE (LEDP:57-66):  stride = keep_len = B, keep_off = 0
+ *   VAEflex (FLEX:59-70): stride = keep_len = flex_step, keep_off = (B-flex_step)/2
+ * rx[2][2][S]; window of step s starts at symbol s*stride.  q_out[2][2n][n_steps*keep_len],
+ * y_out[2][2][n_steps*keep_len], loss[n_steps], var_est[2][n_steps].  State (W,h,Adam m/v,
+ * step counter) is caller-owned and updated in place. */
+void FN(vaeq_oracle_dp_train)(int n_steps, int B, int sps, int M, int n, int stride, int keep_off, int keep_len, int S,
+                              const REAL *rx, REAL *W, REAL *h, REAL *mW, REAL *vW, REAL *mh_, REAL *vh, int *step,
+                              const REAL *amp, const REAL *P, const REAL *var, REAL nu_sc, double lr_W, double lr_h,
+                              REAL *q_out, REAL *y_out, REAL *loss, REAL *var_est)
+{
+    const int L = B * sps, No = n_steps * keep_len;
+    REAL *mb = (REAL *)malloc(sizeof(REAL) * (4 * L + 4 * n * B + 4 * B + 8 * M + 8 * M));
+    REAL *q = mb + 4 * L, *out = q + 4 * n * B, *gW = out + 4 * B, *gh = gW + 8 * M;
+    for (int s = 0; s < n_steps; s++) {
+        const int s0 = s * stride * sps;
+        for (int r = 0; r < 4; r++) memcpy(mb + r * L, rx + (size_t)r * S + s0, sizeof(REAL) * L);   /* LEDP:58 / FLEX:60 */
+        REAL ve[2];
+        loss[s] = FN(vaeq_oracle_dp_step_grads)(B, sps, M, n, mb, W, h, amp, P, var, nu_sc, q, out, ve, gW, gh);
+        var_est[0 * n_steps + s] = ve[0];
+        var_est[1 * n_steps + s] = ve[1];
+        if (q_out)
+            for (int r = 0; r < 4 * n; r++)
+                memcpy(q_out + (size_t)r * No + s * keep_len, q + r * B + keep_off, sizeof(REAL) * keep_len);
+        if (y_out)
+            for (int r = 0; r < 4; r++)
+                memcpy(y_out + (size_t)r * No + s * keep_len, out + r * B + keep_off, sizeof(REAL) * keep_len);
+        *step += 1;
+        FN(vaeq_oracle_adam)(8 * M, W, gW, mW, vW, NULL, *step, lr_W, 0);
+        FN(vaeq_oracle_adam)(8 * M, h, gh, mh_, vh, NULL, *step, lr_h, 0);
+    }
+    free(mb);
+}
+
+/* ================================================================== AWGN */
+
+/* R8: twoFIR.forward, AWGN:214-231.  x[2][L], W[1][2][M] (pad=(M-1)/2, AWGN:209):
+ *   out_I = W0*x0 + W1*x1,  out_Q = W0*x1 - W1*x0   (AWGN:216-219)
+ * normalised yhat_c = y_c / mean|y_c| * amp_mean (AWGN:228); q = softmin((yhat-a)^2/var) (AWGN:229).
+ * Returns the UN-normalised out[2][B] (AWGN:227,231) and q[2n][B]; ynorm (may be NULL) gets yhat. */
+void FN(vaeq_oracle_awgn_forward)(int B, int sps, int M, int n, const REAL *x, const REAL *W, const REAL *amp,
+                                  REAL amp_mean, REAL var, REAL *q, REAL *out, REAL *ynorm, REAL *mabs)
+{
+    const int L = B * sps, pad = (M - 1) / 2;
+    for (int nn = 0; nn < B; nn++) {
+        REAL aI = 0, aQ = 0;
+        for (int k = 0; k < M; k++) {
+            const int s = nn * sps + k - pad;
+            if (s < 0 || s >= L) continue;
+            aI += W[k] * x[s] + W[M + k] * x[L + s];
+            aQ += W[k] * x[L + s] - W[M + k] * x[s];
+        }
+        out[nn] = aI;
+        out[B + nn] = aQ;
+    }
+    for (int c = 0; c < 2; c++) {
+        REAL ma = 0;
+        for (int nn = 0; nn < B; nn++) ma += FN(r_abs)(out[c * B + nn]);
+        ma /= (REAL)B;
+        if (mabs) mabs[c] = ma;
+        for (int nn = 0; nn < B; nn++) {
+            const REAL yh = out[c * B + nn] / ma * amp_mean;
+            if (ynorm) ynorm[c * B + nn] = yh;
+            REAL cost[MAXLEV], qq[MAXLEV];
+            for (int i = 0; i < n; i++) { const REAL d = yh - amp[i]; cost[i] = d * d / var; }
+            FN(softmin)(n, cost, qq);
+            for (int i = 0; i < n; i++) q[(c * n + i) * B + nn] = qq[i];
+        }
+    }
+}
+
+/* R9: loss_function, AWGN:63-95.  h[2][M] (re, im). */
+static REAL FN(awgn_loss_core)(int B, int sps, int M, int n, const REAL *q, const REAL *x, const REAL *h, const REAL *amp,
+                               const REAL *P, REAL *Eq /*[2][L]*/, REAL *Eq2, REAL *Dre /*[nm]*/, REAL *Dim, REAL *Cout)
+{
+    const int L = B * sps, mh = M / 2, Mh = 2 * mh, nm = L - Mh;
+    for (int i = 0; i < 2 * L; i++) { Eq[i] = 0; Eq2[i] = 0; }
+    for (int c = 0; c < 2; c++)
+        for (int nn = 0; nn < B; nn++) {
+            REAL mu = 0, rho = 0;
+            for (int i = 0; i < n; i++) {
+                const REAL qq = q[(c * n + i) * B + nn];
+                mu += amp[i] * qq;
+                rho += (amp[i] * amp[i]) * qq;
+            }
+            Eq[c * L + nn * sps] = mu;                           /* AWGN:77 */
+            Eq2[c * L + nn * sps] = rho;                         /* AWGN:78 */
+        }
+    REAL sE = 0;
+    for (int t = 0; t < nm; t++) { Dre[t] = 0; Dim[t] = 0; }
+    for (int j = 0; j <= Mh; j++) {                              /* AWGN:85-88 */
+        const REAL hr = h[j], hi = h[M + j];
+        for (int t = 0; t < nm; t++) {
+            const int s = t + Mh - j;
+            Dre[t] += hr * Eq[s] - hi * Eq[L + s];
+            Dim[t] += hr * Eq[L + s] + hi * Eq[s];
+            sE += (hr * hr + hi * hi) * ((Eq2[s] - Eq[s] * Eq[s]) + (Eq2[L + s] - Eq[L + s] * Eq[L + s]));
+        }
+    }
+    REAL ent = 0;                                                /* AWGN:90-91 */
+    for (int r = 0; r < 2 * n; r++)
+        for (int nn = mh; nn < B - mh; nn++) {
+            const REAL qq = q[r * B + nn];
+            ent += -qq * FN(r_log)(qq / P[r % n] + (REAL)1e-12);
+        }
+    REAL s_xx = 0, s_xd = 0, s_dd = 0;                           /* AWGN:92-93 */
+    for (int t = 0; t < nm; t++) {
+        const REAL xr = x[mh + t], xi = x[L + mh + t];
+        s_xx += xr * xr + xi * xi;
+        s_xd += xr * Dre[t] + xi * Dim[t];
+        s_dd += Dre[t] * Dre[t] + Dim[t] * Dim[t];
+    }
+    const REAL C = s_xx - 2 * s_xd + s_dd + sE;
+    *Cout = C;
+    return (REAL)nm * FN(r_log)(C) - ent;                        /* AWGN:94 */
+}
+
+REAL FN(vaeq_oracle_awgn_loss)(int B, int sps, int M, int n, const REAL *q, const REAL *x, const REAL *h, const REAL *amp,
+                               const REAL *P)
+{
+    const int L = B * sps, nm = L - 2 * (M / 2);
+    REAL *buf = (REAL *)malloc(sizeof(REAL) * (4 * L + 2 * nm));
+    REAL C;
+    REAL loss = FN(awgn_loss_core)(B, sps, M, n, q, x, h, amp, P, buf, buf + 2 * L, buf + 4 * L, buf + 4 * L + nm, &C);
+    free(buf);
+    return loss;
+}
+
+/* AWGN forward + loss + backward (AWGN:302-305): gW[1][2][M], gh[2][M] */
+REAL FN(vaeq_oracle_awgn_step_grads)(int B, int sps, int M, int n, const REAL *x, const REAL *W, const REAL *h,
+                                     const REAL *amp, const REAL *P, REAL amp_mean, REAL var, REAL *q, REAL *out,
+                                     REAL *gW, REAL *gh)
+{
+    const int L = B * sps, mh = M / 2, Mh = 2 * mh, nm = L - Mh, pad = (M - 1) / 2;
+    REAL *buf = (REAL *)malloc(sizeof(REAL) * (8 * L + 2 * nm + 6 * B));
+    REAL *Eq = buf, *Eq2 = buf + 2 * L, *gEq = buf + 4 * L, *gEq2 = buf + 6 * L;
+    REAL *Dre = buf + 8 * L, *Dim = Dre + nm, *yh = Dim + nm, *gyh = yh + 2 * B, *gy = gyh + 2 * B;
+    REAL mabs[2], C;
+
+    FN(vaeq_oracle_awgn_forward)(B, sps, M, n, x, W, amp, amp_mean, var, q, out, yh, mabs);
+    REAL loss = FN(awgn_loss_core)(B, sps, M, n, q, x, h, amp, P, Eq, Eq2, Dre, Dim, &C);
+    const REAL gC = (REAL)nm / C;
+    for (int i = 0; i < 2 * L; i++) { gEq[i] = 0; gEq2[i] = 0; }
+    for (int j = 0; j <= Mh; j++) {
+        const REAL hr = h[j], hi = h[M + j], hh = hr * hr + hi * hi;
+        REAL ghr = 0, ghi = 0, vs = 0;
+        for (int t = 0; t < nm; t++) {
+            const int s = t + Mh - j;
+            const REAL dDr = -2 * (x[mh + t] - Dre[t]) * gC, dDi = -2 * (x[L + mh + t] - Dim[t]) * gC;
+            /* D_re += hr*Eq0 - hi*Eq1 ; D_im += hr*Eq1 + hi*Eq0  (AWGN:86-87) */
+            ghr += dDr * Eq[s] + dDi * Eq[L + s];
+            ghi += -dDr * Eq[L + s] + dDi * Eq[s];
+            gEq[s] += dDr * hr + dDi * hi;
+            gEq[L + s] += -dDr * hi + dDi * hr;
+            /* E term AWGN:88 */
+            gEq2[s] += gC * hh;
+            gEq2[L + s] += gC * hh;
+            gEq[s] += gC * hh * (-2 * Eq[s]);
+            gEq[L + s] += gC * hh * (-2 * Eq[L + s]);
+            vs += (Eq2[s] - Eq[s] * Eq[s]) + (Eq2[L + s] - Eq[L + s] * Eq[L + s]);
+        }
+        gh[j] = ghr + gC * 2 * hr * vs;
+        gh[M + j] = ghi + gC * 2 * hi * vs;
+    }
+    for (int c = 0; c < 2; c++)
+        for (int nn = 0; nn < B; nn++) {
+            const REAL gmu = gEq[c * L + nn * sps], grho = gEq2[c * L + nn * sps];
+            const REAL y = yh[c * B + nn];
+            const int inr = (nn >= mh && nn < B - mh);
+            REAL gq[MAXLEV], dot = 0;
+            for (int i = 0; i < n; i++) {
+                const REAL qq = q[(c * n + i) * B + nn];
+                gq[i] = amp[i] * gmu + (amp[i] * amp[i]) * grho;
+                if (inr) {
+                    const REAL r = qq / P[i], re = r + (REAL)1e-12;
+                    gq[i] += FN(r_log)(re) + r / re;
+                }
+                dot += qq * gq[i];
+            }
+            REAL g = 0;
+            for (int i = 0; i < n; i++) {
+                const REAL qq = q[(c * n + i) * B + nn];
+                g += qq * (gq[i] - dot) * (-2 * (y - amp[i]) / var);   /* cost=(yhat-a)^2/var, AWGN:229 */
+            }
+            gyh[c * B + nn] = g;
+        }
+    /* normalisation yhat = y / mean|y| * A  (AWGN:228) */
+    for (int c = 0; c < 2; c++) {
+        REAL dot = 0;
+        for (int nn = 0; nn < B; nn++) dot += gyh[c * B + nn] * out[c * B + nn];
+        for (int nn = 0; nn < B; nn++) {
+            const REAL y = out[c * B + nn];
+            const REAL sg = (y > 0) - (y < 0);
+            gy[c * B + nn] = gyh[c * B + nn] * amp_mean / mabs[c] - dot * amp_mean / (mabs[c] * mabs[c]) * sg / (REAL)B;
+        }
+    }
+    for (int k = 0; k < M; k++) {
+        REAL g0 = 0, g1 = 0;
+        for (int nn = 0; nn < B; nn++) {
+            const int s = nn * sps + k - pad;
+            if (s < 0 || s >= L) continue;
+            g0 += gy[nn] * x[s] + gy[B + nn] * x[L + s];
+            g1 += gy[nn] * x[L + s] - gy[B + nn] * x[s];
+        }
+        gW[k] = g0;
+        gW[M + k] = g1;
+    }
+    free(buf);
+    return loss;
+}
+
+/* R10: AWGN minibatch loop with Adam(amsgrad=True), AWGN:283,297-306 */
+void FN(vaeq_oracle_awgn_train)(int n_steps, int B, int sps, int M, int n, int S, const REAL *rx, REAL *W, REAL *h,
+                                REAL *mW, REAL *vW, REAL *vmaxW, REAL *mh_, REAL *vh, REAL *vmaxh, int *step,
+                                const REAL *amp, const REAL *P, REAL amp_mean, REAL var, double lr, REAL *loss)
+{
+    const int L = B * sps;
+    REAL *mb = (REAL *)malloc(sizeof(REAL) * (2 * L + 2 * n * B + 2 * B + 4 * M));
+    REAL *q = mb + 2 * L, *out = q + 2 * n * B, *gW = out + 2 * B, *gh = gW + 2 * M;
+    for (int s = 0; s < n_steps; s++) {
+        for (int r = 0; r < 2; r++) memcpy(mb + r * L, rx + (size_t)r * S + s * L, sizeof(REAL) * L);   /* AWGN:299 */
+        loss[s] = FN(vaeq_oracle_awgn_step_grads)(B, sps, M, n, mb, W, h, amp, P, amp_mean, var, q, out, gW, gh);
+        *step += 1;
+        FN(vaeq_oracle_adam)(2 * M, W, gW, mW, vW, vmaxW, *step, lr, 1);
+        FN(vaeq_oracle_adam)(2 * M, h, gh, mh_, vh, vmaxh, *step, lr, 1);
+    }
+    free(mb);
+}
+
+#undef FN
+#undef CAT
+#undef CAT_
+#undef MAXLEV
