@@ -1,0 +1,119 @@
+/*
+ * vaeq.h -- C ABI of libvaeq_hip.so: the MI355X (gfx950) implementation of the
+ * VAE blind-equalizer training inner loop of kit-cel/vae-equalizer.
+ *
+ * The reference has no FFI: its "operator interface" for this path is a set of
+ * Python callables.  Each entry point below names the
+ * reference code it replaces (paths relative to the reference tree) and is what
+ * a binding of that code would call; INTEGRATION.md shows the ctypes stubs.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer to row-major fp32 unless noted;
+ *   - the caller owns all buffers; kernels keep no state between calls
+ *     (equalizer taps, channel estimate, Adam moments and step counters are
+ *     caller-owned arrays that are updated in place);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls
+ *     are asynchronous with respect to the host;
+ *   - return value: 0 = ok, negative = error (vaeq_strerror), never throws;
+ *   - one "run" = one independent Monte-Carlo run / sweep point
+ *     (optical_DP_channel/Eval_run_DP.py:68-86); runs never communicate.
+ */
+#ifndef VAEQ_H
+#define VAEQ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VAEQ_VERSION 100
+
+enum {
+    VAEQ_OK = 0,
+    VAEQ_ERR_NULL = -1,      /* a required pointer is NULL */
+    VAEQ_ERR_SHAPE = -2,     /* inconsistent or unsupported sizes (even M, n_lev not in {2,4,8}, window past S ...) */
+    VAEQ_ERR_LDS = -3,       /* the per-run working set does not fit the 160 KiB LDS of a CU */
+    VAEQ_ERR_LAUNCH = -4,    /* HIP launch error (hipGetLastError) */
+    VAEQ_ERR_DEVICE = -5     /* not a gfx950 device / no device */
+};
+
+/* ------------------------------------------------------------------------
+ * Dual-polarisation VAE-LE / VAEflex training loop.
+ *
+ * Replaces, for R independent runs at once, the minibatch loop
+ *   optical_DP_channel/func_VAELE_DP_MQAM_shaping.py:57-66   (VAE-LE)
+ *   optical_DP_channel/func_VAEflex_DP_MQAM_shaping.py:59-70 (VAEflex)
+ * i.e. per step: twoXtwoFIR.forward (shared_funcs.py:500-527), loss_function_shaping
+ * (shared_funcs.py:92-137), loss.backward(), optim.Adam.step() for both parameter
+ * groups (func_VAELE_DP_MQAM_shaping.py:28,31), and the copies into
+ * out_train / out_const / var_est (:61-62,64).
+ *
+ * Window of step s of frame f starts at symbol s*stride_sym of that frame's row
+ * and spans B symbols (= B*sps samples, zero-padded by M/2 samples on both sides
+ * exactly like Conv1d(padding=M//2), shared_funcs.py:494).
+ *   VAE-LE : stride_sym = B,         keep_off = 0,               keep_len = B
+ *   VAEflex: stride_sym = flex_step, keep_off = (B-flex_step)/2, keep_len = flex_step
+ */
+typedef struct vaeq_dp_args {
+    int32_t R;           /* independent runs in this call (one workgroup each) */
+    int32_t n_frames;    /* frames per run held in rx (taps/Adam state carry across frames) */
+    int32_t steps;       /* minibatch steps per frame */
+    int32_t B;           /* batch_len: symbols per minibatch window */
+    int32_t sps;         /* samples per symbol (reference: 2) */
+    int32_t M;           /* M_est: taps of the butterfly FIR and of h_est; odd, <= 63 */
+    int32_t n_lev;       /* ASK levels per axis: 2, 4 or 8 (4-/16-/64-QAM) */
+    int32_t stride_sym;  /* symbols between consecutive window starts */
+    int32_t keep_off;    /* first window-local symbol copied to q_out / y_out */
+    int32_t keep_len;    /* number of window-local symbols copied per step */
+    int64_t S;           /* samples per (run, frame, pol, I/Q) row of rx */
+    const float *rx;     /* [R][n_frames][2 pol][2 I/Q][S]   received samples (rx_tensor, shared_funcs.py:88) */
+    float *W;            /* [R][2][4][M]     FIR weight, nn.Conv1d(4,2,M) layout (shared_funcs.py:494) */
+    float *h;            /* [R][2][2][2][M]  h_est[chi][nu][re/im][tap] (shared_funcs.py:583-586) */
+    float *adam_mW, *adam_vW;   /* [R][2][4][M]     exp_avg / exp_avg_sq of W */
+    float *adam_mh, *adam_vh;   /* [R][2][2][2][M]  exp_avg / exp_avg_sq of h */
+    int32_t *step;       /* [R] Adam step count (in: steps done so far; out: += n_frames*steps) */
+    const float *amp;    /* [n_lev]    amp_levels, shared by all runs (shared_funcs.py:568) */
+    const float *P;      /* [R][n_lev] PCS pmf of the levels (shared_funcs.py:572) */
+    const float *var;    /* [R][2]     demapper noise variance per polarisation (shared_funcs.py:581) */
+    const float *nu_sc;  /* [R]        rescaled shaping factor (shared_funcs.py:570) */
+    const float *lr_W;   /* [R] learning rate of param group 0 (W) for this call (func_VAELE_DP...:45-46) */
+    const float *lr_h;   /* [R] learning rate of param group 1 (h_est) */
+    float *q_out;        /* nullable [R][n_frames][2][2*n_lev][steps*keep_len]  out_train */
+    float *y_out;        /* nullable [R][n_frames][2][2][steps*keep_len]        out_const */
+    float *loss;         /* nullable [R][n_frames][steps]                        ELBO per minibatch */
+    float *var_est;      /* nullable [R][n_frames][2][steps]                     C/(N-Mh) per minibatch */
+    float *dbg_gW;       /* nullable [R][2][4][M]     gradient of the LAST step (parity tests) */
+    float *dbg_gh;       /* nullable [R][2][2][2][M] */
+    int32_t threads;     /* workgroup size per run: 0 = library default, else 64 / 128 / 256 */
+    int32_t no_update;   /* 1: skip the Adam update (forward + loss + gradients only) */
+} vaeq_dp_args;
+
+int vaeq_dp_train(const vaeq_dp_args *args, void *stream);
+
+/* LDS bytes one run (= one workgroup) needs for the given shape, or a negative error code. */
+int64_t vaeq_dp_lds_bytes(int32_t B, int32_t sps, int32_t M, int32_t n_lev);
+
+/* ------------------------------------------------------------------------
+ * Stand-alone soft demapper:  shared_funcs.py:529-542 (soft_dec), the same
+ * formula as the demapping half of twoXtwoFIR.forward (shared_funcs.py:521-523).
+ * y[R][2][2][N] -> q[R][2][2*n_lev][N];  amp[n_lev]; var[R][2]; nu_sc[R].
+ */
+int vaeq_soft_demap(int32_t R, int64_t N, int32_t n_lev, const float *y, const float *amp, const float *var,
+                    const float *nu_sc, float *q, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Butterfly FIR + soft demapper without training (twoXtwoFIR.forward in eval
+ * mode, shared_funcs.py:500-527) on one zero-padded block of N symbols per run:
+ * x[R][2][2][N*sps], W[R][2][4][M] -> q[R][2][2*n_lev][N] (nullable), y[R][2][2][N].
+ */
+int vaeq_dp_forward(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, const float *x, const float *W,
+                    const float *amp, const float *var, const float *nu_sc, float *q, float *y, void *stream);
+
+int vaeq_version(void);
+const char *vaeq_strerror(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAEQ_H */

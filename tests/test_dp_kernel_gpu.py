@@ -1,0 +1,194 @@
+"""GPU parity of the fused DP training kernel (through the C ABI) against the golden vectors captured from the
+reference and against the CPU oracle on the same inputs.
+
+Tolerances (fp32): per-minibatch ELBO <= 1e-5 relative (north_star); taps after teacher-forced / short free runs
+<= 1e-5 absolute (taps are O(1)); q <= 2e-4 absolute (steep softmin); gradients <= 1e-4 of their max.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+G1 = ["G1_dp_step_64qam_pcs", "G1_dp_step_64qam", "G1_dp_step_16qam", "G1_dp_step_4qam"]
+DEV = "cuda:0"
+
+
+def _engine(g, R=1, threads=0):
+    from vae_equalizer_amd.engine import DPEngine
+    return DPEngine(R, int(g["M_est"]), g["amp_levels"], g["P"], g["var"], float(g["nu_sc"]), DEV, int(g["sps"]), threads)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("threads", [64, 128, 256])
+@pytest.mark.parametrize("name", G1)
+def test_teacher_forced_step(name, threads):
+    """One minibatch from a random (non-Dirac) state: q, y, ELBO, var_est, gradients, and the Adam update (R1-R5)."""
+    g = load_golden(name)
+    B, sps = int(g["B"]), int(g["sps"])
+    eng = _engine(g, threads=threads)
+    eng.set_state(g["W0"], g["h0"])
+    rx = torch.from_numpy(g["rx"][None, :, :, :B * sps]).to(DEV)
+    r = eng.train(rx, B, 1, float(g["lr"]), debug_grads=True)
+    torch.cuda.synchronize()
+    assert relerr(_np(r["y"])[0, 0], g["out0"]) < 2e-6
+    assert np.max(np.abs(_np(r["q"])[0, 0] - g["q0"])) < 2e-4
+    assert abs(_np(r["loss"])[0, 0, 0] - g["loss0"]) / abs(g["loss0"]) < 1e-5
+    assert relerr(_np(r["var_est"])[0, 0, :, 0], g["var_est0"]) < 1e-5
+    assert relerr(_np(r["gh"])[0], g["gh0"]) < 2e-5
+    assert relerr(_np(r["gW"])[0], g["gW0"]) < 1e-4
+    # truth check: at least as close to the f64 oracle as the reference's own fp32 result is (x3 slack)
+    t = oracle.dp_step_grads(g["rx"][:, :, :B * sps], g["W0"], g["h0"], g["amp_levels"], g["P"], g["var"], float(g["nu_sc"]), sps, np.float64)
+    assert relerr(_np(r["gW"])[0], t["gW"]) < max(3 * relerr(g["gW0"], t["gW"]), 2e-6)
+    assert relerr(_np(r["gh"])[0], t["gh"]) < max(3 * relerr(g["gh0"], t["gh"]), 2e-6)
+    assert abs(_np(r["loss"])[0, 0, 0] - t["loss"]) / abs(t["loss"]) < 1e-5
+    # Adam: taps after the step; moments
+    assert np.max(np.abs(_np(eng.W)[0] - g["W1"])) < 1e-5
+    assert np.max(np.abs(_np(eng.h)[0] - g["h1"])) < 1e-5
+    assert int(eng.step[0]) == 1
+
+
+@pytest.mark.parametrize("name", G1)
+def test_three_steps_and_moments(name):
+    g = load_golden(name)
+    B = int(g["B"])
+    eng = _engine(g)
+    eng.set_state(g["W0"], g["h0"])
+    rx = torch.from_numpy(g["rx"][None]).to(DEV)
+    r = eng.train(rx, B, 3, float(g["lr"]))
+    torch.cuda.synchronize()
+    for s in range(3):
+        assert abs(_np(r["loss"])[0, 0, s] - g[f"loss{s}"]) / abs(g[f"loss{s}"]) < 2e-5
+    assert np.max(np.abs(_np(eng.W)[0] - g["W3"])) < 2e-5
+    assert np.max(np.abs(_np(eng.h)[0] - g["h3"])) < 2e-5
+    assert relerr(_np(eng.mW)[0], g["mW"]) < 1e-4 and relerr(_np(eng.vW)[0], g["vW"]) < 1e-4
+    assert relerr(_np(eng.mh)[0], g["mh"]) < 1e-4 and relerr(_np(eng.vh)[0], g["vh"]) < 1e-4
+    assert int(eng.step[0]) == 3
+
+
+def test_no_update_leaves_state():
+    g = load_golden(G1[0])
+    B, sps = int(g["B"]), int(g["sps"])
+    eng = _engine(g)
+    eng.set_state(g["W0"], g["h0"])
+    rx = torch.from_numpy(g["rx"][None, :, :, :B * sps]).to(DEV)
+    eng.train(rx, B, 1, float(g["lr"]), no_update=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(_np(eng.W)[0], g["W0"]) and np.array_equal(_np(eng.h)[0], g["h0"])
+    assert int(eng.step[0]) == 0 and float(eng.mW.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("threads", [64, 256])
+def test_freerun_vaele_golden(threads):
+    """G2: 20 free-running steps from the Dirac start: ELBO per minibatch and taps <= 1e-5 (north_star)."""
+    g = load_golden("G2_dp_freerun")
+    B = int(g["B"])
+    eng = _engine(g, threads=threads)
+    rx = torch.from_numpy(g["rx"][None]).to(DEV)
+    r = eng.train(rx, B, 20, float(g["lr"]))
+    torch.cuda.synchronize()
+    loss = _np(r["loss"])[0, 0]
+    assert np.max(np.abs(loss - g["loss"][:20]) / np.abs(g["loss"][:20])) < 1e-5
+    assert np.max(np.abs(_np(eng.W)[0] - g["W_after20"])) < 1e-5
+    assert np.max(np.abs(_np(eng.h)[0] - g["h_after20"])) < 1e-5
+    assert relerr(_np(r["y"])[0, 0], g["out_const"][:, :, :20 * B]) < 3e-5
+    assert np.max(np.abs(_np(r["q"])[0, 0] - g["out_train"][:, :, :20 * B])) < 5e-4
+    assert relerr(_np(r["var_est"])[0, 0], g["var_est"][:, :20]) < 1e-5
+
+
+def test_freerun_flex_golden():
+    """G3: VAEflex windows (stride 10, centre slice kept), 30 steps."""
+    g = load_golden("G3_dp_flex_freerun")
+    B, fs, ns = int(g["B"]), int(g["flex_step"]), int(g["n_steps"])
+    eng = _engine(g)
+    rx = torch.from_numpy(g["rx"][None]).to(DEV)
+    r = eng.train(rx, B, ns, float(g["lr"]), stride=fs, keep_off=(B - fs) // 2, keep_len=fs)
+    torch.cuda.synchronize()
+    loss = _np(r["loss"])[0, 0]
+    assert np.max(np.abs(loss[:10] - g["loss"][:10]) / np.abs(g["loss"][:10])) < 1e-5
+    assert relerr(_np(r["y"])[0, 0][:, :, :10 * fs], g["out_const"][:, :, :10 * fs]) < 1e-5
+    assert np.max(np.abs(loss - g["loss"]) / np.abs(g["loss"])) < 1e-4
+    assert relerr(_np(r["y"])[0, 0], g["out_const"]) < 3e-4
+    assert np.max(np.abs(_np(eng.W)[0] - g[f"W_after{ns}"])) < 3e-4
+    assert np.max(np.abs(_np(eng.h)[0] - g[f"h_after{ns}"])) < 3e-4
+
+
+def test_batch_of_runs_matches_oracle():
+    """R=37 runs with different seeds / SNR / shaping / lr in one launch == 37 oracle runs (ragged sizes: B=37, M=9)."""
+    from vae_equalizer_amd.engine import DPEngine
+    rng = np.random.default_rng(5)
+    R, B, M, n, sps, steps = 37, 37, 9, 4, 2, 6
+    amp = np.array([-3, -1, 1, 3], np.float32) / np.sqrt(10).astype(np.float32)
+    P = rng.dirichlet(np.ones(n) * 5, R).astype(np.float32)
+    var = rng.uniform(0.002, 0.02, (R, 2)).astype(np.float32)
+    nu_sc = rng.uniform(0, 1, R).astype(np.float32)
+    lr = rng.uniform(1e-3, 4e-3, R).astype(np.float32)
+    rx = (0.4 * rng.standard_normal((R, 2, 2, steps * B * sps))).astype(np.float32)
+    eng = DPEngine(R, M, amp, P, var, nu_sc, DEV, sps)
+    r = eng.train(torch.from_numpy(rx).to(DEV), B, steps, lr)
+    torch.cuda.synchronize()
+    for i in range(R):
+        st = oracle.DPState(M, np.float32)
+        o = oracle.dp_train(st, rx[i], steps, B, amp, P[i], var[i], float(nu_sc[i]), float(lr[i]), float(lr[i]), sps)
+        assert np.max(np.abs(_np(r["loss"])[i, 0] - o["loss"]) / np.abs(o["loss"])) < 2e-5, i
+        assert np.max(np.abs(_np(eng.W)[i] - st.W)) < 2e-5, i
+        assert np.max(np.abs(_np(eng.h)[i] - st.h)) < 2e-5, i
+        assert relerr(_np(r["y"])[i, 0], o["out"]) < 2e-5, i
+
+
+def test_multi_frame_call_equals_frame_by_frame():
+    """n_frames=3 in one launch == three launches with state carried by the caller (bitwise)."""
+    g = load_golden("G2_dp_freerun")
+    B, sps = int(g["B"]), int(g["sps"])
+    rx = torch.from_numpy(g["rx"][:, :, :3 * 5 * B * sps]).to(DEV)
+    frames = rx.reshape(2, 2, 3, 5 * B * sps).permute(2, 0, 1, 3).contiguous()   # [F,2,2,S]
+    e1, e2 = _engine(g), _engine(g)
+    r1 = e1.train(frames[None], B, 5, float(g["lr"]))
+    l2 = [e2.train(frames[f][None, None], B, 5, float(g["lr"]))["loss"] for f in range(3)]
+    torch.cuda.synchronize()
+    assert torch.equal(r1["loss"][0], torch.cat([x[0] for x in l2]))
+    assert torch.equal(e1.W, e2.W) and torch.equal(e1.h, e2.h) and int(e1.step[0]) == 15
+
+
+def test_deterministic_bitwise():
+    g = load_golden("G2_dp_freerun")
+    rx = torch.from_numpy(g["rx"][None]).to(DEV)
+    outs = []
+    for _ in range(2):
+        eng = _engine(g)
+        r = eng.train(rx, int(g["B"]), 30, float(g["lr"]))
+        torch.cuda.synchronize()
+        outs.append((r["loss"].clone(), eng.W.clone(), r["q"].clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
+def test_soft_demap_and_forward_entry_points():
+    from vae_equalizer_amd.engine import dp_forward, soft_demap
+    g = load_golden(G1[0])
+    B, sps = int(g["B"]), int(g["sps"])
+    q = soft_demap(torch.from_numpy(g["out0"]).to(DEV), g["amp_levels"], g["var"], float(g["nu_sc"]))
+    assert np.max(np.abs(_np(q) - g["q0"])) < 2e-4
+    q2, y2 = dp_forward(torch.from_numpy(g["rx"][:, :, :B * sps]).to(DEV), torch.from_numpy(g["W0"]).to(DEV), g["amp_levels"],
+                        g["var"], float(g["nu_sc"]), sps)
+    assert relerr(_np(y2), g["out0"]) < 2e-6
+    assert np.max(np.abs(_np(q2) - g["q0"])) < 2e-4
+
+
+def test_error_codes():
+    from vae_equalizer_amd import _native as nat
+    from vae_equalizer_amd.engine import DPEngine
+    g = load_golden(G1[0])
+    eng = _engine(g)
+    rx = torch.zeros(1, 1, 2, 2, 100, device=DEV)
+    with pytest.raises(nat.VaeqError):          # window (B=100 symbols -> 200 samples) past the row
+        eng.train(rx, 100, 1, 1e-3)
+    with pytest.raises(ValueError):
+        DPEngine(1, 24, g["amp_levels"], g["P"], g["var"], 0.0, DEV)
+    with pytest.raises(nat.VaeqError):          # CPU tensors are refused: there is no CPU path
+        eng.train(torch.zeros(1, 1, 2, 2, 400), 100, 1, 1e-3)

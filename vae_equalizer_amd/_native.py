@@ -1,0 +1,125 @@
+"""ctypes binding of ``libvaeq_hip.so`` (C ABI declared in ``include/vaeq.h``).
+
+There is no CPU fallback: if the library is missing or a call fails, this module raises.
+PyTorch is used only to own device memory and streams; every pointer that crosses the
+boundary is a raw device pointer.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "libvaeq_hip.so")
+SOURCES = ["vaeq_dp.hip", "vaeq_awgn.hip", "vaeq_misc.hip"]
+HEADERS = ["vaeq_common.h"]
+_LIB = None
+
+
+class VaeqError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP sources for gfx950 into ``vae_equalizer_amd/libvaeq_hip.so`` (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(_PKG, "csrc")
+    srcs = [os.path.join(csrc, s) for s in SOURCES if os.path.exists(os.path.join(csrc, s))]
+    deps = srcs + [os.path.join(csrc, h) for h in HEADERS] + [os.path.join(_ROOT, "include", "vaeq.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(_ROOT, "include"),
+           "-I", csrc, *srcs, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+class DPArgs(C.Structure):
+    """Mirror of ``struct vaeq_dp_args`` (include/vaeq.h)."""
+    _fields_ = [
+        ("R", C.c_int32), ("n_frames", C.c_int32), ("steps", C.c_int32), ("B", C.c_int32), ("sps", C.c_int32),
+        ("M", C.c_int32), ("n_lev", C.c_int32), ("stride_sym", C.c_int32), ("keep_off", C.c_int32), ("keep_len", C.c_int32),
+        ("S", C.c_int64),
+        ("rx", C.c_void_p), ("W", C.c_void_p), ("h", C.c_void_p),
+        ("adam_mW", C.c_void_p), ("adam_vW", C.c_void_p), ("adam_mh", C.c_void_p), ("adam_vh", C.c_void_p),
+        ("step", C.c_void_p), ("amp", C.c_void_p), ("P", C.c_void_p), ("var", C.c_void_p), ("nu_sc", C.c_void_p),
+        ("lr_W", C.c_void_p), ("lr_h", C.c_void_p),
+        ("q_out", C.c_void_p), ("y_out", C.c_void_p), ("loss", C.c_void_p), ("var_est", C.c_void_p),
+        ("dbg_gW", C.c_void_p), ("dbg_gh", C.c_void_p),
+        ("threads", C.c_int32), ("no_update", C.c_int32),
+    ]
+
+
+class AWGNArgs(C.Structure):
+    """Mirror of ``struct vaeq_awgn_args`` (include/vaeq.h)."""
+    _fields_ = [
+        ("R", C.c_int32), ("steps", C.c_int32), ("B", C.c_int32), ("sps", C.c_int32), ("M", C.c_int32), ("n_lev", C.c_int32),
+        ("S", C.c_int64),
+        ("rx", C.c_void_p), ("W", C.c_void_p), ("h", C.c_void_p),
+        ("adam_mW", C.c_void_p), ("adam_vW", C.c_void_p), ("adam_xW", C.c_void_p),
+        ("adam_mh", C.c_void_p), ("adam_vh", C.c_void_p), ("adam_xh", C.c_void_p),
+        ("step", C.c_void_p), ("amp", C.c_void_p), ("P", C.c_void_p), ("amp_mean", C.c_void_p), ("var", C.c_void_p),
+        ("lr", C.c_void_p),
+        ("q_out", C.c_void_p), ("y_out", C.c_void_p), ("loss", C.c_void_p),
+        ("dbg_gW", C.c_void_p), ("dbg_gh", C.c_void_p),
+        ("threads", C.c_int32), ("no_update", C.c_int32),
+    ]
+
+
+# every symbol include/vaeq.h declares; tests check the library exports all of them
+EXPORTS = ["vaeq_dp_train", "vaeq_dp_lds_bytes", "vaeq_soft_demap", "vaeq_dp_forward", "vaeq_awgn_train",
+           "vaeq_awgn_lds_bytes", "vaeq_awgn_forward", "vaeq_version", "vaeq_strerror"]
+
+
+def lib():
+    """Load the library (once).  Raises VaeqError if it has not been built -- no silent fallback."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise VaeqError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.vaeq_strerror.restype = C.c_char_p
+        L.vaeq_strerror.argtypes = [C.c_int]
+        L.vaeq_version.restype = C.c_int
+        L.vaeq_dp_train.restype = C.c_int
+        L.vaeq_dp_train.argtypes = [C.POINTER(DPArgs), C.c_void_p]
+        L.vaeq_dp_lds_bytes.restype = C.c_int64
+        L.vaeq_dp_lds_bytes.argtypes = [C.c_int32] * 4
+        L.vaeq_soft_demap.restype = C.c_int
+        L.vaeq_soft_demap.argtypes = [C.c_int32, C.c_int64, C.c_int32] + [C.c_void_p] * 6
+        L.vaeq_dp_forward.restype = C.c_int
+        L.vaeq_dp_forward.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 8
+        if hasattr(L, "vaeq_awgn_train"):
+            L.vaeq_awgn_train.restype = C.c_int
+            L.vaeq_awgn_train.argtypes = [C.POINTER(AWGNArgs), C.c_void_p]
+            L.vaeq_awgn_lds_bytes.restype = C.c_int64
+            L.vaeq_awgn_lds_bytes.argtypes = [C.c_int32] * 4
+            L.vaeq_awgn_forward.restype = C.c_int
+            L.vaeq_awgn_forward.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 8
+        _LIB = L
+    return _LIB
+
+
+def check(code, what):
+    if code != 0:
+        raise VaeqError(f"{what} failed: {lib().vaeq_strerror(int(code)).decode()} (code {int(code)})")
+
+
+def ptr(t, dtype=torch.float32):
+    """Raw device pointer of a contiguous CUDA(HIP) tensor of the expected dtype; None passes NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise VaeqError("the vaeq kernels take device tensors (no CPU path)")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise VaeqError(f"expected a contiguous {dtype} tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

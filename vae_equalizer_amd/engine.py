@@ -1,0 +1,141 @@
+"""Batched run engines: device-resident state of R independent equalizer runs + launches of the HIP training loop.
+
+This is the host side of the C ABI (include/vaeq.h).  It mirrors what one call of the reference's
+``processing()`` keeps alive between minibatches -- the ``twoXtwoFIR`` weight, ``h_est`` and the two
+``optim.Adam`` parameter groups (optical_DP_channel/func_VAELE_DP_MQAM_shaping.py:26-31) -- for R runs at
+once, because on an MI355X the sweep (Eval_run_DP.py:68-86), not the single run, is the unit of parallelism.
+"""
+import ctypes as C
+
+import torch
+
+from . import _native as nat
+
+
+def _f32(x, device):
+    return torch.as_tensor(x, dtype=torch.float32).to(device).contiguous()
+
+
+class DPEngine:
+    """R dual-polarisation runs (VAE-LE or VAEflex) sharing modulation, M_est and sps; P/var/nu_sc/lr per run."""
+
+    def __init__(self, R, M_est, amp_levels, P, var, nu_sc, device="cuda:0", sps=2, threads=0):
+        if M_est % 2 == 0:
+            # even M_est: FIR yields B+1 outputs and the loss indexes M_est+1 taps in the reference (SURVEY note N3)
+            raise ValueError("M_est must be odd")
+        self.device = torch.device(device)
+        self.R, self.M, self.sps, self.threads = int(R), int(M_est), int(sps), int(threads)
+        self.amp = _f32(amp_levels, self.device).reshape(-1)
+        self.n_lev = self.amp.numel()
+        self.P = self._per_run(P, (self.n_lev,))
+        self.var = self._per_run(var, (2,))
+        self.nu_sc = self._per_run(nu_sc, ())
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.device)
+        self.W, self.h = z(R, 2, 4, self.M), z(R, 2, 2, 2, self.M)
+        self.mW, self.vW, self.mh, self.vh = z(R, 2, 4, self.M), z(R, 2, 4, self.M), z(R, 2, 2, 2, self.M), z(R, 2, 2, 2, self.M)
+        self.step = torch.zeros(R, dtype=torch.int32, device=self.device)
+        self.reset()
+
+    def _per_run(self, x, shape):
+        t = _f32(x, self.device)
+        if t.dim() == len(shape):
+            t = t.expand(self.R, *shape)
+        if tuple(t.shape) != (self.R, *shape):
+            raise ValueError(f"expected shape {(self.R, *shape)} or {shape}, got {tuple(t.shape)}")
+        return t.contiguous()
+
+    def reset(self):
+        """Dirac initialisation of W (shared_funcs.py:495) and h_est (:585); Adam state zeroed."""
+        for t in (self.W, self.h, self.mW, self.vW, self.mh, self.vh):
+            t.zero_()
+        self.step.zero_()
+        c = self.M // 2
+        self.W[:, 0, 0, c] = 1.0
+        self.W[:, 1, 1, c] = 1.0
+        self.h[:, 0, 0, 0, c] = 1.0
+        self.h[:, 1, 1, 0, c] = 1.0
+
+    def set_state(self, W=None, h=None):
+        if W is not None:
+            self.W.copy_(_f32(W, self.device).expand_as(self.W))
+        if h is not None:
+            self.h.copy_(_f32(h, self.device).expand_as(self.h))
+
+    def train(self, rx, B, steps, lr_W, lr_h=None, stride=None, keep_off=0, keep_len=None, want_q=True, want_y=True,
+              want_loss=True, debug_grads=False, no_update=False):
+        """Run ``steps`` minibatch steps per frame on rx[R, n_frames, 2, 2, S] (or [R, 2, 2, S]).
+
+        VAE-LE: defaults (stride = keep_len = B).  VAEflex: stride = keep_len = flex_step, keep_off = (B-flex_step)//2.
+        Returns dict of device tensors: q [R,F,2,2n,steps*keep_len], y [R,F,2,2,...], loss [R,F,steps], var_est [R,F,2,steps].
+        """
+        if rx.dim() == 4:
+            rx = rx.unsqueeze(1)
+        R, F, S = rx.shape[0], rx.shape[1], rx.shape[-1]
+        if R != self.R or tuple(rx.shape[2:4]) != (2, 2):
+            raise ValueError(f"rx must be [R={self.R}, F, 2, 2, S], got {tuple(rx.shape)}")
+        stride = B if stride is None else stride
+        keep_len = B if keep_len is None else keep_len
+        lr_h = lr_W if lr_h is None else lr_h
+        lrW, lrH = self._per_run(lr_W, ()), self._per_run(lr_h, ())
+        No = steps * keep_len
+        dev = self.device
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        out = {
+            "q": e(R, F, 2, 2 * self.n_lev, No) if want_q else None,
+            "y": e(R, F, 2, 2, No) if want_y else None,
+            "loss": e(R, F, steps) if want_loss else None,
+            "var_est": e(R, F, 2, steps) if want_loss else None,
+            "gW": e(R, 2, 4, self.M) if debug_grads else None,
+            "gh": e(R, 2, 2, 2, self.M) if debug_grads else None,
+        }
+        a = nat.DPArgs(R=R, n_frames=F, steps=steps, B=B, sps=self.sps, M=self.M, n_lev=self.n_lev, stride_sym=stride,
+                       keep_off=keep_off, keep_len=keep_len, S=S, rx=nat.ptr(rx), W=nat.ptr(self.W), h=nat.ptr(self.h),
+                       adam_mW=nat.ptr(self.mW), adam_vW=nat.ptr(self.vW), adam_mh=nat.ptr(self.mh), adam_vh=nat.ptr(self.vh),
+                       step=nat.ptr(self.step, torch.int32), amp=nat.ptr(self.amp), P=nat.ptr(self.P), var=nat.ptr(self.var),
+                       nu_sc=nat.ptr(self.nu_sc), lr_W=nat.ptr(lrW), lr_h=nat.ptr(lrH), q_out=nat.ptr(out["q"]),
+                       y_out=nat.ptr(out["y"]), loss=nat.ptr(out["loss"]), var_est=nat.ptr(out["var_est"]),
+                       dbg_gW=nat.ptr(out["gW"]), dbg_gh=nat.ptr(out["gh"]), threads=self.threads, no_update=int(no_update))
+        with torch.cuda.device(dev):
+            nat.check(nat.lib().vaeq_dp_train(C.byref(a), nat.current_stream(dev)), "vaeq_dp_train")
+        out["_keepalive"] = (lrW, lrH, rx)
+        return out
+
+
+def soft_demap(y, amp_levels, var, nu_sc):
+    """soft_dec on device: y[R,2,2,N] (or [2,2,N]) -> q[R,2,2n,N]."""
+    squeeze = y.dim() == 3
+    if squeeze:
+        y = y.unsqueeze(0)
+    dev, R, N = y.device, y.shape[0], y.shape[-1]
+    amp = _f32(amp_levels, dev).reshape(-1)
+    n = amp.numel()
+    var = _f32(var, dev).expand(R, 2).contiguous()
+    nu = _f32(nu_sc, dev).expand(R).contiguous()
+    y = y.contiguous()
+    q = torch.empty(R, 2, 2 * n, N, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().vaeq_soft_demap(R, N, n, nat.ptr(y), nat.ptr(amp), nat.ptr(var), nat.ptr(nu), nat.ptr(q),
+                                            nat.current_stream(dev)), "vaeq_soft_demap")
+    return q[0] if squeeze else q
+
+
+def dp_forward(x, W, amp_levels, var, nu_sc, sps=2, want_q=True):
+    """twoXtwoFIR.forward (eval) on device: x[R,2,2,N*sps], W[R,2,4,M] -> (q[R,2,2n,N] or None, y[R,2,2,N])."""
+    squeeze = x.dim() == 3
+    if squeeze:
+        x, W = x.unsqueeze(0), W.unsqueeze(0)
+    dev, R = x.device, x.shape[0]
+    N, M = x.shape[-1] // sps, W.shape[-1]
+    amp = _f32(amp_levels, dev).reshape(-1)
+    n = amp.numel()
+    var = _f32(var, dev).expand(R, 2).contiguous()
+    nu = _f32(nu_sc, dev).expand(R).contiguous()
+    x, W = x.contiguous(), W.contiguous()
+    q = torch.empty(R, 2, 2 * n, N, dtype=torch.float32, device=dev) if want_q else None
+    y = torch.empty(R, 2, 2, N, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().vaeq_dp_forward(R, N, sps, M, n, nat.ptr(x), nat.ptr(W), nat.ptr(amp), nat.ptr(var), nat.ptr(nu),
+                                            nat.ptr(q), nat.ptr(y), nat.current_stream(dev)), "vaeq_dp_forward")
+    if squeeze:
+        return (q[0] if want_q else None), y[0]
+    return q, y
