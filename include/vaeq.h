@@ -110,6 +110,58 @@ int vaeq_soft_demap(int32_t R, int64_t N, int32_t n_lev, const float *y, const f
 int vaeq_dp_forward(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, const float *x, const float *W,
                     const float *amp, const float *var, const float *nu_sc, float *q, float *y, void *stream);
 
+/* ------------------------------------------------------------------------
+ * ELBO of one minibatch per run, values only: shared_funcs.py:92-137 (loss_function_shaping).
+ * q[R][2][2*n_lev][B], x[R][2][2][B*sps], h[R][2][2][2][M], P[R][n_lev] -> loss[R], var_est[R][2].
+ */
+int vaeq_dp_loss(int32_t R, int32_t B, int32_t sps, int32_t M, int32_t n_lev, const float *q, const float *x,
+                 const float *h, const float *amp, const float *P, float *loss, float *var_est, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Single-polarisation (AWGN / ISI channel) VAE-LE training loop.
+ *
+ * Replaces, for R independent runs at once, the minibatch loop
+ *   AWGN_channel/func_VAELE_MQAM_shaping.py:297-306
+ * i.e. per step: twoFIR.forward (:214-231, with the mean-|y| normalisation), loss_function (:63-95),
+ * loss.backward(), optim.Adam(amsgrad=True).step() for both parameter groups (:283-286).
+ * Minibatches are contiguous and non-overlapping: step s uses symbols [s*B, (s+1)*B) of the row.
+ */
+typedef struct vaeq_awgn_args {
+    int32_t R;           /* independent runs (one workgroup each) */
+    int32_t steps;       /* minibatch steps in this call (N_train // batch_len per epoch, :297) */
+    int32_t B;           /* batch_len */
+    int32_t sps;         /* samples per symbol */
+    int32_t M;           /* M_est: taps of the FIR and of h_est; odd, <= 63 */
+    int32_t n_lev;       /* ASK levels per axis: 2, 4 or 8 */
+    int64_t S;           /* samples per (run, I/Q) row of rx */
+    const float *rx;     /* [R][2 I/Q][S]  (rx_tensor, :58) */
+    float *W;            /* [R][1][2][M]   nn.Conv1d(2,1,M) weight (:209) */
+    float *h;            /* [R][2][M]      h_est re/im (:278-280) */
+    float *adam_mW, *adam_vW, *adam_xW;   /* [R][2][M] exp_avg, exp_avg_sq, max_exp_avg_sq of W */
+    float *adam_mh, *adam_vh, *adam_xh;   /* [R][2][M] ... of h */
+    int32_t *step;       /* [R] Adam step count */
+    const float *amp;    /* [n_lev]    amp_levels (:260) */
+    const float *P;      /* [R][n_lev] pmf of the levels (:264) */
+    const float *amp_mean; /* [R]      mean |Re|,|Im| of the shaped constellation (:271) */
+    const float *var;    /* [R]        demapper variance 10^(-SNR/10) (:272) */
+    const float *lr;     /* [R]        learning rate (both groups, no schedule) */
+    float *q_out;        /* nullable [R][2*n_lev][steps*B] */
+    float *y_out;        /* nullable [R][2][steps*B]  un-normalised FIR output (:227,231) */
+    float *loss;         /* nullable [R][steps] */
+    float *dbg_gW;       /* nullable [R][2][M] gradient of the LAST step */
+    float *dbg_gh;       /* nullable [R][2][M] */
+    int32_t threads;     /* 0 = default, else 64 / 128 / 256 */
+    int32_t no_update;   /* 1: skip the Adam update */
+} vaeq_awgn_args;
+
+int vaeq_awgn_train(const vaeq_awgn_args *args, void *stream);
+int64_t vaeq_awgn_lds_bytes(int32_t B, int32_t sps, int32_t M, int32_t n_lev);
+
+/* twoFIR.forward in eval mode (validation pass, func_VAELE_MQAM_shaping.py:311-313) on N symbols per run:
+ * x[R][2][N*sps], W[R][2][M] -> q[R][2*n_lev][N] (nullable), y[R][2][N] (un-normalised). */
+int vaeq_awgn_forward(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, const float *x, const float *W,
+                      const float *amp, const float *amp_mean, const float *var, float *q, float *y, void *stream);
+
 int vaeq_version(void);
 const char *vaeq_strerror(int code);
 

@@ -1,0 +1,84 @@
+"""GPU parity of the AWGN VAE-LE kernel (vaeq_awgn_train / vaeq_awgn_forward) against the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+AWGN = ["G4_awgn_16qam_cfg1", "G4_awgn_64qam_pcs_free10", "G4_awgn_4qam_small"]
+DEV = "cuda:0"
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _engine(g, threads=0):
+    from vae_equalizer_amd.engine import AWGNEngine
+    eng = AWGNEngine(1, int(g["M_est"]), g["amp_levels"], g["P"], float(g["amp_mean"]), float(g["var"]), DEV, int(g["sps"]), threads)
+    eng.set_state(g["W0"], g["h0"])
+    return eng
+
+
+@pytest.mark.parametrize("threads", [64, 256])
+@pytest.mark.parametrize("name", AWGN)
+def test_awgn_teacher_forced_step(name, threads):
+    """Config 1 (AWGN 16-QAM, one minibatch from seed 5) and friends: q, out, ELBO, gradients, AMSGrad update."""
+    g = load_golden(name)
+    B, sps = int(g["B"]), int(g["sps"])
+    eng = _engine(g, threads)
+    rx = torch.from_numpy(g["rx"][None, :, :B * sps]).to(DEV)
+    r = eng.train(rx, B, 1, float(g["lr"]), want_q=True, want_y=True, debug_grads=True)
+    torch.cuda.synchronize()
+    assert relerr(_np(r["y"])[0], g["out0"]) < 2e-6
+    assert np.max(np.abs(_np(r["q"])[0] - g["q0"])) < 5e-4
+    assert abs(_np(r["loss"])[0, 0] - g["loss"][0]) / abs(g["loss"][0]) < 1e-5
+    assert relerr(_np(r["gh"])[0], g["gh0"]) < 2e-5
+    assert relerr(_np(r["gW"])[0], g["gW0"].reshape(2, -1)) < 1e-4
+    t = oracle.awgn_step_grads(g["rx"][:, :B * sps], g["W0"], g["h0"], g["amp_levels"], g["P"], float(g["amp_mean"]), float(g["var"]), sps, np.float64)
+    assert relerr(_np(r["gW"])[0], t["gW"].reshape(2, -1)) < max(3 * relerr(g["gW0"], t["gW"]), 2e-6)
+    assert relerr(_np(r["gh"])[0], t["gh"]) < max(3 * relerr(g["gh0"], t["gh"]), 2e-6)
+    # taps after the AMSGrad step; entries whose golden gradient is rounding noise (|g| < 1e-6 max|g|: the scale
+    # direction of the Dirac start, see tests/test_oracle_golden.py) move by +-lr on a coin flip and are excluded
+    lr = float(g["lr"])
+    ok = np.abs(g["gW0"].reshape(2, -1)) > 1e-6 * np.abs(g["gW0"]).max()
+    assert np.max(np.abs(_np(eng.W)[0] - g["W1"].reshape(2, -1))[ok]) < 1e-5
+    assert np.max(np.abs(_np(eng.W)[0] - g["W1"].reshape(2, -1))) < 2.01 * lr
+    assert np.max(np.abs(_np(eng.h)[0] - g["h1"])) < 1e-5
+
+
+def test_awgn_freerun_perturbed_start():
+    """3 free steps from a non-Dirac state (no noise-driven tap): losses, taps, AMSGrad max state."""
+    g = load_golden("G4_awgn_4qam_small")
+    B, ns = int(g["B"]), int(g["n_steps"])
+    eng = _engine(g)
+    r = eng.train(torch.from_numpy(g["rx"][None]).to(DEV), B, ns, float(g["lr"]))
+    torch.cuda.synchronize()
+    assert np.max(np.abs(_np(r["loss"])[0] - g["loss"]) / np.abs(g["loss"])) < 2e-5
+    assert np.max(np.abs(_np(eng.W)[0] - g[f"W{ns}"].reshape(2, -1))) < 2e-5
+    assert np.max(np.abs(_np(eng.h)[0] - g[f"h{ns}"])) < 2e-5
+    assert relerr(_np(eng.xW)[0], g["vmaxW"].reshape(2, -1)) < 1e-4 and relerr(_np(eng.xh)[0], g["vmaxh"]) < 1e-4
+
+
+def test_awgn_freerun_dirac_within_coinflip():
+    g = load_golden("G4_awgn_64qam_pcs_free10")
+    B, ns, lr = int(g["B"]), int(g["n_steps"]), float(g["lr"])
+    eng = _engine(g)
+    r = eng.train(torch.from_numpy(g["rx"][None]).to(DEV), B, ns, lr)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(_np(r["loss"])[0] - g["loss"]) / np.abs(g["loss"])) < 2e-3
+    assert np.max(np.abs(_np(eng.W)[0] - g[f"W{ns}"].reshape(2, -1))) < 2.5 * lr
+
+
+def test_awgn_forward_validation_pass():
+    """Eval-mode forward on a long block == oracle forward (normalisation by the block's own mean |y|)."""
+    g = load_golden("G4_awgn_64qam_pcs_free10")
+    eng = _engine(g)
+    eng.set_state(g["W3"], None)
+    x = g["rx"]
+    q, y = eng.forward(torch.from_numpy(x[None]).to(DEV))
+    qo, yo = oracle.awgn_forward(x, g["W3"], g["amp_levels"], float(g["amp_mean"]), float(g["var"]), int(g["sps"]), np.float64)
+    assert relerr(_np(y)[0], yo) < 2e-6
+    assert np.max(np.abs(_np(q)[0] - qo)) < 5e-4

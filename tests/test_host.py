@@ -1,0 +1,168 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol of include/vaeq.h, the host mirrors
+keep the reference's call surface, the batched epilogue agrees with the oracle, product code never imports the oracle."""
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import ROOT, load_golden
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from vae_equalizer_amd import _native as nat
+    nat.build()
+    L = nat.lib()
+    header = open(os.path.join(ROOT, "include", "vaeq.h")).read()
+    declared = set(re.findall(r"\b(vaeq_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(nat.EXPORTS), declared ^ set(nat.EXPORTS)
+    for s in declared:
+        assert hasattr(L, s), s
+    assert L.vaeq_version() == 100
+    assert L.vaeq_strerror(-2) == b"inconsistent or unsupported sizes"
+    # shape validation is host-side: no GPU needed
+    assert L.vaeq_dp_lds_bytes(100, 2, 25, 8) > 0
+    assert L.vaeq_dp_lds_bytes(100, 2, 24, 8) == -2       # even M_est
+    assert L.vaeq_dp_lds_bytes(100, 2, 25, 3) == -2       # levels
+    assert L.vaeq_dp_lds_bytes(10, 2, 25, 8) == -2        # window shorter than the channel memory
+    assert L.vaeq_awgn_lds_bytes(350, 2, 25, 8) > 0
+
+
+def test_struct_mirrors_match_header_field_order():
+    from vae_equalizer_amd import _native as nat
+    header = open(os.path.join(ROOT, "include", "vaeq.h")).read()
+    for name, cls in (("vaeq_dp_args", nat.DPArgs), ("vaeq_awgn_args", nat.AWGNArgs)):
+        body = header[header.index(f"typedef struct {name} {{"):header.index(f"}} {name};")]
+        fields = []
+        for line in body.splitlines()[1:]:
+            line = line.split("/*")[0].strip()
+            if not line.endswith(";"):
+                continue
+            for part in line[:-1].split(","):
+                fields.append(part.replace("*", " ").split()[-1])
+        assert fields == [f[0] for f in cls._fields_], name
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "vae_equalizer_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            assert not re.search(r"^\s*(import|from)\s+oracle\b", src, re.M), f
+
+
+def test_no_gpu_means_loud_failure():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from vae_equalizer_amd import _native as nat
+    from vae_equalizer_amd.func_VAELE_DP_MQAM_shaping import processing
+    with pytest.raises(nat.VaeqError):
+        processing('64-QAM', 2, 23, 0, 25, 0.0, 0.3, 2.5e-3, 100, 1000, 1, 10, 'h0', 90e9, -26e-24, 3e-12,
+                   np.array([0.03, 0.03], dtype=np.complex64), 170, verbose=False)
+
+
+def test_processing_signatures_match_reference():
+    from vae_equalizer_amd import func_VAEflex_DP_MQAM_shaping as fx
+    from vae_equalizer_amd import func_VAELE_DP_MQAM_shaping as le
+    from vae_equalizer_amd import func_VAELE_MQAM_shaping as aw
+    pos = lambda f: [p.name for p in inspect.signature(f).parameters.values() if p.kind == p.POSITIONAL_OR_KEYWORD]
+    assert pos(le.processing) == ["mod", "sps", "SNR", "nu", "M_est", "theta_diff", "theta", "lr_optim", "batch_len", "N_frame_max",
+                                  "num_frames", "flex_step", "channel", "symb_rate", "tau_cd", "tau_pmd", "phiIQ", "N_lrhalf"]
+    assert pos(fx.processing) == ["mod", "sps", "SNR", "nu", "M_est", "theta_diff", "theta", "lr_optim", "batch_len", "N_train_max",
+                                  "num_frames", "flex_step", "channel", "symb_rate", "tau_cd", "tau_pmd", "phiIQ", "N_lrhalf"]
+    assert pos(aw.processing) == ["mod", "sps", "SNR", "nu", "M_est", "lr_optim", "batch_len", "N_valid", "N_train", "num_epochs", "epe", "channel"]
+
+
+def test_init_tables_bit_exact():
+    from vae_equalizer_amd import shared_funcs as sfun
+    g = load_golden("G0_init")
+    for k in range(int(g["n_cases"])):
+        mod, nu, SNR, ch, M = g[f"c{k}_args"]
+        r = sfun.init(str(ch), str(mod), "cpu", float(nu), 2, int(M), float(SNR))
+        for nm, v in zip(["h_est", "h_channel", "P", "amp_levels", "amps", None, "nu_sc", "var", "pow_mean"], r):
+            if nm is None:
+                assert v == 2
+                continue
+            v = v.detach().numpy() if hasattr(v, "detach") else np.asarray(v)
+            assert np.array_equal(v, g[f"c{k}_{nm}"]), (k, nm)
+    with pytest.raises(KeyError):
+        sfun.init("h0", "8-QAM", "cpu", 0, 2, 25, 20)
+    with pytest.raises(UnboundLocalError):
+        sfun.init("h9", "4-QAM", "cpu", 0, 2, 25, 20)
+
+
+def test_awgn_tables_match_capture():
+    from vae_equalizer_amd.func_VAELE_MQAM_shaping import awgn_tables
+    g = load_golden("G4_awgn_64qam_pcs_free10")
+    t = awgn_tables("64-QAM", float(g["nu"]), float(g["SNR"]), "h1", 2)
+    assert np.allclose(t["amps"].astype(np.float32), g["amp_levels"]) and np.allclose(t["P"].astype(np.float32), g["P"])
+    assert abs(t["amp_mean"] - float(g["amp_mean"])) < 1e-12 and abs(t["var"] - float(g["var"])) < 1e-15
+
+
+def _epi_inputs(g):
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    return t(g["out_train"])[None], t(g["out_const"])[None], t(g["data"])[None], t(g["amp_levels"])
+
+
+def test_batched_epilogue_matches_oracle_and_reference_on_converged_frame():
+    """The torch epilogue (device-agnostic) on G5's converged frame == the reference's own results."""
+    from vae_equalizer_amd import epilogue as epi
+    g = load_golden("G5_dp_epilogue")
+    q, y, data, amp = _epi_inputs(g)
+    nu = torch.tensor([float(g["nu_sc"])]); var = torch.from_numpy(g["var"])[None]
+    r = epi.dp_frame_epilogue(q, y, data, amp, nu, var, batch_len=int(g["B"]))
+    assert np.array_equal(r["shift_q"][0].numpy(), g["shifts"][-1, 0]) and int(r["r_q"][0]) == g["rs"][-1, 0]
+    assert np.array_equal(r["shift_c"][0].numpy(), g["shifts"][-1, 1]) and int(r["r_c"][0]) == g["rs"][-1, 1]
+    assert np.allclose(r["SER"][0].numpy(), g["SER_valid"][:, -1], atol=1e-6)
+
+
+@pytest.mark.parametrize("batch_len", [None, 100])
+def test_batched_epilogue_random_batch_vs_oracle(batch_len):
+    """R=6 synthetic runs with different delays / swaps / rotations: batched torch epilogue == per-run numpy oracle."""
+    from vae_equalizer_amd import epilogue as epi
+    g = load_golden("G5_dp_epilogue")
+    amp, var0 = g["amp_levels"], g["var"]
+    rng = np.random.default_rng(11)
+    R, N, n = 6, 1000, amp.shape[0]
+    qs, ys, ds, nus, vars_ = [], [], [], [], []
+    for i in range(R):
+        lev = rng.integers(0, n, (2, 2, N))
+        clean = amp[lev].astype(np.float32)
+        k = i % 4
+        rot = [clean, np.stack([-clean[:, 1], clean[:, 0]], 1), -clean, np.stack([clean[:, 1], -clean[:, 0]], 1)][k]
+        if i == 4:
+            rot = np.stack([rot[:, 0], -rot[:, 1]], 1)          # conjugate (IQ flip)
+        y = rot + (0.03 + 0.02 * i) * rng.standard_normal(rot.shape).astype(np.float32)
+        sw, d = i % 2, int(rng.integers(-9, 10))
+        y = np.roll(y, sw, axis=0)
+        dl = (d, d) if sw else (d, int(rng.integers(-9, 10)))
+        y = np.stack([np.roll(y[0], dl[0], -1), np.roll(y[1], dl[1], -1)])
+        nu_sc = float(rng.uniform(0, 1.2)); v = (var0 * rng.uniform(0.5, 2)).astype(np.float32)
+        qs.append(oracle.dp_soft_dec(y, v, amp, nu_sc)); ys.append(y); ds.append(amp[lev].astype(np.float16)); nus.append(nu_sc); vars_.append(v)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(np.stack(a)))
+    r = epi.dp_frame_epilogue(t(qs), t(ys), t(ds), torch.from_numpy(amp), torch.tensor(nus, dtype=torch.float32), t(vars_), batch_len)
+    for i in range(R):
+        o = oracle.dp_frame_epilogue(qs[i], ys[i], ds[i], amp, nus[i], vars_[i], batch_len=batch_len)
+        assert np.array_equal(r["shift_q"][i].numpy(), o["shift_q"]) and int(r["r_q"][i]) == o["r_q"], i
+        assert np.array_equal(r["shift_c"][i].numpy(), o["shift_c"]) and int(r["r_c"][i]) == o["r_c"], i
+        assert np.allclose(r["SER"][i].numpy(), o["SER"], atol=1e-6), (i, r["SER"][i], o["SER"])
+
+
+def test_unbatched_mirrors_keep_reference_shapes():
+    from vae_equalizer_amd import shared_funcs as sfun
+    g = load_golden("G5_dp_epilogue")
+    q, y, data, amp = (x[0] if x.dim() == 4 else x for x in _epi_inputs(g))
+    shift, r = sfun.find_shift(q, data, 21, amp, 2)
+    assert shift.dtype == torch.int16 and shift.shape == (2,) and r in (0, 1)
+    shift2, r2 = sfun.find_shift_symb_full(y, data, 21)
+    assert np.array_equal(shift.numpy(), g["shifts"][-1, 0]) and np.array_equal(shift2.numpy(), g["shifts"][-1, 1])
+    o = oracle.SER_IQflip(g["out_train"][:, :, 11:-11], g["data"][:, :, 11:-11])
+    assert np.allclose(sfun.SER_IQflip(q[:, :, 11:-11], data[:, :, 11:-11]).numpy(), o, atol=1e-7)
+    yy = y[:, :, 11:-11].clone()
+    o = oracle.SER_constell_shaping(g["out_const"][:, :, 11:-11].copy(), g["data"][:, :, 11:-11], g["amp_levels"], float(g["nu_sc"]), g["var"])
+    s = sfun.SER_constell_shaping(yy, data[:, :, 11:-11], amp, float(g["nu_sc"]), torch.from_numpy(g["var"]))
+    assert np.allclose(s.numpy(), o, atol=1e-7)
+    assert not torch.equal(yy, y[:, :, 11:-11])       # rescaled in place like the reference (shared_funcs.py:242)

@@ -71,7 +71,7 @@ class AWGNArgs(C.Structure):
 
 
 # every symbol include/vaeq.h declares; tests check the library exports all of them
-EXPORTS = ["vaeq_dp_train", "vaeq_dp_lds_bytes", "vaeq_soft_demap", "vaeq_dp_forward", "vaeq_awgn_train",
+EXPORTS = ["vaeq_dp_train", "vaeq_dp_lds_bytes", "vaeq_soft_demap", "vaeq_dp_forward", "vaeq_dp_loss", "vaeq_awgn_train",
            "vaeq_awgn_lds_bytes", "vaeq_awgn_forward", "vaeq_version", "vaeq_strerror"]
 
 
@@ -94,6 +94,8 @@ def lib():
         L.vaeq_soft_demap.argtypes = [C.c_int32, C.c_int64, C.c_int32] + [C.c_void_p] * 6
         L.vaeq_dp_forward.restype = C.c_int
         L.vaeq_dp_forward.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 8
+        L.vaeq_dp_loss.restype = C.c_int
+        L.vaeq_dp_loss.argtypes = [C.c_int32] * 5 + [C.c_void_p] * 8
         if hasattr(L, "vaeq_awgn_train"):
             L.vaeq_awgn_train.restype = C.c_int
             L.vaeq_awgn_train.argtypes = [C.POINTER(AWGNArgs), C.c_void_p]

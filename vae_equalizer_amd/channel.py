@@ -1,0 +1,194 @@
+"""Input producer for the hot path: seeded dual-polarisation / AWGN channel simulators.
+
+``generate_data_shaping`` / ``generate_data`` restate optical_DP_channel/shared_funcs.py:17-90 and
+AWGN_channel/func_VAELE_MQAM_shaping.py:28-61 in numpy with the SAME random-number consumption
+(``Generator.choice`` for the PCS symbols, legacy global ``randn`` for the noise), so that a run seeded
+like tools/capture_golden.py reproduces the reference's data stream (pinned by tests/golden/G6_generator.npz).
+The reference seeds nothing; here every call may be given explicit generators.
+
+``generate_batch_gpu`` is the same physical model evaluated with torch ops on the device for a whole batch of
+runs at once: it feeds bench.py and large sweeps without a host round trip.  Its random stream
+is torch's, not numpy's.
+"""
+import math
+
+import numpy as np
+import torch
+
+PULSE_SPAN = 8      # T: pulse length in symbols        (shared_funcs.py:66)
+ROLL_OFF = 0.1      # beta                               (shared_funcs.py:67)
+
+
+def rrcfir(T, sps, beta):
+    """Root-raised-cosine taps, unit energy (shared_funcs.py:27-36).  float32 time grid like the reference."""
+    t = np.arange(-T * sps / 2, T * sps / 2, 1 / sps, dtype=np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        num = np.sin(np.pi * t * (1 - beta)) + 4 * beta * t * np.cos(np.pi * t * (1 + beta))
+        h = num / (np.pi * t * (1 - (4 * beta * t) ** 2))
+    h[np.abs(t) == 1 / 4 / beta] = beta / np.sqrt(2) * ((1 + 2 / np.pi) * np.sin(np.pi / 4 / beta) + (1 - 2 / np.pi) * np.cos(np.pi / 4 / beta))
+    h[t == 0] = 1 + beta * (4 / np.pi - 1)
+    return h / np.linalg.norm(h)
+
+
+def rcfir(T, sps, beta):
+    """Raised-cosine taps, unit energy (shared_funcs.py:17-25)."""
+    t = np.arange(-T * sps / 2, T * sps / 2, 1 / sps, dtype=np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        h = np.sinc(t) * np.cos(np.pi * beta * t) / (1 - (2 * beta * t) ** 2)
+    h[np.abs(t) == 1 / 2 / beta] = np.pi / 4 * np.sinc(1 / (2 * beta))
+    return h / np.linalg.norm(h)
+
+
+def _fiber_matrix(freq, tau_pmd, phiIQ, theta):
+    """H(f) = R^T diag(e^{j pi tau f}, e^{-j pi tau f}) R with the IQ-phase folded into R (shared_funcs.py:42-50)."""
+    d = np.exp(1j * np.pi * tau_pmd * freq)
+    c, s = np.cos(theta), np.sin(theta)
+    e = np.exp(-1j * phiIQ)
+    R = ((c * e[0], s * e[0]), (-s * e[1], c * e[1]))
+    RT = ((c * e[0], -s * e[0]), (s * e[1], c * e[1]))
+    di = 1 / d
+    return [[RT[a][0] * d * R[0][b] + RT[a][1] * di * R[1][b] for b in range(2)] for a in range(2)]
+
+
+def simulate_dispersion(rx, symb_rate, sps, tau_cd, tau_pmd, phiIQ, theta):
+    """Residual CD + PMD + polarisation rotation + IQ phase in the frequency domain (shared_funcs.py:38-54)."""
+    spec = np.fft.fft(rx, axis=1)
+    freq = np.fft.fftfreq(rx.shape[1], 1 / symb_rate / sps)
+    cd = np.exp(1j * 2 * (np.pi * freq) ** 2 * tau_cd)
+    H = _fiber_matrix(freq, tau_pmd, phiIQ, theta)
+    out = np.zeros((2, rx.shape[1]), dtype=np.complex128)
+    out[0] = (H[0][0] * spec[0] + H[0][1] * spec[1]) * cd
+    out[1] = (H[1][0] * spec[0] + H[1][1] * spec[1]) * cd
+    return np.complex64(np.fft.ifft(out, axis=1))
+
+
+def simulate_channel(tx_up, h_pulse, h_channel):
+    """Pulse shaping then the (optional) extra impulse response, both 'valid' (shared_funcs.py:56-63)."""
+    n_out = tx_up.shape[1] - h_pulse.shape[0] - h_channel.shape[0] + 2
+    out = np.zeros((tx_up.shape[0], n_out), dtype=np.complex64)
+    for p in range(tx_up.shape[0]):
+        out[p] = np.convolve(np.convolve(tx_up[p], h_pulse, mode="valid"), h_channel, mode="valid")
+    return out
+
+
+def generate_data_shaping(N, amps, SNR, h_channel, P, pol, symb_rate, sps, tau_cd, tau_pmd, phiIQ, theta, device,
+                          rng=None, noise=None):
+    """One frame of received samples + TX reference (shared_funcs.py:65-90).
+
+    Returns (rx[pol,2,sps*N] float32, data[pol,2,N] float16, sigma_n).  ``rng``: numpy Generator for the symbol draw
+    (default: fresh ``np.random.default_rng()`` like the reference); ``noise``: object with ``randn`` (default: the
+    global ``np.random`` like the reference)."""
+    rng = np.random.default_rng() if rng is None else rng
+    noise = np.random if noise is None else noise
+    T, Mc = PULSE_SPAN, len(h_channel)
+    N_conv = N + Mc + 4 * T
+    data = rng.choice(amps, (pol * 2, N_conv), p=P)
+    tx_up = np.zeros((pol, sps * (N_conv - 1) + 1), dtype=np.complex64)
+    tx_up[:, ::sps] = data[0::pol, :] + 1j * data[1::pol, :]
+    sig = simulate_channel(tx_up, rrcfir(T, sps, ROLL_OFF), h_channel)
+    sig = simulate_dispersion(sig, symb_rate, sps, tau_cd, tau_pmd, phiIQ, theta)
+    sigma_n = np.sqrt(np.mean(np.abs(sig) ** 2) * sps / 2 / 10 ** (SNR / 10))
+    sig += sigma_n * (noise.randn(*sig.shape) + 1j * noise.randn(*sig.shape))
+    rx = np.stack([sig[:, :sps * N].real, sig[:, :sps * N].imag], axis=1)
+    lo = T + Mc - 1
+    ref = np.stack([data[0::pol, lo:lo + N], data[1::pol, lo:lo + N]], axis=1)
+    return (torch.from_numpy(np.ascontiguousarray(rx)).to(device, torch.float32),
+            torch.from_numpy(np.ascontiguousarray(ref)).to(device, torch.float16), sigma_n)
+
+
+def generate_data(N, M, amps, SNR, h_channel, sps, device, P, rng=None, noise=None):
+    """Single-polarisation AWGN/ISI channel (AWGN_channel/func_VAELE_MQAM_shaping.py:39-61) -> (rx[2,sps*N], data[2,N])."""
+    rng = np.random.default_rng() if rng is None else rng
+    noise = np.random if noise is None else noise
+    T = PULSE_SPAN
+    N_conv = N + len(h_channel) + 4 * T
+    data = rng.choice(amps, (2, N_conv), p=P)
+    tx_up = np.zeros(sps * (N_conv - 1) + 1, dtype=np.complex64)
+    tx_up[::sps] = data[0] + 1j * data[1]
+    sig = np.convolve(np.convolve(tx_up, rrcfir(T, sps, ROLL_OFF), mode="valid"), h_channel, mode="valid")
+    sigma_n = np.sqrt(sps * np.mean(np.abs(sig) ** 2) / 2 / 10 ** (SNR / 10))
+    sig += sigma_n * (noise.randn(*sig.shape) + 1j * noise.randn(*sig.shape))
+    rx = np.stack([sig[:sps * N].real, sig[:sps * N].imag])
+    lo = T + M - 1
+    ref = np.stack([data[0, lo:lo + N], data[1, lo:lo + N]])
+    return (torch.from_numpy(np.ascontiguousarray(rx)).to(device, torch.float32),
+            torch.from_numpy(np.ascontiguousarray(ref)).to(device, torch.float16))
+
+
+class SeededStreams:
+    """Reproducible stand-in for the reference's unseeded RNG use, frame by frame.
+
+    Frame k draws its symbols from ``np.random.default_rng(seed + k)`` and all noise comes from ONE legacy
+    ``RandomState(seed)`` stream -- the consumption pattern tools/capture_golden.py imposes on the reference, so the
+    same seed yields the same frames here and there."""
+
+    def __init__(self, seed):
+        self.seed, self.k = int(seed), 0
+        self.noise = np.random.RandomState(self.seed)
+
+    def next_rng(self):
+        g = np.random.default_rng(self.seed + self.k)
+        self.k += 1
+        return g
+
+
+# ------------------------------------------------------------------ batched device generator (row f1)
+def generate_batch_gpu(R, N, amps, P, SNR, h_channel, symb_rate, sps, tau_cd, tau_pmd, phiIQ, theta, device, generator=None):
+    """The DP channel model for R runs at once with torch ops on ``device``.
+
+    amps[n]; P[R,n] or [n]; SNR / theta: scalar or [R].  Returns (rx[R,2,2,sps*N] f32, data[R,2,2,N] f16).
+    Same physics as generate_data_shaping (PCS draw, zero-stuffing, RRC, extra IR, CD+PMD+rotation+IQ phase, AWGN)."""
+    dev = torch.device(device)
+    T = PULSE_SPAN
+    hc = torch.as_tensor(np.asarray(h_channel), dtype=torch.complex64, device=dev)
+    Mc = hc.numel()
+    N_conv = N + Mc + 4 * T
+    amps_t = torch.as_tensor(np.asarray(amps), dtype=torch.float32, device=dev)
+    Pt = torch.as_tensor(np.asarray(P), dtype=torch.float32, device=dev)
+    if Pt.dim() == 1:
+        Pt = Pt.expand(R, -1)
+    idx = torch.multinomial(Pt, 4 * N_conv, replacement=True, generator=generator).reshape(R, 4, N_conv)
+    data = amps_t[idx]                                                     # [R, 4, N_conv]: rows I0,Q0,I1,Q1
+    sym = torch.complex(data[:, 0::2], data[:, 1::2])                      # [R, 2, N_conv]
+    Lup = sps * (N_conv - 1) + 1
+    up = torch.zeros(R, 2, Lup, dtype=torch.complex64, device=dev)
+    up[:, :, ::sps] = sym
+    hp = torch.as_tensor(rrcfir(T, sps, ROLL_OFF), dtype=torch.float32, device=dev)
+
+    def conv_valid(x, k):                                                  # true convolution, 'valid'
+        kk = torch.flip(k, [0]).reshape(1, 1, -1)
+        xr = torch.nn.functional.conv1d(x.real.reshape(-1, 1, x.shape[-1]), kk.real if kk.is_complex() else kk)
+        xi = torch.nn.functional.conv1d(x.imag.reshape(-1, 1, x.shape[-1]), kk.real if kk.is_complex() else kk)
+        if kk.is_complex():
+            yr = xr - torch.nn.functional.conv1d(x.imag.reshape(-1, 1, x.shape[-1]), kk.imag)
+            yi = xi + torch.nn.functional.conv1d(x.real.reshape(-1, 1, x.shape[-1]), kk.imag)
+            xr, xi = yr, yi
+        return torch.complex(xr, xi).reshape(*x.shape[:-1], -1)
+
+    sig = conv_valid(up, hp)
+    if Mc > 1:
+        sig = conv_valid(sig, hc)
+    Ls = sig.shape[-1]
+    spec = torch.fft.fft(sig.to(torch.complex128), dim=-1)
+    freq = torch.fft.fftfreq(Ls, 1 / symb_rate / sps, device=dev, dtype=torch.float64)
+    cd = torch.exp(1j * 2 * (math.pi * freq) ** 2 * tau_cd)
+    d = torch.exp(1j * math.pi * tau_pmd * freq)
+    th = torch.as_tensor(theta, dtype=torch.float64, device=dev).expand(R).reshape(R, 1)
+    c, s = torch.cos(th), torch.sin(th)
+    e = np.exp(-1j * np.asarray(phiIQ, dtype=np.complex128))
+    e0, e1 = complex(e[0]), complex(e[1])
+    di = 1 / d
+    H00 = (c * e0) * d * (c * e0) + (-s * e0) * di * (-s * e1)
+    H01 = (c * e0) * d * (s * e0) + (-s * e0) * di * (c * e1)
+    H10 = (s * e1) * d * (c * e0) + (c * e1) * di * (-s * e1)
+    H11 = (s * e1) * d * (s * e0) + (c * e1) * di * (c * e1)
+    out = torch.stack([(H00 * spec[:, 0] + H01 * spec[:, 1]) * cd, (H10 * spec[:, 0] + H11 * spec[:, 1]) * cd], dim=1)
+    sig = torch.fft.ifft(out, dim=-1).to(torch.complex64)
+    snr = torch.as_tensor(SNR, dtype=torch.float32, device=dev).expand(R).reshape(R, 1, 1)
+    sigma = torch.sqrt(sig.abs().square().mean(dim=(1, 2), keepdim=True) * sps / 2 / 10 ** (snr / 10))
+    noise = torch.randn(R, 2, Ls, 2, device=dev, generator=generator)
+    sig = sig + sigma * torch.complex(noise[..., 0], noise[..., 1])
+    rx = torch.stack([sig.real[..., :sps * N], sig.imag[..., :sps * N]], dim=2).contiguous()   # [R,2,2,sps*N]
+    lo = T + Mc - 1
+    ref = torch.stack([data[:, 0::2, lo:lo + N], data[:, 1::2, lo:lo + N]], dim=2).to(torch.float16).contiguous()
+    return rx.to(torch.float32), ref

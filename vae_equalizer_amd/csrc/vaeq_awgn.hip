@@ -1,0 +1,389 @@
+// vaeq_awgn.hip -- single-polarisation (AWGN / ISI channel) VAE-LE training loop for gfx950.
+//
+// Same structure as vaeq_dp.hip (one workgroup = one run, everything in LDS) for the 1x1 variant of
+// AWGN_channel/func_VAELE_MQAM_shaping.py:
+//   twoFIR.forward (:214-231)   y = (W0 - j W1) * x, pad (M-1)/2, stride sps;
+//                               yhat_c = y_c / mean_n|y_c| * amp_mean  (:228, differentiable);
+//                               q_i = softmax_i( -(yhat_c - a_i)^2 / var )  -- no 1/2, no PCS term (:229)
+//   loss_function (:63-95)      C = sum|x - D|^2 + sum_j |h_j|^2 VS[j];  loss = nm log C + sum q log(q/P + 1e-12)
+//   Adam(amsgrad=True) (:283)   one learning rate for both groups, no schedule
+// Backward = vaeq_dp.hip's closed form specialised to one polarisation, with dz_i/dyhat = -2 (yhat - a_i) / var and
+// the normalisation's Jacobian:
+//   dL/dy_c[n] = g_c[n] A/m_c - (sum_n' g_c[n'] y_c[n']) A / m_c^2 * sign(y_c[n]) / B,   g = dL/dyhat, m_c = mean|y_c|
+//   dL/dW0[k] = sum_n gI x0 + gQ x1,   dL/dW1[k] = sum_n gI x1 - gQ x0        (w = W0 - j W1)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vaeq.h"
+#include "vaeq_common.h"
+
+namespace vaeq {
+
+struct AWGNLayout {
+    int L, mh, Mh, nm, Lp;
+    int xs, Ws, hs, mW, vW, xW, mH, vH, xH, gW, gH, ys, mu, vr, t3, kc, gy, es, VS, red, total;
+};
+
+__host__ __device__ inline int apad4(int x) { return (x + 3) & ~3; }
+
+__host__ __device__ inline AWGNLayout awgn_layout(int B, int sps, int M)
+{
+    AWGNLayout l;
+    l.L = B * sps;
+    l.mh = M / 2;
+    l.Mh = 2 * l.mh;
+    l.nm = l.L - l.Mh;
+    l.Lp = apad4(l.L + 2 * l.mh);
+    int o = 0;
+    auto take = [&](int n) { int r = o; o += apad4(n); return r; };
+    l.xs = take(2 * l.Lp);
+    l.Ws = take(2 * M); l.hs = take(2 * M);
+    l.mW = take(2 * M); l.vW = take(2 * M); l.xW = take(2 * M);
+    l.mH = take(2 * M); l.vH = take(2 * M); l.xH = take(2 * M);
+    l.gW = take(2 * M); l.gH = take(2 * M);
+    l.ys = take(2 * B);
+    l.mu = take(2 * B); l.vr = take(2 * B); l.t3 = take(2 * B); l.kc = take(2 * B); l.gy = take(2 * B);
+    l.es = take(2 * l.nm);
+    l.VS = take(M);
+    l.red = take(64);
+    l.total = o;
+    return l;
+}
+
+template <int NT, int NLEV>
+__global__ __launch_bounds__(NT) void awgn_train_kernel(const vaeq_awgn_args a)
+{
+    extern __shared__ float4 smem4[];
+    float *sm = reinterpret_cast<float *>(smem4);
+    const int tid = threadIdx.x, run = blockIdx.x;
+    const int B = a.B, sps = a.sps, M = a.M;
+    const AWGNLayout l = awgn_layout(B, sps, M);
+    const int L = l.L, mh = l.mh, Mh = l.Mh, nm = l.nm, Lp = l.Lp;
+    float *xs = sm + l.xs, *Ws = sm + l.Ws, *hs = sm + l.hs;
+    float *mWs = sm + l.mW, *vWs = sm + l.vW, *xWs = sm + l.xW, *mHs = sm + l.mH, *vHs = sm + l.vH, *xHs = sm + l.xH;
+    float *gWs = sm + l.gW, *gHs = sm + l.gH, *ys = sm + l.ys;
+    float *mu = sm + l.mu, *vr = sm + l.vr, *t3 = sm + l.t3, *kc = sm + l.kc, *gy = sm + l.gy, *es = sm + l.es;
+    float *VS = sm + l.VS, *red = sm + l.red;
+    const int NP = 2 * M;
+
+    float amp[NLEV], invP[NLEV];
+#pragma unroll
+    for (int i = 0; i < NLEV; i++) {
+        amp[i] = a.amp[i];
+        invP[i] = 1.0f / a.P[(size_t)run * NLEV + i];
+    }
+    const float A = a.amp_mean[run], var = a.var[run], ivar = 1.0f / var;
+    const double lr = (double)a.lr[run];
+
+    for (int i = tid; i < NP; i += NT) {
+        const size_t g = (size_t)run * NP + i;
+        Ws[i] = a.W[g]; hs[i] = a.h[g];
+        mWs[i] = a.adam_mW[g]; vWs[i] = a.adam_vW[g]; xWs[i] = a.adam_xW[g];
+        mHs[i] = a.adam_mh[g]; vHs[i] = a.adam_vh[g]; xHs[i] = a.adam_xh[g];
+    }
+    int step = a.step[run];
+    double b1t = pow(0.9, (double)step), b2t = pow(0.999, (double)step);
+    __syncthreads();
+
+    const size_t No = (size_t)a.steps * B;
+    const float *rxr = a.rx + (size_t)run * 2 * (size_t)a.S;
+    float *qf = a.q_out ? a.q_out + (size_t)run * 2 * NLEV * No : nullptr;
+    float *yf = a.y_out ? a.y_out + (size_t)run * 2 * No : nullptr;
+
+    for (int s = 0; s < a.steps; s++) {
+        // ---- P0: minibatch -> LDS with zero halo (:299, Conv1d padding :209)
+        const size_t s0 = (size_t)s * L;
+        for (int i = tid; i < 2 * Lp; i += NT) {
+            const int row = i / Lp, c = i - row * Lp, sx = c - mh;
+            xs[i] = (sx >= 0 && sx < L) ? rxr[(size_t)row * a.S + s0 + sx] : 0.0f;
+        }
+        __syncthreads();
+
+        // ---- P1a: FIR, |y| sums
+        float sa0 = 0.f, sa1 = 0.f;
+        for (int n = tid; n < B; n += NT) {
+            const float *x0 = xs + n * sps, *x1 = xs + Lp + n * sps;
+            float yI = 0.f, yQ = 0.f;
+            for (int k = 0; k < M; k++) {
+                const float a_ = x0[k], b_ = x1[k], c_ = Ws[k], d_ = Ws[M + k];
+                yI = fmaf(c_, a_, yI); yI = fmaf(d_, b_, yI);
+                yQ = fmaf(c_, b_, yQ); yQ = fmaf(-d_, a_, yQ);
+            }
+            ys[n] = yI; ys[B + n] = yQ;
+            if (yf) { yf[s * (size_t)B + n] = yI; yf[No + s * (size_t)B + n] = yQ; }   // un-normalised out (:227,231)
+            sa0 += fabsf(yI); sa1 += fabsf(yQ);
+        }
+        block_reduce3<NT>(sa0, sa1, 0.f, red);
+        const float m0 = red[0] / (float)B, m1 = red[1] / (float)B;   // mean|y_c| (:228)
+        __syncthreads();                                               // red is reused below
+
+        // ---- P1b: normalise, demap, moments; item = (c, n)
+        float klsum = 0.f;
+        for (int it = tid; it < 2 * B; it += NT) {
+            const int c = it / B, n = it - c * B;
+            const float y = ys[it] / (c ? m1 : m0) * A;
+            const bool inr = (n >= mh) && (n < B - mh);
+            float z[NLEV], zmax = -3.0e38f;
+#pragma unroll
+            for (int i = 0; i < NLEV; i++) {
+                const float d = y - amp[i];
+                z[i] = -(d * d * ivar);
+                zmax = fmaxf(zmax, z[i]);
+            }
+            float ssum = 0.f;
+#pragma unroll
+            for (int i = 0; i < NLEV; i++) { z[i] = __expf(z[i] - zmax); ssum += z[i]; }
+            const float rs = 1.0f / ssum;
+            float e1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NLEV; i++) { z[i] *= rs; e1 = fmaf(amp[i], z[i], e1); }
+            if (qf) {
+#pragma unroll
+                for (int i = 0; i < NLEV; i++) qf[(size_t)(c * NLEV + i) * No + s * (size_t)B + n] = z[i];
+            }
+            float e2 = 0.f, e3 = 0.f, kk = 0.f;
+#pragma unroll
+            for (int i = 0; i < NLEV; i++) {
+                const float d = amp[i] - e1, qd = z[i] * d;
+                e2 = fmaf(qd, d, e2);
+                e3 = fmaf(qd * d, d, e3);
+                if (inr) {
+                    const float r = z[i] * invP[i], re = r + 1e-12f;
+                    const float lg = __logf(re);
+                    klsum = fmaf(z[i], lg, klsum);
+                    kk = fmaf(qd, lg + r / re, kk);
+                }
+            }
+            mu[it] = e1; vr[it] = e2; t3[it] = e3; kc[it] = kk;
+        }
+        __syncthreads();
+
+        // ---- P2: e = x - D (item t), VS (item j)
+        float se = 0.f;
+        for (int t = tid; t < nm; t += NT) {
+            float dr = 0.f, di = 0.f;
+            for (int j = (t + Mh) % sps; j <= Mh; j += sps) {
+                const int np = (t + Mh - j) / sps;
+                const float a_ = mu[np], b_ = mu[B + np], c_ = hs[j], d_ = hs[M + j];
+                dr = fmaf(c_, a_, dr); dr = fmaf(-d_, b_, dr);
+                di = fmaf(c_, b_, di); di = fmaf(d_, a_, di);
+            }
+            const float er = xs[Mh + t] - dr, ei = xs[Lp + Mh + t] - di;
+            es[t] = er; es[nm + t] = ei;
+            se += er * er + ei * ei;
+        }
+        for (int j = tid; j < M; j += NT) {
+            const int lo = (Mh - j + sps - 1) / sps, hi_ = (nm - 1 + Mh - j) / sps;
+            float acc = 0.f;
+            for (int np = lo; np <= hi_; np++) acc += vr[np] + vr[B + np];
+            VS[j] = acc;
+        }
+        block_reduce3<NT>(se, klsum, 0.f, red);
+        float C = red[0];
+        for (int j = 0; j < M; j++) C = fmaf(hs[j] * hs[j] + hs[M + j] * hs[M + j], VS[j], C);
+        const float gC = (float)nm / C;
+        if (tid == 0 && a.loss) a.loss[(size_t)run * a.steps + s] = (float)nm * logf(C) + red[1];
+
+        // ---- P4a: dL/dh (item j)
+        for (int j = tid; j < M; j += NT) {
+            const int lo = (Mh - j + sps - 1) / sps, hi_ = (nm - 1 + Mh - j) / sps;
+            float ar = 0.f, ai = 0.f;
+            for (int np = lo; np <= hi_; np++) {
+                const int t = np * sps - Mh + j;
+                const float a_ = es[t], b_ = es[nm + t], c_ = mu[np], d_ = mu[B + np];
+                ar = fmaf(a_, c_, ar); ar = fmaf(b_, d_, ar);
+                ai = fmaf(b_, c_, ai); ai = fmaf(-a_, d_, ai);
+            }
+            gHs[j] = gC * (-2.0f * ar + 2.0f * hs[j] * VS[j]);
+            gHs[M + j] = gC * (-2.0f * ai + 2.0f * hs[M + j] * VS[j]);
+        }
+        // ---- P4b: dL/dU, G_V -> dL/dyhat (item n); dot_c = sum_n g_c y_c
+        float dt0 = 0.f, dt1 = 0.f;
+        for (int n = tid; n < B; n += NT) {
+            const int sx = n * sps;
+            const int jlo = max(0, Mh - sx), jhi = min(Mh, nm - 1 + Mh - sx);
+            const float *er = es + (sx - Mh), *ei = er + nm;
+            float pr = 0.f, pi = 0.f, ph = 0.f;
+            for (int j = jlo; j <= jhi; j++) {
+                const float a_ = er[j], b_ = ei[j], c_ = hs[j], d_ = hs[M + j];
+                pr = fmaf(a_, c_, pr); pr = fmaf(b_, d_, pr);
+                pi = fmaf(b_, c_, pi); pi = fmaf(-a_, d_, pi);
+                ph = fmaf(c_, c_, ph); ph = fmaf(d_, d_, ph);
+            }
+            const float ur = -2.0f * gC * pr, ui = -2.0f * gC * pi, gv = gC * ph;
+            const float gI = 2.0f * ivar * (ur * vr[n] + gv * t3[n] + kc[n]);
+            const float gQ = 2.0f * ivar * (ui * vr[B + n] + gv * t3[B + n] + kc[B + n]);
+            gy[n] = gI; gy[B + n] = gQ;
+            dt0 = fmaf(gI, ys[n], dt0);
+            dt1 = fmaf(gQ, ys[B + n], dt1);
+        }
+        __syncthreads();   // every thread has read red[0..1] of the previous reduction
+        block_reduce3<NT>(dt0, dt1, 0.f, red);
+        {
+            const float s0_ = A / m0, s1_ = A / m1;
+            const float k0_ = red[0] * A / (m0 * m0) / (float)B, k1_ = red[1] * A / (m1 * m1) / (float)B;
+            __syncthreads();
+            for (int n = tid; n < B; n += NT) {   // normalisation backward (:228)
+                const float yI = ys[n], yQ = ys[B + n];
+                const float sgI = (yI > 0.f) - (yI < 0.f), sgQ = (yQ > 0.f) - (yQ < 0.f);
+                gy[n] = gy[n] * s0_ - k0_ * sgI;
+                gy[B + n] = gy[B + n] * s1_ - k1_ * sgQ;
+            }
+        }
+        __syncthreads();
+
+        // ---- P5: dL/dW (item k)
+        for (int k = tid; k < M; k += NT) {
+            const float *x0 = xs + k, *x1 = xs + Lp + k;
+            float g0 = 0.f, g1 = 0.f;
+            for (int n = 0; n < B; n++) {
+                const float a_ = gy[n], b_ = gy[B + n], c_ = x0[n * sps], d_ = x1[n * sps];
+                g0 = fmaf(a_, c_, g0); g0 = fmaf(b_, d_, g0);
+                g1 = fmaf(a_, d_, g1); g1 = fmaf(-b_, c_, g1);
+            }
+            gWs[k] = g0; gWs[M + k] = g1;
+        }
+        __syncthreads();
+
+        // ---- P6: Adam(amsgrad)
+        step += 1;
+        b1t *= 0.9;
+        b2t *= 0.999;
+        if (!a.no_update) {
+            const float bc2s = (float)sqrt(1.0 - b2t), ss = (float)(lr / (1.0 - b1t));
+            for (int i = tid; i < 2 * NP; i += NT) {
+                if (i < NP) adam_update_amsgrad(Ws[i], mWs[i], vWs[i], xWs[i], gWs[i], ss, bc2s);
+                else adam_update_amsgrad(hs[i - NP], mHs[i - NP], vHs[i - NP], xHs[i - NP], gHs[i - NP], ss, bc2s);
+            }
+        }
+        __syncthreads();
+    }
+
+    for (int i = tid; i < NP; i += NT) {
+        const size_t g = (size_t)run * NP + i;
+        if (!a.no_update) {
+            a.W[g] = Ws[i]; a.h[g] = hs[i];
+            a.adam_mW[g] = mWs[i]; a.adam_vW[g] = vWs[i]; a.adam_xW[g] = xWs[i];
+            a.adam_mh[g] = mHs[i]; a.adam_vh[g] = vHs[i]; a.adam_xh[g] = xHs[i];
+        }
+        if (a.dbg_gW) a.dbg_gW[g] = gWs[i];
+        if (a.dbg_gh) a.dbg_gh[g] = gHs[i];
+    }
+    if (tid == 0 && !a.no_update) a.step[run] = step;
+}
+
+// twoFIR.forward in eval mode on N symbols (validation, :311-313): one workgroup per run, two passes over y.
+template <int NLEV>
+__global__ __launch_bounds__(256) void awgn_forward_kernel(int64_t N, int sps, int M, const float *__restrict__ x, const float *__restrict__ W,
+                                                           const float *__restrict__ amp_g, const float *__restrict__ amp_mean,
+                                                           const float *__restrict__ var, float *__restrict__ q, float *__restrict__ yout)
+{
+    __shared__ float Ws[2 * 64];
+    __shared__ float red[64];
+    const int run = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < 2 * M; i += 256) Ws[i] = W[(size_t)run * 2 * M + i];
+    __syncthreads();
+    const int64_t L = N * sps;
+    const int pad = (M - 1) / 2;
+    const float *x0 = x + (size_t)run * 2 * L, *x1 = x0 + L;
+    float *y0 = yout + (size_t)run * 2 * N, *y1 = y0 + N;
+    float sa0 = 0.f, sa1 = 0.f;
+    for (int64_t n = tid; n < N; n += 256) {
+        float yI = 0.f, yQ = 0.f;
+        for (int k = 0; k < M; k++) {
+            const int64_t s = n * sps + k - pad;
+            if (s < 0 || s >= L) continue;
+            const float a_ = x0[s], b_ = x1[s];
+            yI = fmaf(Ws[k], a_, yI); yI = fmaf(Ws[M + k], b_, yI);
+            yQ = fmaf(Ws[k], b_, yQ); yQ = fmaf(-Ws[M + k], a_, yQ);
+        }
+        y0[n] = yI; y1[n] = yQ;
+        sa0 += fabsf(yI); sa1 += fabsf(yQ);
+    }
+    block_reduce3<256>(sa0, sa1, 0.f, red);
+    if (!q) return;
+    float amp[NLEV], amp2[NLEV];
+#pragma unroll
+    for (int i = 0; i < NLEV; i++) { amp[i] = amp_g[i]; amp2[i] = 0.f; }
+    const float A = amp_mean[run], ivar = 1.0f / var[run];
+    const float s0 = A / (red[0] / (float)N), s1 = A / (red[1] / (float)N);
+    for (int64_t it = tid; it < 2 * N; it += 256) {      // each thread re-reads only the y it wrote? no: any -> fence below
+        const int c = it >= N;
+        const int64_t n = it - (c ? N : 0);
+        float qq[NLEV];
+        // soft_demap computes -(d^2 * i2v + nusc*a^2): i2v = 1/var, nusc = 0 gives (yhat-a)^2/var (:229)
+        soft_demap<NLEV>((c ? y1[n] : y0[n]) * (c ? s1 : s0), amp, amp2, ivar, 0.f, qq);
+#pragma unroll
+        for (int i = 0; i < NLEV; i++) q[((size_t)run * 2 * NLEV + c * NLEV + i) * N + n] = qq[i];
+    }
+}
+
+template <int NT, int NLEV>
+static int launch_awgn(const vaeq_awgn_args &a, size_t lds, hipStream_t st)
+{
+    auto k = awgn_train_kernel<NT, NLEV>;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return VAEQ_ERR_LDS;
+    hipLaunchKernelGGL(k, dim3(a.R), dim3(NT), lds, st, a);
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}
+
+template <int NT>
+static int launch_awgn_lev(const vaeq_awgn_args &a, size_t lds, hipStream_t st)
+{
+    switch (a.n_lev) {
+    case 2: return launch_awgn<NT, 2>(a, lds, st);
+    case 4: return launch_awgn<NT, 4>(a, lds, st);
+    case 8: return launch_awgn<NT, 8>(a, lds, st);
+    }
+    return VAEQ_ERR_SHAPE;
+}
+
+}  // namespace vaeq
+
+extern "C" int64_t vaeq_awgn_lds_bytes(int32_t B, int32_t sps, int32_t M, int32_t n_lev)
+{
+    if (B <= 0 || sps <= 0 || M <= 0 || (M & 1) == 0 || M > 63 || !(n_lev == 2 || n_lev == 4 || n_lev == 8)) return VAEQ_ERR_SHAPE;
+    if ((int64_t)B * sps - 2 * (M / 2) <= 0 || B <= 2 * (M / 2)) return VAEQ_ERR_SHAPE;
+    return (int64_t)vaeq::awgn_layout(B, sps, M).total * 4;
+}
+
+extern "C" int vaeq_awgn_train(const vaeq_awgn_args *pa, void *stream)
+{
+    if (!pa) return VAEQ_ERR_NULL;
+    const vaeq_awgn_args &a = *pa;
+    if (!a.rx || !a.W || !a.h || !a.adam_mW || !a.adam_vW || !a.adam_xW || !a.adam_mh || !a.adam_vh || !a.adam_xh || !a.step ||
+        !a.amp || !a.P || !a.amp_mean || !a.var || !a.lr)
+        return VAEQ_ERR_NULL;
+    const int64_t lds = vaeq_awgn_lds_bytes(a.B, a.sps, a.M, a.n_lev);
+    if (lds < 0) return (int)lds;
+    if (lds > 160 * 1024) return VAEQ_ERR_LDS;
+    if (a.R < 0 || a.steps <= 0) return VAEQ_ERR_SHAPE;
+    if ((int64_t)a.steps * a.B * a.sps > a.S) return VAEQ_ERR_SHAPE;
+    if (a.R == 0) return VAEQ_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (a.threads) {
+    case 0:
+    case 256: return vaeq::launch_awgn_lev<256>(a, (size_t)lds, st);
+    case 128: return vaeq::launch_awgn_lev<128>(a, (size_t)lds, st);
+    case 64: return vaeq::launch_awgn_lev<64>(a, (size_t)lds, st);
+    }
+    return VAEQ_ERR_SHAPE;
+}
+
+extern "C" int vaeq_awgn_forward(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, const float *x, const float *W,
+                                 const float *amp, const float *amp_mean, const float *var, float *q, float *y, void *stream)
+{
+    if (!x || !W || !amp || !amp_mean || !var || !y) return VAEQ_ERR_NULL;
+    if (R < 0 || N < 0 || sps <= 0 || M <= 0 || (M & 1) == 0 || M > 63) return VAEQ_ERR_SHAPE;
+    if (R == 0 || N == 0) return VAEQ_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (n_lev) {
+    case 2: hipLaunchKernelGGL(vaeq::awgn_forward_kernel<2>, dim3(R), dim3(256), 0, st, N, sps, M, x, W, amp, amp_mean, var, q, y); break;
+    case 4: hipLaunchKernelGGL(vaeq::awgn_forward_kernel<4>, dim3(R), dim3(256), 0, st, N, sps, M, x, W, amp, amp_mean, var, q, y); break;
+    case 8: hipLaunchKernelGGL(vaeq::awgn_forward_kernel<8>, dim3(R), dim3(256), 0, st, N, sps, M, x, W, amp, amp_mean, var, q, y); break;
+    default: return VAEQ_ERR_SHAPE;
+    }
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}

@@ -75,7 +75,82 @@ __global__ __launch_bounds__(256) void dp_forward_kernel(int64_t N, int sps, int
     }
 }
 
+// loss_function_shaping alone (shared_funcs.py:92-137): one workgroup per run, moments of q in LDS.
+// Values only -- the training path never calls this (its forward is fused into dp_train_kernel).
+template <int NLEV>
+__global__ __launch_bounds__(256) void dp_loss_kernel(int B, int sps, int M, const float *__restrict__ q, const float *__restrict__ x,
+                                                      const float *__restrict__ h, const float *__restrict__ amp_g,
+                                                      const float *__restrict__ P, float *__restrict__ loss, float *__restrict__ var_est)
+{
+    extern __shared__ float4 smem4[];
+    float *sm = reinterpret_cast<float *>(smem4);
+    const int run = blockIdx.x, tid = threadIdx.x;
+    const int L = B * sps, mh = M / 2, Mh = 2 * mh, nm = L - Mh;
+    float *mu = sm, *vr = sm + 4 * B, *hs = vr + 4 * B, *VS = hs + 8 * M, *red = VS + 2 * M;
+    float amp[NLEV], invP[NLEV];
+#pragma unroll
+    for (int i = 0; i < NLEV; i++) { amp[i] = amp_g[i]; invP[i] = 1.0f / P[(size_t)run * NLEV + i]; }
+    const float *qr = q + (size_t)run * 4 * NLEV * B, *xr = x + (size_t)run * 4 * L;
+    for (int i = tid; i < 8 * M; i += 256) hs[i] = h[(size_t)run * 8 * M + i];
+    float kl = 0.f;
+    for (int it = tid; it < 4 * B; it += 256) {
+        const int vc = it / B, n = it - vc * B;
+        float qq[NLEV], m1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NLEV; i++) { qq[i] = qr[((size_t)vc * NLEV + i) * B + n]; m1 = fmaf(amp[i], qq[i], m1); }
+        float m2 = 0.f;
+        const bool inr = n >= mh && n < B - mh;
+#pragma unroll
+        for (int i = 0; i < NLEV; i++) {
+            const float d = amp[i] - m1;
+            m2 = fmaf(qq[i] * d, d, m2);
+            if (inr) kl = fmaf(qq[i], __logf(qq[i] * invP[i] + 1e-12f), kl);
+        }
+        mu[it] = m1;
+        vr[it] = m2;
+    }
+    __syncthreads();
+    float se0 = 0.f, se1 = 0.f;
+    for (int it = tid; it < 2 * nm; it += 256) {
+        const int chi = it / nm, t = it - chi * nm;
+        float dr = 0.f, di = 0.f;
+        for (int v = 0; v < 2; v++) {
+            const float *hr = hs + ((chi * 2 + v) * 2 + 0) * M, *hi = hr + M;
+            for (int j = (t + Mh) % sps; j <= Mh; j += sps) {
+                const int np = (t + Mh - j) / sps;
+                const float a_ = mu[(v * 2 + 0) * B + np], b_ = mu[(v * 2 + 1) * B + np];
+                dr = fmaf(hr[j], a_, dr); dr = fmaf(-hi[j], b_, dr);
+                di = fmaf(hi[j], a_, di); di = fmaf(hr[j], b_, di);
+            }
+        }
+        const float er = xr[(size_t)(chi * 2 + 0) * L + mh + t] - dr, ei = xr[(size_t)(chi * 2 + 1) * L + mh + t] - di;
+        if (chi) se1 += er * er + ei * ei; else se0 += er * er + ei * ei;
+    }
+    for (int it = tid; it < 2 * M; it += 256) {
+        const int v = it / M, j = it - v * M;
+        const int lo = (Mh - j + sps - 1) / sps, hi_ = (nm - 1 + Mh - j) / sps;
+        float acc = 0.f;
+        for (int np = lo; np <= hi_; np++) acc += vr[(v * 2 + 0) * B + np] + vr[(v * 2 + 1) * B + np];
+        VS[it] = acc;
+    }
+    block_reduce3<256>(se0, se1, kl, red);
+    if (tid == 0) {
+        float C0 = red[0], C1 = red[1];
+        for (int i = 0; i < 2 * M; i++) {
+            const int v = i / M, j = i - v * M;
+            const float a0 = hs[((0 * 2 + v) * 2 + 0) * M + j], b0 = hs[((0 * 2 + v) * 2 + 1) * M + j];
+            const float a1 = hs[((1 * 2 + v) * 2 + 0) * M + j], b1 = hs[((1 * 2 + v) * 2 + 1) * M + j];
+            C0 = fmaf(a0 * a0 + b0 * b0, VS[i], C0);
+            C1 = fmaf(a1 * a1 + b1 * b1, VS[i], C1);
+        }
+        loss[run] = (float)nm * (logf(C0) + logf(C1)) + red[2];
+        var_est[run * 2 + 0] = C0 / (float)nm;
+        var_est[run * 2 + 1] = C1 / (float)nm;
+    }
+}
+
 }  // namespace vaeq
+
 
 extern "C" int vaeq_soft_demap(int32_t R, int64_t N, int32_t n_lev, const float *y, const float *amp, const float *var,
                                const float *nu_sc, float *q, void *stream)
@@ -108,6 +183,33 @@ extern "C" int vaeq_dp_forward(int32_t R, int64_t N, int32_t sps, int32_t M, int
     case 8: hipLaunchKernelGGL(vaeq::dp_forward_kernel<8>, grid, dim3(256), 0, st, N, sps, M, x, W, amp, var, nu_sc, q, y); break;
     default: return VAEQ_ERR_SHAPE;
     }
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}
+
+extern "C" int vaeq_dp_loss(int32_t R, int32_t B, int32_t sps, int32_t M, int32_t n_lev, const float *q, const float *x,
+                            const float *h, const float *amp, const float *P, float *loss, float *var_est, void *stream)
+{
+    if (!q || !x || !h || !amp || !P || !loss || !var_est) return VAEQ_ERR_NULL;
+    if (R < 0 || B <= 0 || sps <= 0 || M <= 0 || (M & 1) == 0 || M > 63 || B * sps - 2 * (M / 2) <= 0 || B <= 2 * (M / 2)) return VAEQ_ERR_SHAPE;
+    if (R == 0) return VAEQ_OK;
+    const size_t lds = sizeof(float) * (size_t)(8 * B + 8 * M + 2 * M + 64);
+    if (lds > 160 * 1024) return VAEQ_ERR_LDS;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define VAEQ_LOSS_CASE(NL)                                                                                                         \
+    case NL: {                                                                                                                     \
+        auto k = vaeq::dp_loss_kernel<NL>;                                                                                         \
+        if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                   (int)lds) != hipSuccess)                                                        \
+            return VAEQ_ERR_LDS;                                                                                                   \
+        hipLaunchKernelGGL(k, dim3(R), dim3(256), lds, st, B, sps, M, q, x, h, amp, P, loss, var_est);                             \
+    } break;
+    switch (n_lev) {
+        VAEQ_LOSS_CASE(2)
+        VAEQ_LOSS_CASE(4)
+        VAEQ_LOSS_CASE(8)
+    default: return VAEQ_ERR_SHAPE;
+    }
+#undef VAEQ_LOSS_CASE
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
 

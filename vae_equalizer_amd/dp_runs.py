@@ -1,0 +1,126 @@
+"""Batched driver of the DP VAE-LE / VAEflex Monte-Carlo runs: what ``processing()`` of
+optical_DP_channel/func_VAELE_DP_MQAM_shaping.py:17-95 and func_VAEflex_DP_MQAM_shaping.py:16-90 does for one run,
+done for R runs per frame with one kernel launch (engine.DPEngine) and one batched epilogue (epilogue.py).
+
+Runs in one batch share (mod, sps, M_est, batch_len, N_frame_max, num_frames, flex_step, channel, N_lrhalf) -- the
+shape of the problem -- and may differ in SNR, nu, theta_diff, theta, lr_optim, symb_rate and seed.
+"""
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import channel as ch
+from . import epilogue as epi
+from . import shared_funcs as sfun
+from .engine import DPEngine
+
+
+@dataclass
+class DPRun:
+    """One sweep point (the per-run arguments of processing())."""
+    SNR: float
+    nu: float
+    theta_diff: float
+    theta: float
+    lr_optim: float
+    symb_rate: float
+    seed: int = None
+
+
+def default_device():
+    if not torch.cuda.is_available():
+        from ._native import VaeqError
+        raise VaeqError("no GPU visible: the VAE training path runs only on the HIP device (there is no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def run_dp_batch(runs, mod, sps, M_est, batch_len, N_frame_max, num_frames, flex_step, channel, tau_cd, tau_pmd, phiIQ,
+                 N_lrhalf, flex=False, device=None, generator="numpy", verbose=False, threads=0, keep_last=False):
+    """Train + evaluate R runs.  Returns dict(SER[R,4,num_frames], Var_est[R,2,num_frames], var[R,2]) on the CPU.
+
+    generator: "numpy" = reference-faithful host simulator per run (seeded per run when DPRun.seed is set);
+               "torch" = batched on-device simulator (channel.generate_batch_gpu), seeded from the first run's seed.
+    """
+    device = default_device() if device is None else torch.device(device)
+    R = len(runs)
+    tabs = [sfun.qam_tables(mod, r.nu) for r in runs]
+    h_channel = sfun.upsampled_channel(channel, sps)
+    amps = tabs[0]["amps"]
+    amp = torch.tensor(amps, dtype=torch.float32, device=device)
+    n_lev = amp.numel()
+    P = np.stack([t["P"] for t in tabs])
+    nu_sc = np.array([t["nu_sc"] for t in tabs])
+    pow_mean = np.array([t["pow_mean"] for t in tabs])
+    var_np = np.stack([np.full(2, t["pow_mean"] / 10 ** (r.SNR / 10) / 2) for t, r in zip(tabs, runs)]).astype(np.float32)
+    var = torch.tensor(var_np, device=device)
+    nu_sc_t = torch.tensor(nu_sc, dtype=torch.float32, device=device)
+    eng = DPEngine(R, M_est, amp, P, var, nu_sc, device, sps, threads)
+
+    # frame geometry: func_VAELE_DP_MQAM_shaping.py:38-39 / func_VAEflex_DP_MQAM_shaping.py:37-40
+    m_max = N_frame_max // batch_len
+    N_frame = m_max * batch_len
+    if flex:
+        N_out = (N_frame - batch_len) // flex_step * flex_step
+        steps, stride, k0, klen = N_out // flex_step, flex_step, (batch_len - flex_step) // 2, flex_step
+    else:
+        N_out, steps, stride, k0, klen = N_frame, m_max, batch_len, 0, batch_len
+
+    theta = np.array([r.theta for r in runs], dtype=np.float64)
+    theta_diff = np.array([r.theta_diff for r in runs], dtype=np.float64)
+    lr0 = np.array([r.lr_optim for r in runs], dtype=np.float32)
+    streams = [ch.SeededStreams(r.seed) if r.seed is not None else None for r in runs]
+    tgen = None
+    if generator == "torch":
+        tgen = torch.Generator(device=device)
+        tgen.manual_seed(int(runs[0].seed) if runs[0].seed is not None else torch.seed())
+
+    SER = torch.empty(R, 4, num_frames, dtype=torch.float32)
+    Var_est = torch.empty(R, 2, num_frames, dtype=torch.float32)
+    last = None
+    for frame in range(num_frames):
+        # lr schedule: group 0 (W) only, set (not multiplied) to lr/2 (func_VAELE_DP_MQAM_shaping.py:45-46)
+        # -> lr from frame 0, lr/2 from frame N_lrhalf on (every later trigger re-sets the same value)
+        cur_lr_W = lr0 * 0.5 if frame >= N_lrhalf else lr0
+        if generator == "torch":
+            SNRs = np.array([r.SNR for r in runs], dtype=np.float32)
+            srate = runs[0].symb_rate
+            rx, data = ch.generate_batch_gpu(R, N_frame, amps, P, SNRs, h_channel, srate, sps, tau_cd, tau_pmd, phiIQ, theta,
+                                             device, generator=tgen)
+        else:
+            rxs, datas = [], []
+            for i, r in enumerate(runs):
+                st = streams[i]
+                rx_i, d_i, _ = ch.generate_data_shaping(N_frame, amps, r.SNR, h_channel, tabs[i]["P"], 2, r.symb_rate, sps, tau_cd,
+                                                        tau_pmd, phiIQ, theta[i], "cpu", rng=st.next_rng() if st else None,
+                                                        noise=st.noise if st else None)
+                rxs.append(rx_i)
+                datas.append(d_i)
+            rx = torch.stack(rxs).to(device, non_blocking=True)
+            data = torch.stack(datas).to(device, non_blocking=True)
+        theta = theta + theta_diff                                              # :51
+        if flex:
+            data = data[:, :, :, batch_len // 2:N_out + batch_len // 2]          # func_VAEflex...:51
+        out = eng.train(rx, batch_len, steps, cur_lr_W, lr0, stride=stride, keep_off=k0, keep_len=klen)
+        q, y = out["q"][:, 0], out["y"][:, 0]
+        ve = out["var_est"][:, 0]                                               # [R,2,steps]
+        Var_est[:, :, frame] = ve.mean(dim=2).cpu()                             # :69
+        res = epi.dp_frame_epilogue(q, y, data, amp, nu_sc_t, var, None if flex else batch_len)
+        SER[:, :, frame] = res["SER"].cpu()
+        if verbose:
+            loss = out["loss"][:, 0, -1].cpu()
+            snr_est = torch.tensor(pow_mean, dtype=torch.float32) / ve.mean(dim=(1, 2)).cpu()   # :68
+            for i in range(R):
+                tag = f"[run {i}] " if R > 1 else ""
+                print(f"{tag}{frame}", "\t\ttraining: loss = ", loss[i].item(), "\tshift_x = ", res["shift_c"][i, 0].item(),
+                      "\tshift_y = ", res["shift_c"][i, 1].item(), "\tr = ", int(res["r_c"][i]), "\tSNR_est = ",
+                      10 * math.log10(snr_est[i].item()))
+                print("\t\t\t\t\t\t\tSER_x = ", SER[i, 0, frame].item(), "\tSER_y = ", SER[i, 1, frame].item(), "\t(constell. with shaping)")
+                print("\t\t\t\t\t\t\tSER_x = ", SER[i, 2, frame].item(), "\tSER_y = ", SER[i, 3, frame].item(), "\t(soft demapper)")
+        if keep_last and frame == num_frames - 1:
+            last = dict(q=q, y=y, data=data, rx=rx, **res)
+    ret = dict(SER=SER, Var_est=Var_est, var=torch.tensor(var_np), engine=eng)
+    if last is not None:
+        ret["last"] = last
+    return ret

@@ -139,3 +139,85 @@ def dp_forward(x, W, amp_levels, var, nu_sc, sps=2, want_q=True):
     if squeeze:
         return (q[0] if want_q else None), y[0]
     return q, y
+
+
+def dp_loss(q, rx, h, amp_levels, P):
+    """loss_function_shaping values on device: q[R,2,2n,B], rx[R,2,2,B*sps], h[R,2,2,2,M] (or unbatched) -> (loss, var_est)."""
+    squeeze = q.dim() == 3
+    if squeeze:
+        q, rx, h = q.unsqueeze(0), rx.unsqueeze(0), h.unsqueeze(0)
+    dev, R, B = q.device, q.shape[0], q.shape[-1]
+    sps, M = rx.shape[-1] // B, h.shape[-1]
+    amp = _f32(amp_levels, dev).reshape(-1)
+    n = amp.numel()
+    Pt = _f32(P, dev)
+    Pt = (Pt.expand(R, n) if Pt.dim() == 1 else Pt).contiguous()
+    q, rx, h = q.contiguous(), rx.contiguous(), h.contiguous()
+    loss = torch.empty(R, dtype=torch.float32, device=dev)
+    ve = torch.empty(R, 2, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().vaeq_dp_loss(R, B, sps, M, n, nat.ptr(q), nat.ptr(rx), nat.ptr(h), nat.ptr(amp), nat.ptr(Pt),
+                                         nat.ptr(loss), nat.ptr(ve), nat.current_stream(dev)), "vaeq_dp_loss")
+    return (loss[0], ve[0]) if squeeze else (loss, ve)
+
+
+class AWGNEngine:
+    """R single-polarisation VAE-LE runs (AWGN_channel/func_VAELE_MQAM_shaping.py:275-286): twoFIR weight, h_est and the
+    two Adam(amsgrad=True) groups, device-resident."""
+
+    def __init__(self, R, M_est, amp_levels, P, amp_mean, var, device="cuda:0", sps=2, threads=0):
+        if M_est % 2 == 0:
+            raise ValueError("M_est must be odd")
+        self.device = torch.device(device)
+        self.R, self.M, self.sps, self.threads = int(R), int(M_est), int(sps), int(threads)
+        self.amp = _f32(amp_levels, self.device).reshape(-1)
+        self.n_lev = self.amp.numel()
+        pr = lambda x, shape: DPEngine._per_run(self, x, shape)
+        self.P, self.amp_mean, self.var = pr(P, (self.n_lev,)), pr(amp_mean, ()), pr(var, ())
+        z = lambda: torch.zeros(R, 2, self.M, dtype=torch.float32, device=self.device)
+        self.W, self.h = z(), z()
+        self.mW, self.vW, self.xW, self.mh, self.vh, self.xh = z(), z(), z(), z(), z(), z()
+        self.step = torch.zeros(R, dtype=torch.int32, device=self.device)
+        self.W[:, 0, self.M // 2] = 1.0   # nn.init.dirac_ (:210)
+        self.h[:, 0, self.M // 2] = 1.0   # (:279)
+
+    def set_state(self, W=None, h=None):
+        if W is not None:
+            self.W.copy_(_f32(W, self.device).reshape(-1, 2, self.M).expand_as(self.W))
+        if h is not None:
+            self.h.copy_(_f32(h, self.device).expand_as(self.h))
+
+    def train(self, rx, B, steps, lr, want_q=False, want_y=False, debug_grads=False, no_update=False):
+        """rx[R,2,S] -> dict(loss[R,steps], q[R,2n,steps*B]?, y[R,2,steps*B]?, gW?, gh?)."""
+        R, S = rx.shape[0], rx.shape[-1]
+        if R != self.R or rx.shape[1] != 2:
+            raise ValueError(f"rx must be [R={self.R}, 2, S], got {tuple(rx.shape)}")
+        lr_t = DPEngine._per_run(self, lr, ())
+        dev = self.device
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        out = {"loss": e(R, steps), "q": e(R, 2 * self.n_lev, steps * B) if want_q else None,
+               "y": e(R, 2, steps * B) if want_y else None, "gW": e(R, 2, self.M) if debug_grads else None,
+               "gh": e(R, 2, self.M) if debug_grads else None}
+        a = nat.AWGNArgs(R=R, steps=steps, B=B, sps=self.sps, M=self.M, n_lev=self.n_lev, S=S, rx=nat.ptr(rx), W=nat.ptr(self.W),
+                         h=nat.ptr(self.h), adam_mW=nat.ptr(self.mW), adam_vW=nat.ptr(self.vW), adam_xW=nat.ptr(self.xW),
+                         adam_mh=nat.ptr(self.mh), adam_vh=nat.ptr(self.vh), adam_xh=nat.ptr(self.xh),
+                         step=nat.ptr(self.step, torch.int32), amp=nat.ptr(self.amp), P=nat.ptr(self.P),
+                         amp_mean=nat.ptr(self.amp_mean), var=nat.ptr(self.var), lr=nat.ptr(lr_t), q_out=nat.ptr(out["q"]),
+                         y_out=nat.ptr(out["y"]), loss=nat.ptr(out["loss"]), dbg_gW=nat.ptr(out["gW"]), dbg_gh=nat.ptr(out["gh"]),
+                         threads=self.threads, no_update=int(no_update))
+        with torch.cuda.device(dev):
+            nat.check(nat.lib().vaeq_awgn_train(C.byref(a), nat.current_stream(dev)), "vaeq_awgn_train")
+        out["_keepalive"] = (lr_t, rx)
+        return out
+
+    def forward(self, x, want_q=True):
+        """Validation pass (:313): x[R,2,N*sps] -> (q[R,2n,N] or None, y[R,2,N])."""
+        R, N = x.shape[0], x.shape[-1] // self.sps
+        x = x.contiguous()
+        q = torch.empty(R, 2 * self.n_lev, N, dtype=torch.float32, device=self.device) if want_q else None
+        y = torch.empty(R, 2, N, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().vaeq_awgn_forward(R, N, self.sps, self.M, self.n_lev, nat.ptr(x), nat.ptr(self.W), nat.ptr(self.amp),
+                                                  nat.ptr(self.amp_mean), nat.ptr(self.var), nat.ptr(q), nat.ptr(y),
+                                                  nat.current_stream(self.device)), "vaeq_awgn_forward")
+        return q, y

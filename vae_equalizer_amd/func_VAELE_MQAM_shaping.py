@@ -1,0 +1,83 @@
+"""Drop-in for AWGN_channel/func_VAELE_MQAM_shaping.py: same ``processing`` signature (:235) and return value (:324),
+with the training loop and the validation forward pass on the HIP kernels (engine.AWGNEngine)."""
+import numpy as np
+import torch
+
+from . import channel as ch
+from .dp_runs import default_device
+from .engine import AWGNEngine
+from .shared_funcs import _CHANNELS, qam_tables
+
+
+def awgn_tables(mod, nu, SNR, channel, sps):
+    """Constants processing() derives before the loop (:239-272)."""
+    if channel not in ("h1", "h2"):
+        raise UnboundLocalError(f"unknown channel {channel!r} (the reference leaves h_channel_orig unbound, :239-244)")
+    ir = np.array(_CHANNELS[channel]).astype(np.complex64)
+    h_channel = np.zeros(sps * (ir.shape[-1] - 1) + 1, dtype=np.complex64)
+    h_channel[0::sps] = ir
+    h_channel /= np.linalg.norm(h_channel)
+    t = qam_tables(mod, nu)
+    n = t["n"]
+    PP = np.tile(t["P"], (n, 1))
+    shaped = (PP * PP.T).reshape(-1) * t["constellation"]                       # :270
+    amp_mean = np.sum(np.abs(shaped.real) + np.abs(shaped.imag)) / 2             # :271
+    return dict(amps=t["amps"], P=t["P"], amp_mean=amp_mean, var=10 ** (-SNR / 10), h_channel=h_channel, M_channel=len(ir), n=n)
+
+
+def find_shift(q, tx, N_shift, amp_levels, num_lev, device=None):
+    """:188-204 -- lag of the best |correlation| between E_q[x_I] and the TX I (or Q) sequence over the first 1000 symbols."""
+    E = torch.einsum("i,in->n", amp_levels, q[:num_lev, :1000])
+    half = N_shift // 2
+    E_mat = torch.stack([torch.roll(E, i - half, 0) for i in range(N_shift)], dim=1)
+    corr = tx[0, :1000].to(torch.float32) @ E_mat
+    if torch.max(torch.abs(corr)) >= 0.02 * q.shape[-1]:
+        return half - torch.argmax(torch.abs(corr))
+    corr_IQ = tx[1, :1000].to(torch.float32) @ E_mat
+    if torch.max(torch.abs(corr_IQ)) >= torch.max(torch.abs(corr)):
+        return half - torch.argmax(torch.abs(corr_IQ))
+    return half - torch.argmax(torch.abs(corr))
+
+
+def SER_q(q, tx, sps, num_lev, device=None):
+    """:97-123 -- SER of argmax(q) against TX, minimum over the four quadrant rotations."""
+    N = tx.shape[-1]
+    scale = (num_lev - 1) / 2
+    data = torch.round(scale * tx.float() + scale)
+    dec = torch.stack([q[:num_lev, :N].argmax(dim=0), q[num_lev:, :N].argmax(dim=0)]).float()
+    dec_pi = -(dec - scale * 2)
+    dec_pi4 = torch.stack([-(dec[1] - scale * 2), dec[0]])
+    dec_3pi4 = -(dec_pi4 - scale * 2)
+    return torch.stack([((data - d) != 0).any(dim=0).float().mean() for d in (dec, dec_pi, dec_pi4, dec_3pi4)]).min()
+
+
+def processing(mod, sps, SNR, nu, M_est, lr_optim, batch_len, N_valid, N_train, num_epochs, epe, channel, *, seed=None,
+               device=None, verbose=True):
+    """One AWGN VAE-LE run -> SER_valid[num_epochs//epe] (CPU float32).
+
+    NB the sweep script passes its ``N_train`` (350) as ``batch_len`` and ``train_len`` (1200) as ``N_train``
+    (Eval_run_shaping_vaele.py:53)."""
+    device = default_device() if device is None else torch.device(device)
+    if verbose:
+        print("We are using the following device for learning:", device)
+    t = awgn_tables(mod, nu, SNR, channel, sps)
+    amp = torch.tensor(t["amps"], dtype=torch.float32, device=device)
+    eng = AWGNEngine(1, M_est, amp, t["P"], t["amp_mean"], t["var"], device, sps)
+    st = ch.SeededStreams(seed) if seed is not None else None
+    SER_valid = torch.empty(num_epochs // epe, dtype=torch.float32)
+    steps = N_train // batch_len                                                 # :297 (the remainder is dropped)
+    for epoch in range(num_epochs):
+        rx, _ = ch.generate_data(N_train, t["M_channel"], t["amps"], SNR, t["h_channel"], sps, "cpu", t["P"],
+                                 rng=st.next_rng() if st else None, noise=st.noise if st else None)
+        out = eng.train(rx.unsqueeze(0).to(device), batch_len, steps, lr_optim)
+        if epoch % epe == 0:                                                     # :308-318
+            rxv, datav = ch.generate_data(N_valid, t["M_channel"], t["amps"], SNR, t["h_channel"], sps, "cpu", t["P"],
+                                          rng=st.next_rng() if st else None, noise=st.noise if st else None)
+            q, _ = eng.forward(rxv.unsqueeze(0).to(device))
+            q, datav = q[0], datav.to(device)
+            shift = find_shift(q, datav, 21, amp, t["n"])
+            sh = int(shift)
+            SER_valid[epoch // epe] = SER_q(q[:, 11 + sh:-11], datav[:, 11:-11 - sh], sps, t["n"]).cpu()
+            if verbose:
+                print(epoch, out["loss"][0, -1].item(), sh, '\t\t\t\t\t\tSER = ', SER_valid[epoch // epe].item())
+    return SER_valid

@@ -1,0 +1,60 @@
+"""Sharding of an embarrassingly parallel parameter sweep over the GPUs of one node.
+
+Run index r goes to rank r % world_size; every rank trains its runs with no communication, then ONE all_gather of
+the per-run result rows (RCCL over xGMI when the backend is ``nccl``; ``gloo`` in the CPU tests) reassembles the
+full result tensors on every rank.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def dist_info():
+    """(rank, world_size, local_rank) from torch.distributed if initialised, else from the launcher's environment."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size(), int(os.environ.get("LOCAL_RANK", 0))
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+
+
+def init_distributed(backend=None):
+    """Initialise the process group when launched by torch.distributed.run with WORLD_SIZE > 1 (one process per GPU)."""
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        dist.init_process_group(backend=backend)
+    return dist_info()
+
+
+def my_slice(n_runs, rank=None, world=None):
+    """Indices of the runs this rank owns: r = rank (mod world)."""
+    if rank is None:
+        rank, world, _ = dist_info()
+    return list(range(rank, n_runs, world))
+
+
+def gather_rows(local_rows, n_runs, rank=None, world=None):
+    """local_rows[len(my_slice), ...] float32 -> rows[n_runs, ...] in run order, on every rank (a single all_gather)."""
+    if rank is None:
+        rank, world, _ = dist_info()
+    if world == 1:
+        return local_rows
+    per = (n_runs + world - 1) // world
+    shape = (per,) + tuple(local_rows.shape[1:])
+    backend = dist.get_backend()
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    buf = torch.zeros(shape, dtype=torch.float32, device=dev)
+    buf[:local_rows.shape[0]] = local_rows.to(dev)
+    allbuf = torch.empty((world * per,) + shape[1:], dtype=torch.float32, device=dev)   # concatenation form: nccl and gloo
+    dist.all_gather_into_tensor(allbuf, buf)
+    allbuf = allbuf.cpu().reshape((world,) + shape)
+    out = torch.empty((n_runs,) + tuple(local_rows.shape[1:]), dtype=torch.float32)
+    for k in range(world):
+        idx = list(range(k, n_runs, world))
+        out[idx] = allbuf[k, :len(idx)]
+    return out
