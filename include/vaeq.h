@@ -85,7 +85,9 @@ typedef struct vaeq_dp_args {
     float *var_est;      /* nullable [R][n_frames][2][steps]                     C/(N-Mh) per minibatch */
     float *dbg_gW;       /* nullable [R][2][4][M]     gradient of the LAST step (parity tests) */
     float *dbg_gh;       /* nullable [R][2][2][2][M] */
-    int32_t threads;     /* workgroup size per run: 0 = library default, else 64 / 128 / 256 */
+    int32_t threads;     /* kernel choice: 0 = automatic (wave-per-run fast path when the shape allows, else generic/256);
+                            1 = wave-per-run only (VAEQ_ERR_SHAPE if unsupported); 64 / 128 / 256 = generic kernel, that
+                            many threads per run */
     int32_t no_update;   /* 1: skip the Adam update (forward + loss + gradients only) */
 } vaeq_dp_args;
 

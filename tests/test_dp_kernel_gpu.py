@@ -26,7 +26,7 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
-@pytest.mark.parametrize("threads", [64, 128, 256])
+@pytest.mark.parametrize("threads", [0, 64, 128, 256])
 @pytest.mark.parametrize("name", G1)
 def test_teacher_forced_step(name, threads):
     """One minibatch from a random (non-Dirac) state: q, y, ELBO, var_est, gradients, and the Adam update (R1-R5)."""
@@ -84,7 +84,7 @@ def test_no_update_leaves_state():
     assert int(eng.step[0]) == 0 and float(eng.mW.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("threads", [64, 256])
+@pytest.mark.parametrize("threads", [1, 64, 256])
 def test_freerun_vaele_golden(threads):
     """G2: 20 free-running steps from the Dirac start: ELBO per minibatch and taps <= 1e-5 (north_star)."""
     g = load_golden("G2_dp_freerun")
@@ -102,11 +102,12 @@ def test_freerun_vaele_golden(threads):
     assert relerr(_np(r["var_est"])[0, 0], g["var_est"][:, :20]) < 1e-5
 
 
-def test_freerun_flex_golden():
-    """G3: VAEflex windows (stride 10, centre slice kept), 30 steps."""
+@pytest.mark.parametrize("threads", [1, 256])
+def test_freerun_flex_golden(threads):
+    """G3: VAEflex windows (stride 10, centre slice kept), 30 steps (threads=1: wave-per-run kernel, scalar-store variant)."""
     g = load_golden("G3_dp_flex_freerun")
     B, fs, ns = int(g["B"]), int(g["flex_step"]), int(g["n_steps"])
-    eng = _engine(g)
+    eng = _engine(g, threads=threads)
     rx = torch.from_numpy(g["rx"][None]).to(DEV)
     r = eng.train(rx, B, ns, float(g["lr"]), stride=fs, keep_off=(B - fs) // 2, keep_len=fs)
     torch.cuda.synchronize()
@@ -192,3 +193,44 @@ def test_error_codes():
         DPEngine(1, 24, g["amp_levels"], g["P"], g["var"], 0.0, DEV)
     with pytest.raises(nat.VaeqError):          # CPU tensors are refused: there is no CPU path
         eng.train(torch.zeros(1, 1, 2, 2, 400), 100, 1, 1e-3)
+
+
+@pytest.mark.parametrize("B,M,n", [(100, 25, 8), (64, 25, 4), (128, 13, 2), (50, 9, 8), (26, 25, 8)])
+def test_wave_kernel_equals_generic_kernel(B, M, n):
+    """The wave-per-run fast path (threads=1) and the generic kernel (threads=256) agree on ragged shapes, 5 free steps, R=9."""
+    from vae_equalizer_amd.engine import DPEngine
+    rng = np.random.default_rng(B + M)
+    R, sps, steps = 9, 2, 5
+    lev = np.arange(-(n - 1), n, 2).astype(np.float32)
+    amp = lev / np.sqrt(np.mean(lev ** 2) * 2).astype(np.float32)
+    P = rng.dirichlet(np.ones(n) * 5, R).astype(np.float32)
+    var = rng.uniform(0.002, 0.02, (R, 2)).astype(np.float32)
+    nu_sc = rng.uniform(0, 1, R).astype(np.float32)
+    lr = rng.uniform(1e-3, 4e-3, R).astype(np.float32)
+    rx = torch.from_numpy((0.4 * rng.standard_normal((R, 2, 2, steps * B * sps))).astype(np.float32)).to(DEV)
+    outs = []
+    for th in (1, 256):
+        eng = DPEngine(R, M, amp, P, var, nu_sc, DEV, sps, th)
+        eng.set_state(eng.W + 0.03 * torch.randn(eng.W.shape, generator=torch.Generator().manual_seed(1)).to(DEV),
+                      eng.h + 0.03 * torch.randn(eng.h.shape, generator=torch.Generator().manual_seed(2)).to(DEV))
+        r = eng.train(rx, B, steps, lr, debug_grads=True)
+        torch.cuda.synchronize()
+        outs.append((r, eng))
+    (ra, ea), (rb, eb) = outs
+    assert relerr(_np(ra["loss"]), _np(rb["loss"])) < 2e-6
+    assert relerr(_np(ra["y"]), _np(rb["y"])) < 1e-5
+    assert np.max(np.abs(_np(ra["q"]) - _np(rb["q"]))) < 2e-4
+    assert relerr(_np(ra["var_est"]), _np(rb["var_est"])) < 1e-5
+    assert relerr(_np(ra["gW"]), _np(rb["gW"])) < 1e-4 and relerr(_np(ra["gh"]), _np(rb["gh"])) < 1e-4
+    assert np.max(np.abs(_np(ea.W) - _np(eb.W))) < 2e-5 and np.max(np.abs(_np(ea.h) - _np(eb.h))) < 2e-5
+    assert relerr(_np(ea.mW), _np(eb.mW)) < 1e-4 and relerr(_np(ea.vh), _np(eb.vh)) < 1e-4
+    assert torch.equal(ea.step, eb.step)
+
+
+def test_wave_kernel_refused_for_unsupported_shape():
+    from vae_equalizer_amd import _native as nat
+    from vae_equalizer_amd.engine import DPEngine
+    g = load_golden("G1_dp_step_4qam")          # B = 37 is odd
+    eng = DPEngine(1, int(g["M_est"]), g["amp_levels"], g["P"], g["var"], float(g["nu_sc"]), DEV, 2, threads=1)
+    with pytest.raises(nat.VaeqError):
+        eng.train(torch.from_numpy(g["rx"][None]).to(DEV), int(g["B"]), 1, 1e-3)

@@ -13,7 +13,7 @@ import torch
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "libvaeq_hip.so")
-SOURCES = ["vaeq_dp.hip", "vaeq_awgn.hip", "vaeq_misc.hip"]
+SOURCES = ["vaeq_dp.hip", "vaeq_dp_wave.hip", "vaeq_awgn.hip", "vaeq_misc.hip"]
 HEADERS = ["vaeq_common.h"]
 _LIB = None
 

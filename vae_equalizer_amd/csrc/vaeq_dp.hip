@@ -33,6 +33,10 @@
 
 namespace vaeq {
 
+// wave-per-run fast path (vaeq_dp_wave.hip)
+bool dp_wave_supported(const vaeq_dp_args &a);
+int launch_dp_wave(const vaeq_dp_args &a, hipStream_t st);
+
 // ---------------------------------------------------------------- LDS carve
 struct DPLayout {
     int L, mh, Mh, nm, Lp;
@@ -421,6 +425,8 @@ extern "C" int vaeq_dp_train(const vaeq_dp_args *pa, void *stream)
     if (((int64_t)(a.steps - 1) * a.stride_sym + a.B) * a.sps > a.S) return VAEQ_ERR_SHAPE;  // last window inside the row
     if (a.R == 0) return VAEQ_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (a.threads == 1 && !vaeq::dp_wave_supported(a)) return VAEQ_ERR_SHAPE;
+    if ((a.threads == 0 || a.threads == 1) && vaeq::dp_wave_supported(a)) return vaeq::launch_dp_wave(a, st);
     switch (a.threads) {
     case 0:
     case 256: return vaeq::launch_dp_lev<256>(a, (size_t)lds, st);

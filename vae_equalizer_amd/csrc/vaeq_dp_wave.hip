@@ -1,0 +1,635 @@
+// vaeq_dp_wave.hip -- wave-per-run fast path of the DP VAE-LE / VAEflex training loop (gfx950).
+//
+// One 64-lane wavefront = one run; no workgroup barriers, everything between HBM and the taps lives in LDS/VGPRs.
+// Same math as vaeq_dp.hip (see the derivation there and in DESIGN.md); what changes is the mapping:
+//
+//   * lane l owns the symbol pair (2l, 2l+1) of the minibatch (B <= 128): FIR, soft demap, the per-symbol moments
+//     (kept in registers until the backward pass) and dL/dy are all done by the owning lane; q and y leave as one
+//     8-byte store per lane and row (400 contiguous bytes per row and step at B = 100).
+//   * every convolution-shaped phase is register-blocked over that pair and over both outputs: a tap quad is read once
+//     (LDS broadcast) and feeds 16 FMAs
+//     (FIR:  y[n]      = sum_k w[k] x[2n+k],
+//      dL/dU[n]        = sum_j e[2n+j] conj(h[j])    -- the same shape on the residual e,
+//      D[t], t=4l..4l+3: the zero-stuffed convolution, written as two polyphase symbol-rate FIRs on mu).
+//   * sample-rate arrays (x, e) are stored 4-way polyphase in LDS (index c -> [c & 3][c >> 2]) and the symbol-rate mu
+//     2-way, so that the stride-4 / stride-2 accesses of consecutive lanes hit consecutive 8-byte LDS words.
+//   * the two correlation-shaped gradients (dL/dh: 100 outputs x 88 terms, dL/dw: 100 x 100) are laid out as
+//     lane = (tap, half of the sum range); halves are combined with one cross-half shuffle; the lane that ends up
+//     with a gradient also owns that parameter's Adam moments (registers) and writes the updated tap to LDS.
+//   * reductions (sum |e|^2, KL) are fixed-order xor butterflies: bitwise reproducible.
+//
+// Supported here: sps == 2, B even, 2*(M/2)+2 <= B <= 128, M in the instantiated set; everything else takes the
+// generic kernel of vaeq_dp.hip.  BT > 0 bakes the minibatch length into the kernel (all LDS offsets immediate).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vaeq.h"
+#include "vaeq_common.h"
+
+namespace vaeq {
+
+struct WaveLayout {
+    int Lph, Uph;                                      // float2 per polyphase component of x/e and of mu
+    int X, E, U, PSv, W, H, PSh, VS, total;            // byte offsets (the dL/dy buffer aliases U)
+};
+
+__host__ __device__ inline WaveLayout wave_layout(int B, int M)
+{
+    WaveLayout l;
+    const int len = 2 * B + M - 1;                     // L + 2*mh samples incl. zero halo
+    int lph = (len + 3) / 4 + 1;
+    while ((lph & 31) != 8 && (lph & 31) != 24) lph++; // phase arrays 16 (mod 64) dwords apart: conflict-free strided reads
+    l.Lph = lph;
+    l.Uph = B / 2 + 1;
+    int o = 0;
+    auto take = [&](int bytes) { int r = o; o += (bytes + 15) & ~15; return r; };
+    l.X = take(2 * 4 * lph * 8);
+    l.E = take(2 * 4 * lph * 8);
+    const int ubytes = 2 * 2 * l.Uph * 8, gbytes = 2 * B * 8;
+    l.U = take(ubytes > gbytes ? ubytes : gbytes);
+    l.PSv = take(2 * (B + 1) * 4);
+    l.W = take(2 * M * 16);
+    l.H = take(2 * 2 * (M + 1) * 8);                   // one zero pad tap per (chi, nu): j = M
+    l.PSh = take(2 * (M + 1) * 4);
+    l.VS = take(2 * M * 4);
+    l.total = o;
+    return l;
+}
+
+__device__ __forceinline__ void cmac(float2 &acc, float wr, float wi, float2 x)       // acc += (wr + j wi) * x
+{
+    acc.x = fmaf(wr, x.x, acc.x);
+    acc.x = fmaf(-wi, x.y, acc.x);
+    acc.y = fmaf(wr, x.y, acc.y);
+    acc.y = fmaf(wi, x.x, acc.y);
+}
+__device__ __forceinline__ void cmacc(float2 &acc, float2 a, float br, float bi)      // acc += a * conj(br + j bi)
+{
+    acc.x = fmaf(a.x, br, acc.x);
+    acc.x = fmaf(a.y, bi, acc.x);
+    acc.y = fmaf(a.y, br, acc.y);
+    acc.y = fmaf(-a.x, bi, acc.y);
+}
+
+__device__ __forceinline__ float wave_incl_scan(float v, int lane)                    // inclusive prefix sum over lanes
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// y[sym] += sum_k taps[k] * x[4l + 2*sym + k] for the lane's symbol pair, one input polarisation (FIR) -- or the same
+// shape on the residual with conjugated channel taps (dL/dU).  xp = phase-0 pointer of the lane (slot = lane).
+//   FIR : T = float4 tap quads (o0.re, o0.im, o1.re, o1.im), acc[sym][o]  += w * x
+//   DU  : two float2 tap arrays (nu = 0, 1),                   acc[sym][nu] += e * conj(h)
+template <int M, bool CONJ>
+__device__ __forceinline__ void pair_fir(float2 (&acc)[2][2], const float2 *xp, int Lph, const float4 *wq, const float2 *ha,
+                                         const float2 *hb)
+{
+    auto tap = [&](int k, float &ar, float &ai, float &br, float &bi) {
+        if (CONJ) {
+            const float2 a_ = ha[k], b_ = hb[k];
+            ar = a_.x; ai = a_.y; br = b_.x; bi = b_.y;
+        } else {
+            const float4 w = wq[k];
+            ar = w.x; ai = w.y; br = w.z; bi = w.w;
+        }
+    };
+    auto mac = [&](int sy, float2 x, float ar, float ai, float br, float bi) {
+        if (CONJ) { cmacc(acc[sy][0], x, ar, ai); cmacc(acc[sy][1], x, br, bi); }
+        else { cmac(acc[sy][0], ar, ai, x); cmac(acc[sy][1], br, bi, x); }
+    };
+    constexpr int G = M / 4;
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {                      // taps 4g..4g+3, samples c' = 4g..4g+5
+        const float2 *xg = xp + g;
+        const float2 x0 = xg[0], x1 = xg[Lph], x2 = xg[2 * Lph], x3 = xg[3 * Lph], x4 = xg[1], x5 = xg[Lph + 1];
+        float ar, ai, br, bi;
+        tap(4 * g + 0, ar, ai, br, bi); mac(0, x0, ar, ai, br, bi); mac(1, x2, ar, ai, br, bi);
+        tap(4 * g + 1, ar, ai, br, bi); mac(0, x1, ar, ai, br, bi); mac(1, x3, ar, ai, br, bi);
+        tap(4 * g + 2, ar, ai, br, bi); mac(0, x2, ar, ai, br, bi); mac(1, x4, ar, ai, br, bi);
+        tap(4 * g + 3, ar, ai, br, bi); mac(0, x3, ar, ai, br, bi); mac(1, x5, ar, ai, br, bi);
+    }
+#pragma unroll
+    for (int k = 4 * G; k < M; k++) {                  // remaining 1 or 3 taps
+        float ar, ai, br, bi;
+        tap(k, ar, ai, br, bi);
+        mac(0, xp[(k & 3) * Lph + (k >> 2)], ar, ai, br, bi);
+        mac(1, xp[((k + 2) & 3) * Lph + ((k + 2) >> 2)], ar, ai, br, bi);
+    }
+}
+
+template <int M, int NLEV, int BT, bool PAIR>
+__global__ __launch_bounds__(64, 3) void dp_wave_kernel(const vaeq_dp_args a)
+{
+    constexpr int mh = M / 2, Mh = 2 * mh, MP = M + 1;
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    extern __shared__ float4 smem4[];
+    char *sm = reinterpret_cast<char *>(smem4);
+    const int lane = threadIdx.x, run = blockIdx.x;
+    const int B = BT ? BT : a.B;
+    const int L = 2 * B, nm = L - Mh, P2 = B / 2;
+    const WaveLayout lay = wave_layout(B, M);
+    const int Lph = lay.Lph, Uph = lay.Uph;
+    float2 *Xs = reinterpret_cast<float2 *>(sm + lay.X), *Es = reinterpret_cast<float2 *>(sm + lay.E);
+    float2 *Us = reinterpret_cast<float2 *>(sm + lay.U), *GY = Us;
+    float4 *Wt = reinterpret_cast<float4 *>(sm + lay.W);       // [p][k] = (wr[o0], wi[o0], wr[o1], wi[o1])
+    float2 *Ht = reinterpret_cast<float2 *>(sm + lay.H);       // [chi][nu][j] = (re, im), j = 0..M (j = M: zero pad)
+    float *PSv = reinterpret_cast<float *>(sm + lay.PSv);      // [nu][B+1] exclusive prefix sums of v_I + v_Q
+    float *PSh = reinterpret_cast<float *>(sm + lay.PSh);      // [nu][M+1] exclusive prefix sums of sum_chi gC |h|^2
+    float *VS = reinterpret_cast<float *>(sm + lay.VS);        // [nu][M]
+
+    // ---- per-run constants (uniform)
+    float amp[NLEV], b2[NLEV], nlogP[NLEV];
+    const float nusc = a.nu_sc[run];
+#pragma unroll
+    for (int i = 0; i < NLEV; i++) {
+        amp[i] = a.amp[i];
+        b2[i] = nusc * amp[i] * amp[i] * LOG2E;
+        nlogP[i] = -logf(a.P[(size_t)run * NLEV + i]);
+    }
+    const float var0 = a.var[run * 2 + 0], var1 = a.var[run * 2 + 1];
+    const double lrW = (double)a.lr_W[run], lrH = (double)a.lr_h[run];
+
+    // ---- zero the halo'd buffers once; load taps; owner lanes load their Adam moments
+    for (int i = lane; i < (lay.W - lay.X) / 8; i += 64) Xs[i] = make_float2(0.f, 0.f);     // X, E, U, PSv
+    for (int i = lane; i < (lay.PSh - lay.H) / 8; i += 64) Ht[i] = make_float2(0.f, 0.f);   // incl. the pad taps
+    __syncthreads();
+    const int tk = lane & 31, half = lane >> 5;                // tap index / which half this lane owns (o resp. chi)
+    const bool owner = tk < M;
+    const size_t gbase = (size_t)run * 8 * M;
+    float mWr[2] = {0, 0}, mWi[2] = {0, 0}, vWr[2] = {0, 0}, vWi[2] = {0, 0};   // [p]  moments of W[o=half][p][k=tk]
+    float mHr[2] = {0, 0}, mHi[2] = {0, 0}, vHr[2] = {0, 0}, vHi[2] = {0, 0};   // [nu] moments of h[chi=half][nu][.][j=tk]
+    if (owner) {
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const size_t ir = gbase + (half * 4 + p) * M + tk, ii = gbase + (half * 4 + 2 + p) * M + tk;
+            float *wq = reinterpret_cast<float *>(&Wt[p * M + tk]);
+            wq[half * 2 + 0] = a.W[ir];
+            wq[half * 2 + 1] = a.W[ii];
+            mWr[p] = a.adam_mW[ir]; mWi[p] = a.adam_mW[ii];
+            vWr[p] = a.adam_vW[ir]; vWi[p] = a.adam_vW[ii];
+            const size_t hr = gbase + ((half * 2 + p) * 2 + 0) * M + tk, hi = hr + M;
+            Ht[(half * 2 + p) * MP + tk] = make_float2(a.h[hr], a.h[hi]);
+            mHr[p] = a.adam_mh[hr]; mHi[p] = a.adam_mh[hi];
+            vHr[p] = a.adam_vh[hr]; vHi[p] = a.adam_vh[hi];
+        }
+    }
+    int step = a.step[run];
+    double b1t = pow(0.9, (double)step), b2t = pow(0.999, (double)step);
+    __syncthreads();
+
+    const int klen = a.keep_len, k0 = a.keep_off;
+    const size_t No = (size_t)a.steps * klen;
+    constexpr bool pairst = PAIR;                              // keep_off, keep_len even: both symbols of a lane kept together -> 8-byte stores
+    const bool act = lane < P2;                                // lane owns symbols 2*lane, 2*lane+1
+    const int nq = (nm + 3) / 4;                               // residual quads t = 4l' .. 4l'+3
+    const int n0 = 2 * lane;
+    const float2 *Xl = Xs + lane, *El = Es + lane, *Ul = Us + lane;
+
+    for (int f = 0; f < a.n_frames; f++) {
+        const float *rxf = a.rx + ((size_t)run * a.n_frames + f) * 4 * (size_t)a.S;
+        float *qf = a.q_out ? a.q_out + ((size_t)run * a.n_frames + f) * (4 * NLEV) * No : nullptr;
+        float *yf = a.y_out ? a.y_out + ((size_t)run * a.n_frames + f) * 4 * No : nullptr;
+#pragma unroll 1
+        for (int s = 0; s < a.steps; s++) {
+            // ============ P0: window -> LDS (16-byte loads, polyphase scatter); halo stays zero
+            {
+                const size_t s0 = (size_t)s * a.stride_sym * 2;
+                for (int v = lane; v < L / 4; v += 64) {
+#pragma unroll
+                    for (int p = 0; p < 2; p++) {
+                        const float4 I4 = *reinterpret_cast<const float4 *>(rxf + (size_t)(p * 2 + 0) * a.S + s0 + 4 * v);
+                        const float4 Q4 = *reinterpret_cast<const float4 *>(rxf + (size_t)(p * 2 + 1) * a.S + s0 + 4 * v);
+                        const float xi[4] = {I4.x, I4.y, I4.z, I4.w}, xq[4] = {Q4.x, Q4.y, Q4.z, Q4.w};
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int c = mh + i;              // + 4v: phase (c & 3) is lane independent
+                            Xs[(p * 4 + (c & 3)) * Lph + v + (c >> 2)] = make_float2(xi[i], xq[i]);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ============ P1: FIR for the lane's symbol pair, both output polarisations
+            float2 y[2][2];                                    // [sym][o]
+            y[0][0] = y[0][1] = y[1][0] = y[1][1] = make_float2(0.f, 0.f);
+            if (act) {
+                pair_fir<M, false>(y, Xl, Lph, Wt, nullptr, nullptr);
+                pair_fir<M, false>(y, Xl + 4 * Lph, Lph, Wt + M, nullptr, nullptr);
+            }
+            // pin: hipcc otherwise sinks whole FMA chains to their (much later) use and keeps their inputs alive instead
+            asm volatile("" : "+v"(y[0][0].x), "+v"(y[0][0].y), "+v"(y[0][1].x), "+v"(y[0][1].y), "+v"(y[1][0].x), "+v"(y[1][0].y),
+                         "+v"(y[1][1].x), "+v"(y[1][1].y));
+            const bool kept0 = act && (n0 >= k0) && (n0 < k0 + klen), kept1 = act && (n0 + 1 >= k0) && (n0 + 1 < k0 + klen);
+            const size_t col = (size_t)s * klen + (n0 - k0);
+            if (yf) {
+#pragma unroll
+                for (int o = 0; o < 2; o++) {
+                    float *rI = yf + (size_t)(o * 2 + 0) * No + col, *rQ = yf + (size_t)(o * 2 + 1) * No + col;
+                    if (pairst) {
+                        if (kept0) {
+                            *reinterpret_cast<float2 *>(rI) = make_float2(y[0][o].x, y[1][o].x);
+                            *reinterpret_cast<float2 *>(rQ) = make_float2(y[0][o].y, y[1][o].y);
+                        }
+                    } else {
+                        if (kept0) { rI[0] = y[0][o].x; rQ[0] = y[0][o].y; }
+                        if (kept1) { rI[1] = y[1][o].x; rQ[1] = y[1][o].y; }
+                    }
+                }
+            }
+
+            // ============ P2: soft demap + moments (registers), mu -> LDS, prefix sums of the variances
+            float mv[2][2][2], mt3[2][2][2], mkc[2][2][2];     // [sym][o][c]: Var_q, 3rd central moment, KL-gradient moment
+            float klsum = 0.f, vv[2][2];                       // vv[o][sym] = v_I + v_Q
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                const float c2 = 0.5f / (o ? var1 : var0) * LOG2E;
+                float2 muv[2];                                 // per sym: (mu_I, mu_Q)
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    float q[2][NLEV];
+#pragma unroll
+                    for (int sy = 0; sy < 2; sy++) {
+                        const float yy = c ? y[sy][o].y : y[sy][o].x;
+                        const bool inr = (n0 + sy >= mh) && (n0 + sy < B - mh) && act;     // KL slice, symbol index (:132)
+                        float z[NLEV], zmax = -3.0e38f;
+#pragma unroll
+                        for (int i = 0; i < NLEV; i++) {
+                            const float d = yy - amp[i];
+                            z[i] = -fmaf(d * d, c2, b2[i]);
+                            zmax = fmaxf(zmax, z[i]);
+                        }
+                        float ssum = 0.f;
+#pragma unroll
+                        for (int i = 0; i < NLEV; i++) {
+                            z[i] -= zmax;
+                            q[sy][i] = __builtin_amdgcn_exp2f(z[i]);
+                            ssum += q[sy][i];
+                        }
+                        const float rs = __builtin_amdgcn_rcpf(ssum);
+                        float m1 = 0.f;
+#pragma unroll
+                        for (int i = 0; i < NLEV; i++) {
+                            q[sy][i] *= rs;
+                            m1 = fmaf(amp[i], q[sy][i], m1);
+                        }
+                        // log(q_i/P_i) = z_i ln2 - log(ssum) - log P_i: the softmax's own logits; the +1e-12 inside the reference's
+                        // log and the q/(q+eps P) factor of its derivative change q*log(.) by < 1e-12, and the terms
+                        // common to all levels cancel in the centred sum
+                        float m2 = 0.f, m3 = 0.f, kk = 0.f, kl = 0.f;
+#pragma unroll
+                        for (int i = 0; i < NLEV; i++) {
+                            const float d = amp[i] - m1, qd = q[sy][i] * d, g = fmaf(z[i], LN2, nlogP[i]);
+                            m2 = fmaf(qd, d, m2);
+                            m3 = fmaf(qd * d, d, m3);
+                            kk = fmaf(qd, g, kk);
+                            kl = fmaf(q[sy][i], g, kl);
+                        }
+                        if (inr) klsum += kl - __builtin_amdgcn_logf(ssum) * LN2;
+                        asm volatile("" : "+v"(m2), "+v"(m3), "+v"(kk), "+v"(klsum));   // pin (see P1)
+                        mv[sy][o][c] = m2;
+                        mt3[sy][o][c] = m3;
+                        mkc[sy][o][c] = inr ? kk : 0.f;
+                        if (c) muv[sy].y = m1; else muv[sy].x = m1;
+                    }
+                    if (qf) {
+#pragma unroll
+                        for (int i = 0; i < NLEV; i++) {
+                            float *r = qf + (size_t)(o * 2 * NLEV + c * NLEV + i) * No + col;
+                            if (pairst) {
+                                if (kept0) *reinterpret_cast<float2 *>(r) = make_float2(q[0][i], q[1][i]);
+                            } else {
+                                if (kept0) r[0] = q[0][i];
+                                if (kept1) r[1] = q[1][i];
+                            }
+                        }
+                    }
+                }
+                vv[o][0] = act ? mv[0][o][0] + mv[0][o][1] : 0.f;
+                vv[o][1] = act ? mv[1][o][0] + mv[1][o][1] : 0.f;
+                if (act) {                                     // U[nu=o][n]: even symbols in phase 0, odd in phase 1
+                    Us[(o * 2 + 0) * Uph + lane] = muv[0];
+                    Us[(o * 2 + 1) * Uph + lane] = muv[1];
+                }
+            }
+            // exclusive prefix sums PSv[nu][n], n = 0..B  (VS[nu][j] = PSv[hi+1] - PSv[lo])
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                const float inc = wave_incl_scan(vv[o][0] + vv[o][1], lane);
+                if (act) {
+                    PSv[o * (B + 1) + n0 + 1] = inc - vv[o][1];
+                    PSv[o * (B + 1) + n0 + 2] = inc;
+                }
+                if (lane == 0) PSv[o * (B + 1)] = 0.f;
+            }
+            __syncthreads();
+            if (owner) {                                       // VS[nu][j]: lane = (j = tk, nu = half)
+                const int lo = (Mh - tk + 1) >> 1, hi_ = (nm - 1 + Mh - tk) >> 1;
+                VS[half * M + tk] = PSv[half * (B + 1) + hi_ + 1] - PSv[half * (B + 1) + lo];
+            }
+            __syncthreads();
+
+            // ============ P3: residual e = x - D for the quad t = 4l'..4l'+3, both chi.
+            //   D[chi, 2 tau + par] = sum_nu sum_a h[chi,nu,2a+par] U[nu, tau + mh - a],   tau in {2l', 2l'+1}, a = 0..mh
+            float se0 = 0.f, se1 = 0.f;
+            if (lane < nq) {
+                float2 D[2][4];                                // [chi][i], i = 2*dl + par
+#pragma unroll
+                for (int chi = 0; chi < 2; chi++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) D[chi][i] = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int v = 0; v < 2; v++) {
+                    const float2 *h0 = Ht + (0 * 2 + v) * MP, *h1 = Ht + (1 * 2 + v) * MP;
+                    const float2 *up = Ul + v * 2 * Uph;       // U[nu][2l' + d] = up[(d & 1) * Uph + (d >> 1)]
+                    auto step_a = [&](int aa, float2 ulo, float2 uhi) {   // ulo = U[2l' + mh - a], uhi = U[2l' + mh - a + 1]
+                        const float2 e0 = h0[2 * aa], o0 = h0[2 * aa + 1], e1 = h1[2 * aa], o1 = h1[2 * aa + 1];
+                        cmac(D[0][0], e0.x, e0.y, ulo); cmac(D[0][1], o0.x, o0.y, ulo);
+                        cmac(D[0][2], e0.x, e0.y, uhi); cmac(D[0][3], o0.x, o0.y, uhi);
+                        cmac(D[1][0], e1.x, e1.y, ulo); cmac(D[1][1], o1.x, o1.y, ulo);
+                        cmac(D[1][2], e1.x, e1.y, uhi); cmac(D[1][3], o1.x, o1.y, uhi);
+                    };
+                    constexpr int NA = mh + 1, NB = NA / 2;    // a = 0..mh; pairs (2b, 2b+1)
+#pragma unroll 1
+                    for (int b = 0; b < NB; b++) {             // d = mh - 2b: samples d+1, d, d-1
+                        constexpr int ph = mh & 1;             // phase of d (d and mh have equal parity)
+                        const int sl = (mh >> 1) - b;          // slot of d   (d >> 1)
+                        const float2 ud = up[ph * Uph + sl];
+                        const float2 udp = up[(ph ^ 1) * Uph + sl + ph];            // d + 1
+                        const float2 udm = up[(ph ^ 1) * Uph + sl + ph - 1];        // d - 1
+                        step_a(2 * b, ud, udp);
+                        step_a(2 * b + 1, udm, ud);
+                    }
+                    if (NA & 1) {                              // a = mh: d = 0 -> U[2l'], U[2l'+1]
+                        step_a(mh, up[0], up[Uph]);
+                    }
+                }
+#pragma unroll
+                for (int chi = 0; chi < 2; chi++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int ce = Mh + i;                 // + 4*lane: same (phase, slot) arithmetic as x
+                        const float2 x = Xl[(chi * 4 + (ce & 3)) * Lph + (ce >> 2)];
+                        float2 e = make_float2(x.x - D[chi][i].x, x.y - D[chi][i].y);
+                        if (4 * lane + i >= nm) e = make_float2(0.f, 0.f);
+                        Es[(chi * 4 + (ce & 3)) * Lph + lane + (ce >> 2)] = e;
+                        const float e2 = e.x * e.x + e.y * e.y;
+                        if (chi) se1 += e2; else se0 += e2;
+                    }
+            }
+            se0 = wave_sum(se0);
+            se1 = wave_sum(se1);
+            klsum = wave_sum(klsum);
+            // C[chi] = sum|e|^2 + sum_{nu,j} |h|^2 VS   (lanes (j, nu) hold one term each for both chi)
+            float hq0 = 0.f, hq1 = 0.f;
+            if (owner) {
+                const float2 h0 = Ht[(0 * 2 + half) * MP + tk], h1 = Ht[(1 * 2 + half) * MP + tk];
+                hq0 = h0.x * h0.x + h0.y * h0.y;
+                hq1 = h1.x * h1.x + h1.y * h1.y;
+            }
+            const float vsl = owner ? VS[half * M + tk] : 0.f;
+            const float C0 = se0 + wave_sum(hq0 * vsl), C1 = se1 + wave_sum(hq1 * vsl);
+            const float gC0 = (float)nm / C0, gC1 = (float)nm / C1;
+            if (lane == 0) {
+                const size_t li = ((size_t)run * a.n_frames + f) * a.steps + s;
+                if (a.loss) a.loss[li] = (float)nm * (logf(C0) + logf(C1)) + klsum;
+                if (a.var_est) {
+                    const size_t vi = ((size_t)run * a.n_frames + f) * 2 * a.steps + s;
+                    a.var_est[vi] = C0 / (float)nm;
+                    a.var_est[vi + a.steps] = C1 / (float)nm;
+                }
+            }
+            // prefix sums over j of H2[nu][j] = sum_chi gC[chi] |h[chi,nu,j]|^2  -> G_V by two lookups per symbol
+            {
+                float inc = gC0 * hq0 + gC1 * hq1;             // inclusive scan within each 32-lane half
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) {
+                    const float t = __shfl_up(inc, d, 32);
+                    if (tk >= d) inc += t;
+                }
+                if (owner) PSh[half * MP + tk + 1] = inc;
+                if (tk == 0) PSh[half * MP] = 0.f;
+            }
+            __syncthreads();
+
+            // ============ P4a: dL/dh partial sums, lane = (j = tk, half of the tau range); acc[chi][nu]
+            step += 1;
+            b1t *= 0.9;
+            b2t *= 0.999;
+            const double bc1 = 1.0 - b1t, bc2 = 1.0 - b2t;
+            const float bc2s = (float)sqrt(bc2), ssW = (float)(lrW / bc1), ssH = (float)(lrH / bc1);
+            float2 hnew[2];
+            hnew[0] = hnew[1] = make_float2(0.f, 0.f);
+            float ghr[2] = {0, 0}, ghi[2] = {0, 0};
+            {
+                float2 acc[2][2];
+                acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = make_float2(0.f, 0.f);
+                if (owner) {
+                    const int par = tk & 1, aa = tk >> 1;
+                    const int T = (nm - par + 1) >> 1, Th = (T + 1) >> 1;
+                    const int ta = half * Th, tb = min(T, ta + Th);
+#pragma unroll 2
+                    for (int tau = ta; tau < tb; tau++) {
+                        const int ce = 2 * tau + par + Mh, np = tau + mh - aa;
+                        const int ei = (ce & 3) * Lph + (ce >> 2), ui = (np & 1) * Uph + (np >> 1);
+                        const float2 e0 = Es[ei], e1 = Es[4 * Lph + ei];
+                        const float2 u0 = Us[ui], u1 = Us[2 * Uph + ui];
+                        cmacc(acc[0][0], e0, u0.x, u0.y);
+                        cmacc(acc[0][1], e0, u1.x, u1.y);
+                        cmacc(acc[1][0], e1, u0.x, u0.y);
+                        cmacc(acc[1][1], e1, u1.x, u1.y);
+                    }
+                }
+                // combine the two halves; lane (j, half) keeps chi = half
+#pragma unroll
+                for (int chi = 0; chi < 2; chi++)
+#pragma unroll
+                    for (int v = 0; v < 2; v++) {
+                        acc[chi][v].x += __shfl_xor(acc[chi][v].x, 32, 64);
+                        acc[chi][v].y += __shfl_xor(acc[chi][v].y, 32, 64);
+                    }
+                if (owner) {
+                    const float g = half ? gC1 : gC0;
+#pragma unroll
+                    for (int v = 0; v < 2; v++) {
+                        const float2 ac = half ? acc[1][v] : acc[0][v];
+                        const float2 hh = Ht[(half * 2 + v) * MP + tk];
+                        const float vs = VS[v * M + tk];
+                        ghr[v] = g * (-2.0f * ac.x + 2.0f * hh.x * vs);
+                        ghi[v] = g * (-2.0f * ac.y + 2.0f * hh.y * vs);
+                        hnew[v] = hh;
+                        if (!a.no_update) {
+                            adam_update(hnew[v].x, mHr[v], vHr[v], ghr[v], ssH, bc2s);
+                            adam_update(hnew[v].y, mHi[v], vHi[v], ghi[v], ssH, bc2s);
+                        }
+                    }
+                }
+            }
+
+            asm volatile("" : "+v"(hnew[0].x), "+v"(hnew[0].y), "+v"(hnew[1].x), "+v"(hnew[1].y), "+v"(ghr[0]), "+v"(ghr[1]), "+v"(ghi[0]),
+                         "+v"(ghi[1]));                        // pin (see P1)
+            // ============ P4b: dL/dU for the lane's symbol pair (same shape as the FIR, on e with conj(h)), then dL/dy
+            float2 gy[2][2];                                   // [sym][nu]
+            {
+                float2 au0[2][2], au1[2][2];                   // chi = 0 / 1: [sym][nu]
+                au0[0][0] = au0[0][1] = au0[1][0] = au0[1][1] = make_float2(0.f, 0.f);
+                au1[0][0] = au1[0][1] = au1[1][0] = au1[1][1] = make_float2(0.f, 0.f);
+                if (act) {
+                    pair_fir<M, true>(au0, El, Lph, nullptr, Ht + 0 * MP, Ht + 1 * MP);
+                    pair_fir<M, true>(au1, El + 4 * Lph, Lph, nullptr, Ht + 2 * MP, Ht + 3 * MP);
+                }
+#pragma unroll
+                for (int sy = 0; sy < 2; sy++) {
+                    const int sx = 2 * (n0 + sy);
+                    const int jlo = max(0, Mh - sx), jhi = max(jlo - 1, min(Mh, nm - 1 + Mh - sx));
+#pragma unroll
+                    for (int v = 0; v < 2; v++) {
+                        const float ur = -2.0f * (gC0 * au0[sy][v].x + gC1 * au1[sy][v].x);
+                        const float ui = -2.0f * (gC0 * au0[sy][v].y + gC1 * au1[sy][v].y);
+                        const float gv = PSh[v * MP + jhi + 1] - PSh[v * MP + jlo];
+                        const float iv = 1.0f / (v ? var1 : var0);
+                        gy[sy][v].x = iv * (ur * mv[sy][v][0] + gv * mt3[sy][v][0] + mkc[sy][v][0]);
+                        gy[sy][v].y = iv * (ui * mv[sy][v][1] + gv * mt3[sy][v][1] + mkc[sy][v][1]);
+                    }
+                }
+            }
+            __syncthreads();                                   // every read of U / old h is done (GY aliases U)
+            if (act) {
+#pragma unroll
+                for (int v = 0; v < 2; v++) {
+                    GY[v * B + n0] = gy[0][v];
+                    GY[v * B + n0 + 1] = gy[1][v];
+                }
+            }
+            if (owner && !a.no_update) {
+                Ht[(half * 2 + 0) * MP + tk] = hnew[0];
+                Ht[(half * 2 + 1) * MP + tk] = hnew[1];
+            }
+            __syncthreads();
+
+            // ============ P5: dL/dw partial sums, lane = (k = tk, half of the symbol range); acc[o][p]
+            float gwr[2] = {0, 0}, gwi[2] = {0, 0};
+            {
+                float2 acc[2][2];
+                acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = make_float2(0.f, 0.f);
+                if (owner) {
+                    const int Bh = (B + 1) >> 1, na = half * Bh, nb = min(B, na + Bh);
+#pragma unroll 2
+                    for (int n = na; n < nb; n++) {
+                        const int c = 2 * n + tk;
+                        const int xi = (c & 3) * Lph + (c >> 2);
+                        const float2 g0 = GY[n], g1 = GY[B + n];
+                        const float2 x0 = Xs[xi], x1 = Xs[4 * Lph + xi];
+                        cmacc(acc[0][0], g0, x0.x, x0.y);
+                        cmacc(acc[0][1], g0, x1.x, x1.y);
+                        cmacc(acc[1][0], g1, x0.x, x0.y);
+                        cmacc(acc[1][1], g1, x1.x, x1.y);
+                    }
+                }
+#pragma unroll
+                for (int o = 0; o < 2; o++)
+#pragma unroll
+                    for (int p = 0; p < 2; p++) {
+                        acc[o][p].x += __shfl_xor(acc[o][p].x, 32, 64);
+                        acc[o][p].y += __shfl_xor(acc[o][p].y, 32, 64);
+                    }
+                if (owner) {
+#pragma unroll
+                    for (int p = 0; p < 2; p++) {
+                        const float2 ac = half ? acc[1][p] : acc[0][p];
+                        gwr[p] = ac.x;
+                        gwi[p] = ac.y;
+                        if (!a.no_update) {
+                            float *wq = reinterpret_cast<float *>(&Wt[p * M + tk]) + half * 2;
+                            float wr = wq[0], wi = wq[1];
+                            adam_update(wr, mWr[p], vWr[p], gwr[p], ssW, bc2s);
+                            adam_update(wi, mWi[p], vWi[p], gwi[p], ssW, bc2s);
+                            wq[0] = wr;
+                            wq[1] = wi;
+                        }
+                    }
+                }
+            }
+            if (a.dbg_gW && owner && f == a.n_frames - 1 && s == a.steps - 1) {
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    a.dbg_gW[gbase + (half * 4 + p) * M + tk] = gwr[p];
+                    a.dbg_gW[gbase + (half * 4 + 2 + p) * M + tk] = gwi[p];
+                    a.dbg_gh[gbase + ((half * 2 + p) * 2 + 0) * M + tk] = ghr[p];
+                    a.dbg_gh[gbase + ((half * 2 + p) * 2 + 1) * M + tk] = ghi[p];
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- state out
+    if (owner && !a.no_update) {
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const size_t ir = gbase + (half * 4 + p) * M + tk, ii = gbase + (half * 4 + 2 + p) * M + tk;
+            const float *wq = reinterpret_cast<const float *>(&Wt[p * M + tk]) + half * 2;
+            a.W[ir] = wq[0]; a.W[ii] = wq[1];
+            a.adam_mW[ir] = mWr[p]; a.adam_mW[ii] = mWi[p];
+            a.adam_vW[ir] = vWr[p]; a.adam_vW[ii] = vWi[p];
+            const size_t hr = gbase + ((half * 2 + p) * 2 + 0) * M + tk, hi = hr + M;
+            const float2 hh = Ht[(half * 2 + p) * MP + tk];
+            a.h[hr] = hh.x; a.h[hi] = hh.y;
+            a.adam_mh[hr] = mHr[p]; a.adam_mh[hi] = mHi[p];
+            a.adam_vh[hr] = vHr[p]; a.adam_vh[hi] = vHi[p];
+        }
+    }
+    if (lane == 0 && !a.no_update) a.step[run] = step;
+}
+
+template <int M, int NLEV, int BT>
+static int launch_wave(const vaeq_dp_args &a, hipStream_t st)
+{
+    const size_t lds = (size_t)wave_layout(a.B, M).total;
+    auto k = (((a.keep_len | a.keep_off) & 1) == 0) ? dp_wave_kernel<M, NLEV, BT, true> : dp_wave_kernel<M, NLEV, BT, false>;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return VAEQ_ERR_LDS;
+    hipLaunchKernelGGL(k, dim3(a.R), dim3(64), lds, st, a);
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}
+
+template <int M, int BT>
+static int launch_wave_lev(const vaeq_dp_args &a, hipStream_t st)
+{
+    switch (a.n_lev) {
+    case 2: return launch_wave<M, 2, BT>(a, st);
+    case 4: return launch_wave<M, 4, BT>(a, st);
+    case 8: return launch_wave<M, 8, BT>(a, st);
+    }
+    return VAEQ_ERR_SHAPE;
+}
+
+// Whether the wave-per-run kernel covers this call (else the generic kernel runs).
+bool dp_wave_supported(const vaeq_dp_args &a)
+{
+    if (a.sps != 2 || (a.B & 1) || a.B > 128 || a.B < 2 * (a.M / 2) + 2) return false;
+    if (!(a.M == 25 || a.M == 13 || a.M == 9)) return false;
+    if ((a.S & 3) || ((a.stride_sym * 2) & 3) || (reinterpret_cast<uintptr_t>(a.rx) & 15)) return false;   // 16-byte window loads
+    if (a.q_out && (reinterpret_cast<uintptr_t>(a.q_out) & 7)) return false;
+    if (a.y_out && (reinterpret_cast<uintptr_t>(a.y_out) & 7)) return false;
+    if ((a.dbg_gW == nullptr) != (a.dbg_gh == nullptr)) return false;
+    return true;
+}
+
+int launch_dp_wave(const vaeq_dp_args &a, hipStream_t st)
+{
+    switch (a.M) {
+    case 25: return a.B == 100 ? launch_wave_lev<25, 100>(a, st) : launch_wave_lev<25, 0>(a, st);
+    case 13: return launch_wave_lev<13, 0>(a, st);
+    case 9: return launch_wave_lev<9, 0>(a, st);
+    }
+    return VAEQ_ERR_SHAPE;
+}
+
+}  // namespace vaeq
