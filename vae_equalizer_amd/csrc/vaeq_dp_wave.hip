@@ -56,6 +56,8 @@ __host__ __device__ inline WaveLayout wave_layout(int B, int M)
     return l;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));   // element-wise ops compile to v_pk_{add,mul,fma}_f32
+
 __device__ __forceinline__ void cmac(float2 &acc, float wr, float wi, float2 x)       // acc += (wr + j wi) * x
 {
     acc.x = fmaf(wr, x.x, acc.x);
@@ -123,7 +125,7 @@ __device__ __forceinline__ void pair_fir(float2 (&acc)[2][2], const float2 *xp, 
 }
 
 template <int M, int NLEV, int BT, bool PAIR>
-__global__ __launch_bounds__(64, 3) void dp_wave_kernel(const vaeq_dp_args a)
+__global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
 {
     constexpr int mh = M / 2, Mh = 2 * mh, MP = M + 1;
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(64, 3) void dp_wave_kernel(const vaeq_dp_args a)
         nlogP[i] = -logf(a.P[(size_t)run * NLEV + i]);
     }
     const float var0 = a.var[run * 2 + 0], var1 = a.var[run * 2 + 1];
-    const double lrW = (double)a.lr_W[run], lrH = (double)a.lr_h[run];
+    const float lrW = a.lr_W[run], lrH = a.lr_h[run];
 
     // ---- zero the halo'd buffers once; load taps; owner lanes load their Adam moments
     for (int i = lane; i < (lay.W - lay.X) / 8; i += 64) Xs[i] = make_float2(0.f, 0.f);     // X, E, U, PSv
@@ -252,60 +254,63 @@ __global__ __launch_bounds__(64, 3) void dp_wave_kernel(const vaeq_dp_args a)
                 float2 muv[2];                                 // per sym: (mu_I, mu_Q)
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
-                    float q[2][NLEV];
+                    // both symbols of the lane at once: every add/mul/fma below is one packed instruction (v_pk_*_f32)
+                    const v2f yy = c ? v2f{y[0][o].y, y[1][o].y} : v2f{y[0][o].x, y[1][o].x};
+                    v2f z[NLEV], q[NLEV];
+                    float zm0 = -3.0e38f, zm1 = -3.0e38f;
 #pragma unroll
-                    for (int sy = 0; sy < 2; sy++) {
-                        const float yy = c ? y[sy][o].y : y[sy][o].x;
-                        const bool inr = (n0 + sy >= mh) && (n0 + sy < B - mh) && act;     // KL slice, symbol index (:132)
-                        float z[NLEV], zmax = -3.0e38f;
-#pragma unroll
-                        for (int i = 0; i < NLEV; i++) {
-                            const float d = yy - amp[i];
-                            z[i] = -fmaf(d * d, c2, b2[i]);
-                            zmax = fmaxf(zmax, z[i]);
-                        }
-                        float ssum = 0.f;
-#pragma unroll
-                        for (int i = 0; i < NLEV; i++) {
-                            z[i] -= zmax;
-                            q[sy][i] = __builtin_amdgcn_exp2f(z[i]);
-                            ssum += q[sy][i];
-                        }
-                        const float rs = __builtin_amdgcn_rcpf(ssum);
-                        float m1 = 0.f;
-#pragma unroll
-                        for (int i = 0; i < NLEV; i++) {
-                            q[sy][i] *= rs;
-                            m1 = fmaf(amp[i], q[sy][i], m1);
-                        }
-                        // log(q_i/P_i) = z_i ln2 - log(ssum) - log P_i: the softmax's own logits; the +1e-12 inside the reference's
-                        // log and the q/(q+eps P) factor of its derivative change q*log(.) by < 1e-12, and the terms
-                        // common to all levels cancel in the centred sum
-                        float m2 = 0.f, m3 = 0.f, kk = 0.f, kl = 0.f;
-#pragma unroll
-                        for (int i = 0; i < NLEV; i++) {
-                            const float d = amp[i] - m1, qd = q[sy][i] * d, g = fmaf(z[i], LN2, nlogP[i]);
-                            m2 = fmaf(qd, d, m2);
-                            m3 = fmaf(qd * d, d, m3);
-                            kk = fmaf(qd, g, kk);
-                            kl = fmaf(q[sy][i], g, kl);
-                        }
-                        if (inr) klsum += kl - __builtin_amdgcn_logf(ssum) * LN2;
-                        asm volatile("" : "+v"(m2), "+v"(m3), "+v"(kk), "+v"(klsum));   // pin (see P1)
-                        mv[sy][o][c] = m2;
-                        mt3[sy][o][c] = m3;
-                        mkc[sy][o][c] = inr ? kk : 0.f;
-                        if (c) muv[sy].y = m1; else muv[sy].x = m1;
+                    for (int i = 0; i < NLEV; i++) {
+                        const v2f d = yy - amp[i];
+                        z[i] = -(d * d * c2 + b2[i]);
+                        zm0 = fmaxf(zm0, z[i].x);
+                        zm1 = fmaxf(zm1, z[i].y);
                     }
+                    const v2f zmax = {zm0, zm1};
+                    v2f ssum = {0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < NLEV; i++) {
+                        z[i] -= zmax;
+                        q[i] = v2f{__builtin_amdgcn_exp2f(z[i].x), __builtin_amdgcn_exp2f(z[i].y)};
+                        ssum += q[i];
+                    }
+                    const v2f rs = {__builtin_amdgcn_rcpf(ssum.x), __builtin_amdgcn_rcpf(ssum.y)};
+                    v2f m1 = {0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < NLEV; i++) {
+                        q[i] *= rs;
+                        m1 += q[i] * amp[i];
+                    }
+                    // log(q_i/P_i) = z_i ln2 - log(ssum) - log P_i: the softmax's own logits; the +1e-12 inside the reference's
+                    // log and the q/(q+eps P) factor of its derivative change q*log(.) by < 1e-12, and the terms
+                    // common to all levels cancel in the centred sum
+                    v2f m2 = {0.f, 0.f}, m3 = {0.f, 0.f}, kk = {0.f, 0.f}, kl = {0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < NLEV; i++) {
+                        const v2f d = amp[i] - m1, qd = q[i] * d, g = z[i] * LN2 + nlogP[i];
+                        m2 += qd * d;
+                        m3 += qd * d * d;
+                        kk += qd * g;
+                        kl += q[i] * g;
+                    }
+                    const bool inr0 = (n0 >= mh) && (n0 < B - mh) && act;             // KL slice, symbol index (:132)
+                    const bool inr1 = (n0 + 1 >= mh) && (n0 + 1 < B - mh) && act;
+                    if (inr0) klsum += kl.x - __builtin_amdgcn_logf(ssum.x) * LN2;
+                    if (inr1) klsum += kl.y - __builtin_amdgcn_logf(ssum.y) * LN2;
+                    asm volatile("" : "+v"(m2), "+v"(m3), "+v"(kk), "+v"(klsum));   // pin (see P1)
+                    mv[0][o][c] = m2.x; mv[1][o][c] = m2.y;
+                    mt3[0][o][c] = m3.x; mt3[1][o][c] = m3.y;
+                    mkc[0][o][c] = inr0 ? kk.x : 0.f;
+                    mkc[1][o][c] = inr1 ? kk.y : 0.f;
+                    if (c) { muv[0].y = m1.x; muv[1].y = m1.y; } else { muv[0].x = m1.x; muv[1].x = m1.y; }
                     if (qf) {
 #pragma unroll
                         for (int i = 0; i < NLEV; i++) {
                             float *r = qf + (size_t)(o * 2 * NLEV + c * NLEV + i) * No + col;
                             if (pairst) {
-                                if (kept0) *reinterpret_cast<float2 *>(r) = make_float2(q[0][i], q[1][i]);
+                                if (kept0) *reinterpret_cast<v2f *>(r) = q[i];
                             } else {
-                                if (kept0) r[0] = q[0][i];
-                                if (kept1) r[1] = q[1][i];
+                                if (kept0) r[0] = q[i].x;
+                                if (kept1) r[1] = q[i].y;
                             }
                         }
                     }
@@ -421,8 +426,9 @@ __global__ __launch_bounds__(64, 3) void dp_wave_kernel(const vaeq_dp_args a)
             step += 1;
             b1t *= 0.9;
             b2t *= 0.999;
-            const double bc1 = 1.0 - b1t, bc2 = 1.0 - b2t;
-            const float bc2s = (float)sqrt(bc2), ssW = (float)(lrW / bc1), ssH = (float)(lrH / bc1);
+            const float rbc1 = __builtin_amdgcn_rcpf((float)(1.0 - b1t));                 // bias corrections: beta^t in double,
+            const float bc2s = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf((float)(1.0 - b2t)));   // the rest in float
+            const float ssW = lrW * rbc1, ssH = lrH * rbc1;
             float2 hnew[2];
             hnew[0] = hnew[1] = make_float2(0.f, 0.f);
             float ghr[2] = {0, 0}, ghi[2] = {0, 0};
@@ -430,19 +436,27 @@ __global__ __launch_bounds__(64, 3) void dp_wave_kernel(const vaeq_dp_args a)
                 float2 acc[2][2];
                 acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = make_float2(0.f, 0.f);
                 if (owner) {
+                    // sum over tau of e[chi, 2 tau + par] conj(U[nu, tau + mh - a]); tau runs in pairs (2m, 2m+1) so that the
+                    // polyphase component of every operand is a per-lane constant and only the slot advances (by one per m).
+                    // Past the last valid tau the residual cells are zero (pad), so the pair loop may overrun by one.
                     const int par = tk & 1, aa = tk >> 1;
-                    const int T = (nm - par + 1) >> 1, Th = (T + 1) >> 1;
-                    const int ta = half * Th, tb = min(T, ta + Th);
+                    const int T = (nm - par + 1) >> 1, Th = ((T + 3) >> 2) << 1;         // even split point
+                    const int ma = (half * Th) >> 1, mb = (min(T, half * Th + Th) + 1) >> 1;
+                    const int ceA = par + Mh, ceB = par + Mh + 2, npA = mh - aa, npB = mh - aa + 1;
+                    const float2 *eA = Es + (ceA & 3) * Lph + (ceA >> 2), *eB = Es + (ceB & 3) * Lph + (ceB >> 2);
+                    const float2 *uA = Us + (npA & 1) * Uph + (npA >> 1), *uB = Us + (npB & 1) * Uph + (npB >> 1);
 #pragma unroll 2
-                    for (int tau = ta; tau < tb; tau++) {
-                        const int ce = 2 * tau + par + Mh, np = tau + mh - aa;
-                        const int ei = (ce & 3) * Lph + (ce >> 2), ui = (np & 1) * Uph + (np >> 1);
-                        const float2 e0 = Es[ei], e1 = Es[4 * Lph + ei];
-                        const float2 u0 = Us[ui], u1 = Us[2 * Uph + ui];
+                    for (int m = ma; m < mb; m++) {
+                        const float2 e0 = eA[m], e1 = eA[4 * Lph + m], u0 = uA[m], u1 = uA[2 * Uph + m];
+                        const float2 f0 = eB[m], f1 = eB[4 * Lph + m], w0 = uB[m], w1 = uB[2 * Uph + m];
                         cmacc(acc[0][0], e0, u0.x, u0.y);
                         cmacc(acc[0][1], e0, u1.x, u1.y);
                         cmacc(acc[1][0], e1, u0.x, u0.y);
                         cmacc(acc[1][1], e1, u1.x, u1.y);
+                        cmacc(acc[0][0], f0, w0.x, w0.y);
+                        cmacc(acc[0][1], f0, w1.x, w1.y);
+                        cmacc(acc[1][0], f1, w0.x, w0.y);
+                        cmacc(acc[1][1], f1, w1.x, w1.y);
                     }
                 }
                 // combine the two halves; lane (j, half) keeps chi = half
@@ -464,8 +478,8 @@ __global__ __launch_bounds__(64, 3) void dp_wave_kernel(const vaeq_dp_args a)
                         ghi[v] = g * (-2.0f * ac.y + 2.0f * hh.y * vs);
                         hnew[v] = hh;
                         if (!a.no_update) {
-                            adam_update(hnew[v].x, mHr[v], vHr[v], ghr[v], ssH, bc2s);
-                            adam_update(hnew[v].y, mHi[v], vHi[v], ghi[v], ssH, bc2s);
+                            adam_update_fast(hnew[v].x, mHr[v], vHr[v], ghr[v], ssH, bc2s);
+                            adam_update_fast(hnew[v].y, mHi[v], vHi[v], ghi[v], ssH, bc2s);
                         }
                     }
                 }
@@ -518,17 +532,24 @@ __global__ __launch_bounds__(64, 3) void dp_wave_kernel(const vaeq_dp_args a)
                 float2 acc[2][2];
                 acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = make_float2(0.f, 0.f);
                 if (owner) {
-                    const int Bh = (B + 1) >> 1, na = half * Bh, nb = min(B, na + Bh);
+                    // sum over n of gy[o, n] conj(x[p, 2n + k]); n runs in pairs (2m, 2m+1): x phase fixed per lane, gy pair = 16 bytes
+                    const int Bq = ((B + 3) >> 2) << 1;                                  // even split point (B is even)
+                    const int ma = (half * Bq) >> 1, mb = min(B, half * Bq + Bq) >> 1;
+                    const int cA = tk, cB = tk + 2;
+                    const float2 *xA = Xs + (cA & 3) * Lph + (cA >> 2), *xB = Xs + (cB & 3) * Lph + (cB >> 2);
+                    const float4 *G0 = reinterpret_cast<const float4 *>(GY), *G1 = reinterpret_cast<const float4 *>(GY + B);
 #pragma unroll 2
-                    for (int n = na; n < nb; n++) {
-                        const int c = 2 * n + tk;
-                        const int xi = (c & 3) * Lph + (c >> 2);
-                        const float2 g0 = GY[n], g1 = GY[B + n];
-                        const float2 x0 = Xs[xi], x1 = Xs[4 * Lph + xi];
-                        cmacc(acc[0][0], g0, x0.x, x0.y);
-                        cmacc(acc[0][1], g0, x1.x, x1.y);
-                        cmacc(acc[1][0], g1, x0.x, x0.y);
-                        cmacc(acc[1][1], g1, x1.x, x1.y);
+                    for (int m = ma; m < mb; m++) {
+                        const float4 ga = G0[m], gb = G1[m];                             // (gy[o][2m], gy[o][2m+1])
+                        const float2 x0 = xA[m], x1 = xA[4 * Lph + m], z0 = xB[m], z1 = xB[4 * Lph + m];
+                        cmacc(acc[0][0], make_float2(ga.x, ga.y), x0.x, x0.y);
+                        cmacc(acc[0][1], make_float2(ga.x, ga.y), x1.x, x1.y);
+                        cmacc(acc[1][0], make_float2(gb.x, gb.y), x0.x, x0.y);
+                        cmacc(acc[1][1], make_float2(gb.x, gb.y), x1.x, x1.y);
+                        cmacc(acc[0][0], make_float2(ga.z, ga.w), z0.x, z0.y);
+                        cmacc(acc[0][1], make_float2(ga.z, ga.w), z1.x, z1.y);
+                        cmacc(acc[1][0], make_float2(gb.z, gb.w), z0.x, z0.y);
+                        cmacc(acc[1][1], make_float2(gb.z, gb.w), z1.x, z1.y);
                     }
                 }
 #pragma unroll
@@ -547,8 +568,8 @@ __global__ __launch_bounds__(64, 3) void dp_wave_kernel(const vaeq_dp_args a)
                         if (!a.no_update) {
                             float *wq = reinterpret_cast<float *>(&Wt[p * M + tk]) + half * 2;
                             float wr = wq[0], wi = wq[1];
-                            adam_update(wr, mWr[p], vWr[p], gwr[p], ssW, bc2s);
-                            adam_update(wi, mWi[p], vWi[p], gwi[p], ssW, bc2s);
+                            adam_update_fast(wr, mWr[p], vWr[p], gwr[p], ssW, bc2s);
+                            adam_update_fast(wi, mWi[p], vWi[p], gwi[p], ssW, bc2s);
                             wq[0] = wr;
                             wq[1] = wi;
                         }
