@@ -114,7 +114,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--runs", type=int, default=3840, help="independent runs per GPU (one workgroup each)")
+    ap.add_argument("--runs", type=int, default=0, help="independent runs per GPU (one workgroup each); 0 = 4 x the number of runs "
+                    "the device keeps co-resident (vaeq_dp_resident_runs), i.e. four full rounds, no ragged tail")
     ap.add_argument("--threads", type=int, default=0, help="workgroup size per run (0 = library default)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -130,8 +131,13 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    R, K, Wm = args.runs, args.steps, args.warmup
+    K, Wm = args.steps, args.warmup
     B, M, sps = CFG["batch_len"], CFG["M_est"], CFG["sps"]
+    from vae_equalizer_amd import _native as nat
+    resident = int(nat.lib().vaeq_dp_resident_runs(B, sps, M, 8, args.threads))
+    if resident <= 0:
+        raise SystemExit(f"vaeq_dp_resident_runs failed: {resident}")
+    R = args.runs if args.runs > 0 else 4 * resident
     steps_per_frame = CFG["N_frame_max"] // B
     n_distinct = max(1, min(args.distinct_frames, K + Wm))
     frames, t = make_frames(n_distinct, R, device, seed=1000 + rank)
@@ -179,7 +185,7 @@ def main():
         if os.path.exists(tj):
             try:
                 d = json.load(open(tj))
-                if d.get("runs") == R and d.get("threads", 0) == args.threads:
+                if d.get("runs") == R and d.get("threads", 0) == args.threads:  # same launch geometry as this run
                     traffic = d.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -191,10 +197,11 @@ def main():
             "config": {"workload": "SURVEY config 3: optical DP 64-QAM VAE-LE, nu=0, SNR 23 dB, h0, 90 GBd, M_est=25, batch_len=100, "
                                    "N_frame_max=10000 (100 minibatch steps per bench step), lr in {2.5e-3,2e-3,3e-3}; seed axis raised to "
                                    f"{R} independent runs per GPU (script default iter=5 -> 15 runs)",
-                       "runs_per_gpu": R, "dp_symbols_per_step_per_gpu": sym_per_launch, "threads_per_run": args.threads or 256,
+                       "runs_per_gpu": R, "resident_runs_per_gpu": resident, "dp_symbols_per_step_per_gpu": sym_per_launch,
+                       "kernel_choice": args.threads,
                        "distinct_frames": n_distinct, "parallelism": f"sweep-sharded x{world}, one all_gather of result rows"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "vaeq::dp_train_kernel", "kernel_ms": kern_ms,
+                         "traffic": traffic, "kernel": "vaeq::dp_wave_kernel<25,8,100,true>" if args.threads in (0, 1) else "vaeq::dp_train_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_DP_SYMBOL * sym_per_launch},
         }
         if not args.no_cpu_baseline:

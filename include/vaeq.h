@@ -96,6 +96,11 @@ int vaeq_dp_train(const vaeq_dp_args *args, void *stream);
 /* LDS bytes one run (= one workgroup) needs for the given shape, or a negative error code. */
 int64_t vaeq_dp_lds_bytes(int32_t B, int32_t sps, int32_t M, int32_t n_lev);
 
+/* How many runs of this shape the current device keeps co-resident (occupancy x compute units) with the kernel that
+ * `threads` selects (same meaning as vaeq_dp_args.threads; VAE-LE geometry assumed).  Sweeps sized to a multiple of it
+ * have no partially filled last round.  Negative error code on failure. */
+int64_t vaeq_dp_resident_runs(int32_t B, int32_t sps, int32_t M, int32_t n_lev, int32_t threads);
+
 /* ------------------------------------------------------------------------
  * Stand-alone soft demapper:  shared_funcs.py:529-542 (soft_dec), the same
  * formula as the demapping half of twoXtwoFIR.forward (shared_funcs.py:521-523).

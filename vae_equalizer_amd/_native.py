@@ -71,7 +71,7 @@ class AWGNArgs(C.Structure):
 
 
 # every symbol include/vaeq.h declares; tests check the library exports all of them
-EXPORTS = ["vaeq_dp_train", "vaeq_dp_lds_bytes", "vaeq_soft_demap", "vaeq_dp_forward", "vaeq_dp_loss", "vaeq_awgn_train",
+EXPORTS = ["vaeq_dp_train", "vaeq_dp_lds_bytes", "vaeq_dp_resident_runs", "vaeq_soft_demap", "vaeq_dp_forward", "vaeq_dp_loss", "vaeq_awgn_train",
            "vaeq_awgn_lds_bytes", "vaeq_awgn_forward", "vaeq_version", "vaeq_strerror"]
 
 
@@ -90,6 +90,8 @@ def lib():
         L.vaeq_dp_train.argtypes = [C.POINTER(DPArgs), C.c_void_p]
         L.vaeq_dp_lds_bytes.restype = C.c_int64
         L.vaeq_dp_lds_bytes.argtypes = [C.c_int32] * 4
+        L.vaeq_dp_resident_runs.restype = C.c_int64
+        L.vaeq_dp_resident_runs.argtypes = [C.c_int32] * 5
         L.vaeq_soft_demap.restype = C.c_int
         L.vaeq_soft_demap.argtypes = [C.c_int32, C.c_int64, C.c_int32] + [C.c_void_p] * 6
         L.vaeq_dp_forward.restype = C.c_int

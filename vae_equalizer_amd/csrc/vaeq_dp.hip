@@ -435,3 +435,43 @@ extern "C" int vaeq_dp_train(const vaeq_dp_args *pa, void *stream)
     }
     return VAEQ_ERR_SHAPE;
 }
+
+namespace vaeq {
+int64_t dp_wave_resident(int B, int M, int n_lev);   // vaeq_dp_wave.hip
+template <int NT, int NLEV>
+static int64_t resident_generic(size_t lds)
+{
+    int nb = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return VAEQ_ERR_DEVICE;
+    auto k = dp_train_kernel<NT, NLEV>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, NT, lds) != hipSuccess) return VAEQ_ERR_DEVICE;
+    return (int64_t)nb * prop.multiProcessorCount;
+}
+}  // namespace vaeq
+
+extern "C" int64_t vaeq_dp_resident_runs(int32_t B, int32_t sps, int32_t M, int32_t n_lev, int32_t threads)
+{
+    const int64_t lds = vaeq_dp_lds_bytes(B, sps, M, n_lev);
+    if (lds < 0) return lds;
+    vaeq_dp_args a = {};
+    a.B = B; a.sps = sps; a.M = M; a.n_lev = n_lev; a.stride_sym = B; a.keep_len = B; a.S = 4;
+    if ((threads == 0 || threads == 1) && vaeq::dp_wave_supported(a)) return vaeq::dp_wave_resident(B, M, n_lev);
+    if (threads == 1) return VAEQ_ERR_SHAPE;
+#define VAEQ_RES(NT)                                                          \
+    switch (n_lev) {                                                          \
+    case 2: return vaeq::resident_generic<NT, 2>((size_t)lds);                \
+    case 4: return vaeq::resident_generic<NT, 4>((size_t)lds);                \
+    case 8: return vaeq::resident_generic<NT, 8>((size_t)lds);                \
+    }                                                                         \
+    return VAEQ_ERR_SHAPE;
+    switch (threads) {
+    case 0:
+    case 256: VAEQ_RES(256)
+    case 128: VAEQ_RES(128)
+    case 64: VAEQ_RES(64)
+    }
+#undef VAEQ_RES
+    return VAEQ_ERR_SHAPE;
+}

@@ -58,19 +58,24 @@ __host__ __device__ inline WaveLayout wave_layout(int B, int M)
 
 typedef float v2f __attribute__((ext_vector_type(2)));   // element-wise ops compile to v_pk_{add,mul,fma}_f32
 
+// Complex MACs written on 2-vectors so that each is exactly two v_pk_fma_f32 (broadcast / swap / negate ride on the
+// op_sel and neg modifiers; with scalar fmaf chains hipcc's SLP vectoriser pairs unrelated accumulators and pays a
+// v_mov per operand to line them up).
 __device__ __forceinline__ void cmac(float2 &acc, float wr, float wi, float2 x)       // acc += (wr + j wi) * x
 {
-    acc.x = fmaf(wr, x.x, acc.x);
-    acc.x = fmaf(-wi, x.y, acc.x);
-    acc.y = fmaf(wr, x.y, acc.y);
-    acc.y = fmaf(wi, x.x, acc.y);
+    v2f a = {acc.x, acc.y};
+    a += v2f{wr, wr} * v2f{x.x, x.y};
+    a += v2f{wi, wi} * v2f{-x.y, x.x};
+    acc.x = a.x;
+    acc.y = a.y;
 }
-__device__ __forceinline__ void cmacc(float2 &acc, float2 a, float br, float bi)      // acc += a * conj(br + j bi)
+__device__ __forceinline__ void cmacc(float2 &acc, float2 a_, float br, float bi)     // acc += a * conj(br + j bi)
 {
-    acc.x = fmaf(a.x, br, acc.x);
-    acc.x = fmaf(a.y, bi, acc.x);
-    acc.y = fmaf(a.y, br, acc.y);
-    acc.y = fmaf(-a.x, bi, acc.y);
+    v2f a = {acc.x, acc.y};
+    a += v2f{br, br} * v2f{a_.x, a_.y};
+    a += v2f{bi, bi} * v2f{a_.y, -a_.x};
+    acc.x = a.x;
+    acc.y = a.y;
 }
 
 __device__ __forceinline__ float wave_incl_scan(float v, int lane)                    // inclusive prefix sum over lanes
@@ -192,28 +197,38 @@ __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
     const int n0 = 2 * lane;
     const float2 *Xl = Xs + lane, *El = Es + lane, *Ul = Us + lane;
 
+    // The window of the NEXT step is fetched into registers while the current step computes (one 16-byte load per lane and
+    // row: B <= 128 means L/4 <= 64 lanes), so a step never waits for HBM after the first.
+    const bool ldl = lane < L / 4;
+    float4 pf[4];
+    auto fetch = [&](int f, int s) {
+        const float *src = a.rx + ((size_t)run * a.n_frames + f) * 4 * (size_t)a.S + (size_t)s * a.stride_sym * 2 + 4 * lane;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            pf[r] = ldl ? *reinterpret_cast<const float4 *>(src + (size_t)r * a.S) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    fetch(0, 0);
     for (int f = 0; f < a.n_frames; f++) {
-        const float *rxf = a.rx + ((size_t)run * a.n_frames + f) * 4 * (size_t)a.S;
         float *qf = a.q_out ? a.q_out + ((size_t)run * a.n_frames + f) * (4 * NLEV) * No : nullptr;
         float *yf = a.y_out ? a.y_out + ((size_t)run * a.n_frames + f) * 4 * No : nullptr;
 #pragma unroll 1
         for (int s = 0; s < a.steps; s++) {
-            // ============ P0: window -> LDS (16-byte loads, polyphase scatter); halo stays zero
-            {
-                const size_t s0 = (size_t)s * a.stride_sym * 2;
-                for (int v = lane; v < L / 4; v += 64) {
+            // ============ P0: prefetched window -> LDS (polyphase scatter; halo stays zero), then prefetch the next one
+            if (ldl) {
 #pragma unroll
-                    for (int p = 0; p < 2; p++) {
-                        const float4 I4 = *reinterpret_cast<const float4 *>(rxf + (size_t)(p * 2 + 0) * a.S + s0 + 4 * v);
-                        const float4 Q4 = *reinterpret_cast<const float4 *>(rxf + (size_t)(p * 2 + 1) * a.S + s0 + 4 * v);
-                        const float xi[4] = {I4.x, I4.y, I4.z, I4.w}, xq[4] = {Q4.x, Q4.y, Q4.z, Q4.w};
+                for (int p = 0; p < 2; p++) {
+                    const float4 I4 = pf[p * 2 + 0], Q4 = pf[p * 2 + 1];
+                    const float xi[4] = {I4.x, I4.y, I4.z, I4.w}, xq[4] = {Q4.x, Q4.y, Q4.z, Q4.w};
 #pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const int c = mh + i;              // + 4v: phase (c & 3) is lane independent
-                            Xs[(p * 4 + (c & 3)) * Lph + v + (c >> 2)] = make_float2(xi[i], xq[i]);
-                        }
+                    for (int i = 0; i < 4; i++) {
+                        const int c = mh + i;                  // + 4*lane: phase (c & 3) is lane independent
+                        Xs[(p * 4 + (c & 3)) * Lph + lane + (c >> 2)] = make_float2(xi[i], xq[i]);
                     }
                 }
+            }
+            {
+                const bool last_s = s + 1 == a.steps;
+                if (!(last_s && f + 1 == a.n_frames)) fetch(last_s ? f + 1 : f, last_s ? 0 : s + 1);
             }
             __syncthreads();
 
@@ -641,6 +656,35 @@ bool dp_wave_supported(const vaeq_dp_args &a)
     if (a.y_out && (reinterpret_cast<uintptr_t>(a.y_out) & 7)) return false;
     if ((a.dbg_gW == nullptr) != (a.dbg_gh == nullptr)) return false;
     return true;
+}
+
+template <int M, int NLEV, int BT>
+static int64_t wave_resident(int B)
+{
+    int nb = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return VAEQ_ERR_DEVICE;
+    const size_t lds = (size_t)wave_layout(B, M).total;
+    auto k = dp_wave_kernel<M, NLEV, BT, true>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64, lds) != hipSuccess) return VAEQ_ERR_DEVICE;
+    return (int64_t)nb * prop.multiProcessorCount;
+}
+
+int64_t dp_wave_resident(int B, int M, int n_lev)
+{
+#define VAEQ_WR(MM, BB)                                   \
+    switch (n_lev) {                                      \
+    case 2: return wave_resident<MM, 2, BB>(B);           \
+    case 4: return wave_resident<MM, 4, BB>(B);           \
+    case 8: return wave_resident<MM, 8, BB>(B);           \
+    }                                                     \
+    return VAEQ_ERR_SHAPE;
+    if (M == 25 && B == 100) { VAEQ_WR(25, 100) }
+    if (M == 25) { VAEQ_WR(25, 0) }
+    if (M == 13) { VAEQ_WR(13, 0) }
+    if (M == 9) { VAEQ_WR(9, 0) }
+#undef VAEQ_WR
+    return VAEQ_ERR_SHAPE;
 }
 
 int launch_dp_wave(const vaeq_dp_args &a, hipStream_t st)
