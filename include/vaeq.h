@@ -169,6 +169,18 @@ int64_t vaeq_awgn_lds_bytes(int32_t B, int32_t sps, int32_t M, int32_t n_lev);
 int vaeq_awgn_forward(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, const float *x, const float *W,
                       const float *amp, const float *amp_mean, const float *var, float *q, float *y, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Per-frame epilogue of the DP runs: shift / polarisation-swap search and both SER estimators,
+ *   shared_funcs.py:188-338 with the roll / cut / slice logic of func_VAELE_DP_MQAM_shaping.py:68-89 (batch_len > 0)
+ *   or func_VAEflex_DP_MQAM_shaping.py:72-84 (batch_len = 0: no per-minibatch cut).
+ * q[R][2][2*n_lev][N] (out_train), y[R][2][2][N] (out_const), tx_f16[R][2][2][N] IEEE half (data_tensor, shared_funcs.py:89),
+ * var[R][2], nu_sc[R] -> ser[R][4] (rows: constellation x, y; soft demapper x, y), shift[R][2 path][2] (path 0 = q, 1 = y),
+ * rflag[R][2].  workspace: vaeq_dp_epilogue_ws_bytes(R, N) bytes of device memory. */
+int vaeq_dp_epilogue(int32_t R, int64_t N, int32_t n_lev, int32_t batch_len, const float *q, const float *y, const void *tx_f16,
+                     const float *amp, const float *var, const float *nu_sc, float *ser, int32_t *shift, int32_t *rflag,
+                     void *workspace, void *stream);
+int64_t vaeq_dp_epilogue_ws_bytes(int32_t R, int64_t N);
+
 int vaeq_version(void);
 const char *vaeq_strerror(int code);
 

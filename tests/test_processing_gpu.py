@@ -107,3 +107,48 @@ def test_eval_run_awgn_script_mat_schema(tmp_path, monkeypatch):
     m = io.loadmat(name)["dict"]
     assert set(m.dtype.names) == {"SER", "SNR", "M", "lr", "N_train", "nu"}
     assert "SERvsSNR_VAELE_shaping_0_h1_64-QAM_2_2000_2_1200_" in name
+
+
+def test_hip_epilogue_on_converged_reference_frame():
+    """vaeq_dp_epilogue on G5's converged frame == the reference's own shift / swap / SER results."""
+    from vae_equalizer_amd.engine import dp_epilogue
+    g = load_golden("G5_dp_epilogue")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    r = dp_epilogue(t(g["out_train"])[None], t(g["out_const"])[None], t(g["data"])[None], g["amp_levels"], float(g["nu_sc"]), g["var"],
+                    batch_len=int(g["B"]))
+    assert np.array_equal(r["shift_q"][0].cpu().numpy(), g["shifts"][-1, 0]) and int(r["r_q"][0]) == g["rs"][-1, 0]
+    assert np.array_equal(r["shift_c"][0].cpu().numpy(), g["shifts"][-1, 1]) and int(r["r_c"][0]) == g["rs"][-1, 1]
+    assert np.allclose(r["SER"][0].cpu().numpy(), g["SER_valid"][:, -1], atol=1e-6)
+
+
+@pytest.mark.parametrize("batch_len", [None, 100])
+@pytest.mark.parametrize("n", [2, 8])
+def test_hip_epilogue_random_batch_vs_oracle(batch_len, n):
+    """R=12 synthetic runs (delays, swaps, rotations, IQ flips, different noise / shaping): HIP epilogue == numpy oracle per run."""
+    import oracle
+    from vae_equalizer_amd.engine import dp_epilogue
+    lev_all = np.arange(-(n - 1), n, 2).astype(np.float32)
+    amp = (lev_all / np.sqrt(np.mean(lev_all ** 2) * 2)).astype(np.float32)
+    rng = np.random.default_rng(21 + n)
+    R, N = 12, 1000
+    qs, ys, ds, nus, vars_ = [], [], [], [], []
+    for i in range(R):
+        lev = rng.integers(0, n, (2, 2, N))
+        clean = amp[lev].astype(np.float32)
+        rot = [clean, np.stack([-clean[:, 1], clean[:, 0]], 1), -clean, np.stack([clean[:, 1], -clean[:, 0]], 1)][i % 4]
+        if i % 5 == 4:
+            rot = np.stack([rot[:, 0], -rot[:, 1]], 1)
+        y = rot + (0.02 + 0.03 * i) * rng.standard_normal(rot.shape).astype(np.float32)
+        sw, d = i % 2, int(rng.integers(-9, 10))
+        y = np.roll(y, sw, axis=0)
+        dl = (d, d) if sw else (d, int(rng.integers(-9, 10)))
+        y = np.stack([np.roll(y[0], dl[0], -1), np.roll(y[1], dl[1], -1)])
+        nu_sc = float(rng.uniform(0, 1.2)); v = rng.uniform(0.002, 0.02, 2).astype(np.float32)
+        qs.append(oracle.dp_soft_dec(y, v, amp, nu_sc)); ys.append(y); ds.append(amp[lev].astype(np.float16)); nus.append(nu_sc); vars_.append(v)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(np.stack(a))).cuda()
+    r = dp_epilogue(t(qs), t(ys), t(ds), amp, torch.tensor(nus, dtype=torch.float32), t(vars_), batch_len)
+    for i in range(R):
+        o = oracle.dp_frame_epilogue(qs[i], ys[i], ds[i], amp, nus[i], vars_[i], batch_len=batch_len)
+        assert np.array_equal(r["shift_q"][i].cpu().numpy(), o["shift_q"]) and int(r["r_q"][i]) == o["r_q"], i
+        assert np.array_equal(r["shift_c"][i].cpu().numpy(), o["shift_c"]) and int(r["r_c"][i]) == o["r_c"], i
+        assert np.allclose(r["SER"][i].cpu().numpy(), o["SER"], atol=2.5e-3), (i, r["SER"][i], o["SER"])     # <= 2 symbols of ~900 at a threshold

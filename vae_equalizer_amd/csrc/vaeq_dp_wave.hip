@@ -56,6 +56,11 @@ __host__ __device__ inline WaveLayout wave_layout(int B, int M)
     return l;
 }
 
+// One wave per workgroup: LDS instructions of a wave execute in issue order, so a later ds_read of any lane sees an earlier
+// ds_write of any other lane without a hardware wait.  What is needed is only that the COMPILER keeps that order --
+// __syncthreads() would also emit s_waitcnt vmcnt(0) and stall every phase on the step's in-flight q/y stores.
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("" ::: "memory"); }
+
 typedef float v2f __attribute__((ext_vector_type(2)));   // element-wise ops compile to v_pk_{add,mul,fma}_f32
 
 // Complex MACs written on 2-vectors so that each is exactly two v_pk_fma_f32 (broadcast / swap / negate ride on the
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
         float *yf = a.y_out ? a.y_out + ((size_t)run * a.n_frames + f) * 4 * No : nullptr;
 #pragma unroll 1
         for (int s = 0; s < a.steps; s++) {
-            // ============ P0: prefetched window -> LDS (polyphase scatter; halo stays zero), then prefetch the next one
+            // ============ P0: prefetched window -> LDS (polyphase scatter; halo stays zero)
             if (ldl) {
 #pragma unroll
                 for (int p = 0; p < 2; p++) {
@@ -226,11 +231,7 @@ __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
                     }
                 }
             }
-            {
-                const bool last_s = s + 1 == a.steps;
-                if (!(last_s && f + 1 == a.n_frames)) fetch(last_s ? f + 1 : f, last_s ? 0 : s + 1);
-            }
-            __syncthreads();
+            wave_lds_sync();
 
             // ============ P1: FIR for the lane's symbol pair, both output polarisations
             float2 y[2][2];                                    // [sym][o]
@@ -347,12 +348,12 @@ __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
                 }
                 if (lane == 0) PSv[o * (B + 1)] = 0.f;
             }
-            __syncthreads();
+            wave_lds_sync();
             if (owner) {                                       // VS[nu][j]: lane = (j = tk, nu = half)
                 const int lo = (Mh - tk + 1) >> 1, hi_ = (nm - 1 + Mh - tk) >> 1;
                 VS[half * M + tk] = PSv[half * (B + 1) + hi_ + 1] - PSv[half * (B + 1) + lo];
             }
-            __syncthreads();
+            wave_lds_sync();
 
             // ============ P3: residual e = x - D for the quad t = 4l'..4l'+3, both chi.
             //   D[chi, 2 tau + par] = sum_nu sum_a h[chi,nu,2a+par] U[nu, tau + mh - a],   tau in {2l', 2l'+1}, a = 0..mh
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
                 if (owner) PSh[half * MP + tk + 1] = inc;
                 if (tk == 0) PSh[half * MP] = 0.f;
             }
-            __syncthreads();
+            wave_lds_sync();
 
             // ============ P4a: dL/dh partial sums, lane = (j = tk, half of the tau range); acc[chi][nu]
             step += 1;
@@ -502,6 +503,12 @@ __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
 
             asm volatile("" : "+v"(hnew[0].x), "+v"(hnew[0].y), "+v"(hnew[1].x), "+v"(hnew[1].y), "+v"(ghr[0]), "+v"(ghr[1]), "+v"(ghi[0]),
                          "+v"(ghi[1]));                        // pin (see P1)
+            // prefetch the next window now: the q/y stores of this step were issued half a step ago and have drained, so the wait
+            // for these loads at the top of the next step does not also wait for fresh stores (vmcnt retires in order)
+            {
+                const bool last_s = s + 1 == a.steps;
+                if (!(last_s && f + 1 == a.n_frames)) fetch(last_s ? f + 1 : f, last_s ? 0 : s + 1);
+            }
             // ============ P4b: dL/dU for the lane's symbol pair (same shape as the FIR, on e with conj(h)), then dL/dy
             float2 gy[2][2];                                   // [sym][nu]
             {
@@ -527,7 +534,7 @@ __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
                     }
                 }
             }
-            __syncthreads();                                   // every read of U / old h is done (GY aliases U)
+            wave_lds_sync();                                   // every read of U / old h is done (GY aliases U)
             if (act) {
 #pragma unroll
                 for (int v = 0; v < 2; v++) {
@@ -539,7 +546,7 @@ __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
                 Ht[(half * 2 + 0) * MP + tk] = hnew[0];
                 Ht[(half * 2 + 1) * MP + tk] = hnew[1];
             }
-            __syncthreads();
+            wave_lds_sync();
 
             // ============ P5: dL/dw partial sums, lane = (k = tk, half of the symbol range); acc[o][p]
             float gwr[2] = {0, 0}, gwi[2] = {0, 0};
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
                     a.dbg_gh[gbase + ((half * 2 + p) * 2 + 1) * M + tk] = ghi[p];
                 }
             }
-            __syncthreads();
+            wave_lds_sync();
         }
     }
 

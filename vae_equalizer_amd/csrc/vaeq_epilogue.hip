@@ -1,0 +1,262 @@
+// vaeq_epilogue.hip -- per-frame epilogue of the DP runs on the device, one workgroup per run.
+//
+// Restates, for R runs at once,
+//   shared_funcs.py:290-338  find_shift / find_shift_symb_full  (|correlation| of TX I and Q of both polarisations with the
+//                            equaliser-side sequence rolled by -10..10 symbols; straight vs swapped pairing)
+//   shared_funcs.py:188-222  SER_IQflip          (argmax(q) against TX, min over IQ-flip x 4 quadrant rotations)
+//   shared_funcs.py:225-287  SER_constell_shaping + dec_on_bound (PCS-aware thresholds on the mean-radius-normalised FIR output)
+// and the roll / cut / slice logic of func_VAELE_DP_MQAM_shaping.py:68-89 (batch_len > 0: the last shift[0]+10 symbols of every
+// minibatch and 11 (+max|shift|) symbols at the frame ends are dropped) resp. func_VAEflex_DP_MQAM_shaping.py:72-84 (batch_len = 0).
+// Data-dependent rolls and slices are index arithmetic and masks; counters are integers (LDS atomics), float sums are reduced in
+// a fixed order, so results are bitwise reproducible.
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vaeq.h"
+#include "vaeq_common.h"
+
+namespace vaeq {
+
+constexpr int EPI_NT = 256, N_SHIFT = 21, HALF_SHIFT = 10, N_CUT = 10, EDGE = 11;
+constexpr int N_COMBO = 2 * N_SHIFT;          // (lag, E-polarisation)
+constexpr int N_CHUNK = EPI_NT / N_COMBO;     // symbol-axis chunks summed by different threads (6)
+
+struct EpiShared {
+    float part[N_CHUNK][N_COMBO][4];          // partial correlations [chunk][(lag,b)][(a,c)]
+    float corr[2][2][2][N_SHIFT];             // [c][b][a][lag]
+    int shift[2];
+    int r;
+    int cnt[16];                              // error counts [hypothesis 0..7][pol]
+    int kept;
+    float lo[8], hi[8];                       // decision interval of each TX level (shared_funcs.py:234-236)
+    float red[64];
+};
+
+// correlation of the TX reference with E[b][.] rolled by lag-10 (shared_funcs.py:300-304): thread = (lag, b, chunk)
+__device__ void epi_correlate(const float *__restrict__ E /*[2][N] or strided*/, int64_t estride, const __half *__restrict__ tx, int64_t N,
+                              EpiShared &sh)
+{
+    const int tid = threadIdx.x;
+    if (tid < N_COMBO * N_CHUNK) {
+        const int chunk = tid / N_COMBO, cb = tid - chunk * N_COMBO, lag = cb >> 1, b = cb & 1;
+        const int64_t n0 = N * chunk / N_CHUNK, n1 = N * (chunk + 1) / N_CHUNK;
+        const float *Eb = E + (int64_t)b * estride;
+        float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;       // [a][c]
+        int64_t m = (n0 - (lag - HALF_SHIFT)) % N;              // roll(E, lag-10)[n] = E[(n - (lag-10)) mod N]
+        if (m < 0) m += N;
+        for (int64_t n = n0; n < n1; n++) {
+            const float e = Eb[m];
+            s00 = fmaf(__half2float(tx[0 * N + n]), e, s00);
+            s01 = fmaf(__half2float(tx[1 * N + n]), e, s01);
+            s10 = fmaf(__half2float(tx[2 * N + n]), e, s10);
+            s11 = fmaf(__half2float(tx[3 * N + n]), e, s11);
+            if (++m == N) m = 0;
+        }
+        sh.part[chunk][cb][0] = s00; sh.part[chunk][cb][1] = s01; sh.part[chunk][cb][2] = s10; sh.part[chunk][cb][3] = s11;
+    }
+    __syncthreads();
+    if (tid < N_COMBO * 4) {                                    // fixed-order sum over chunks
+        const int cb = tid >> 2, ac = tid & 3, lag = cb >> 1, b = cb & 1, a = ac >> 1, c = ac & 1;
+        float s = 0.f;
+        for (int k = 0; k < N_CHUNK; k++) s += sh.part[k][cb][ac];
+        sh.corr[c][b][a][lag] = fabsf(s);
+    }
+    __syncthreads();
+    if (tid == 0) {                                             // shared_funcs.py:303-314
+        float cm[2][2];
+        int pick[2][2];
+        for (int b = 0; b < 2; b++)
+            for (int a = 0; a < 2; a++) {
+                float best[2];
+                int bi[2];
+                for (int c = 0; c < 2; c++) {
+                    best[c] = sh.corr[c][b][a][0];
+                    bi[c] = 0;
+                    for (int l = 1; l < N_SHIFT; l++)
+                        if (sh.corr[c][b][a][l] > best[c]) { best[c] = sh.corr[c][b][a][l]; bi[c] = l; }
+                }
+                const int cw = best[1] > best[0] ? 1 : 0;       // torch.max over (I, Q): first maximum wins ties
+                cm[b][a] = best[cw];
+                pick[b][a] = bi[cw];
+            }
+        const bool straight = (cm[0][0] + cm[1][1]) >= (cm[0][1] + cm[1][0]);
+        sh.shift[0] = HALF_SHIFT - (straight ? pick[0][0] : pick[0][1]);
+        sh.shift[1] = HALF_SHIFT - (straight ? pick[1][1] : pick[1][0]);
+        sh.r = straight ? 0 : 1;
+        for (int i = 0; i < 16; i++) sh.cnt[i] = 0;
+        sh.kept = 0;
+    }
+    __syncthreads();
+}
+
+// symbols that survive the per-minibatch cut (:73-77) and the frame-edge slice (:79)
+__device__ __forceinline__ bool epi_keep(int64_t n, int64_t N, int batch_len, int shift0, int ms)
+{
+    if (batch_len <= 0) return n >= EDGE && n < N - EDGE - ms;
+    int Lk = batch_len - shift0 - N_CUT;
+    Lk = Lk < 0 ? 0 : (Lk > batch_len ? batch_len : Lk);
+    const int64_t mb = n / batch_len, j = n - mb * batch_len, k = mb * Lk + j, K = (N / batch_len) * Lk;
+    return j < Lk && k >= EDGE && k < K - EDGE - ms;
+}
+
+template <int NLEV>
+__global__ __launch_bounds__(EPI_NT) void dp_epilogue_kernel(int64_t N, int batch_len, const float *__restrict__ q, const float *__restrict__ y,
+                                                             const __half *__restrict__ txg, const float *__restrict__ amp_g,
+                                                             const float *__restrict__ var, const float *__restrict__ nu_sc,
+                                                             float *__restrict__ ser, int32_t *__restrict__ shift_out,
+                                                             int32_t *__restrict__ r_out, float *__restrict__ wsE, int8_t *__restrict__ wsD)
+{
+    __shared__ EpiShared sh;
+    const int run = blockIdx.x, tid = threadIdx.x;
+    const float *qr = q + (size_t)run * 4 * NLEV * N, *yr = y + (size_t)run * 4 * N;
+    const __half *tx = txg + (size_t)run * 4 * N;              // [a][c][n]
+    float *E = wsE + (size_t)run * 2 * N;
+    int8_t *D = wsD + (size_t)run * 4 * N;
+    float amp[NLEV];
+#pragma unroll
+    for (int i = 0; i < NLEV; i++) amp[i] = amp_g[i];
+    const float scale = 0.5f * (NLEV - 1);
+    if (tid == 0) {
+        const float thr_scale = 1.0f + 2.0f * nu_sc[run] * var[run * 2 + 0];      // :234
+        for (int i = 0; i < NLEV; i++) {
+            sh.lo[i] = i == 0 ? -INFINITY : thr_scale * (amp_g[i - 1] + amp_g[i]) / 2;
+            sh.hi[i] = i == NLEV - 1 ? INFINITY : thr_scale * (amp_g[i] + amp_g[i + 1]) / 2;
+        }
+    }
+
+    // ---- pass 1: E_q[x_I] per polarisation (shared_funcs.py:296-297) and hard decisions argmax(q) per axis (:201)
+    for (int64_t n = tid; n < N; n += EPI_NT) {
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            float e = 0.f;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                float best = qr[(size_t)(p * 2 * NLEV + c * NLEV) * N + n];
+                int bi = 0;
+                if (c == 0) e = amp[0] * best;
+#pragma unroll
+                for (int i = 1; i < NLEV; i++) {
+                    const float v = qr[(size_t)(p * 2 * NLEV + c * NLEV + i) * N + n];
+                    if (c == 0) e = fmaf(amp[i], v, e);
+                    if (v > best) { best = v; bi = i; }
+                }
+                D[(size_t)(p * 2 + c) * N + n] = (int8_t)bi;
+            }
+            E[(size_t)p * N + n] = e;
+        }
+    }
+    __syncthreads();                                            // the workgroup's own global writes are visible to it after the barrier
+
+    for (int path = 0; path < 2; path++) {                      // 0: soft-demapper path on q, 1: constellation path on y
+        if (path == 0) epi_correlate(E, N, tx, N, sh);
+        else epi_correlate(yr, 2 * N, tx, N, sh);               // y[:, 0, :]: rows 0 and 2 of y[2][2][N]   (:321)
+        const int s0 = sh.shift[0], s1 = sh.shift[1], r = sh.r;
+        const int ms = max(abs(s0), abs(s1));
+        if (tid == 0) {
+            shift_out[(size_t)run * 4 + path * 2 + 0] = s0;
+            shift_out[(size_t)run * 4 + path * 2 + 1] = s1;
+            r_out[(size_t)run * 2 + path] = r;
+        }
+        float fac = 1.0f;
+        if (path == 1) {                                        // mean radius of TX over mean radius of the aligned output (:242)
+            float st = 0.f, sy = 0.f;
+            for (int64_t n = tid; n < N; n += EPI_NT) {
+                if (!epi_keep(n, N, batch_len, s0, ms)) continue;
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const int sp = (p - r) & 1;
+                    int64_t m = n + (p ? s1 : s0);
+                    m %= N; if (m < 0) m += N;
+                    const float ti = __half2float(tx[(size_t)(p * 2 + 0) * N + n]), tq = __half2float(tx[(size_t)(p * 2 + 1) * N + n]);
+                    const float yi = yr[(size_t)(sp * 2 + 0) * N + m], yq = yr[(size_t)(sp * 2 + 1) * N + m];
+                    st += sqrtf(ti * ti + tq * tq);
+                    sy += sqrtf(yi * yi + yq * yq);
+                }
+            }
+            block_reduce3<EPI_NT>(st, sy, 0.f, sh.red);
+            fac = sh.red[0] / sh.red[1];
+            __syncthreads();
+        }
+        int cnt[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) cnt[i] = 0;
+        int kept = 0;
+        for (int64_t n = tid; n < N; n += EPI_NT) {
+            if (!epi_keep(n, N, batch_len, s0, ms)) continue;
+            kept++;
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const int sp = (p - r) & 1;                     // roll(r, 0): row p comes from row p - r  (:71)
+                int64_t m = n + (p ? s1 : s0);                  // roll(-shift): out[n] = in[n + shift]     (:72)
+                m %= N; if (m < 0) m += N;
+                const float dI = rintf(scale * __half2float(tx[(size_t)(p * 2 + 0) * N + n]) + scale);       // :198
+                const float dQ = rintf(scale * __half2float(tx[(size_t)(p * 2 + 1) * N + n]) + scale);
+                const float dQi = -(dQ - 2.0f * scale);         // IQ flip (:199)
+                if (path == 0) {
+                    const float a0 = (float)D[(size_t)(sp * 2 + 0) * N + m], a1 = (float)D[(size_t)(sp * 2 + 1) * N + m];
+                    // decisions under rotation by 0, pi, pi/2, 3pi/2 (:201-217)
+                    const float hI[4] = {a0, -(a0 - 2.0f * scale), -(a1 - 2.0f * scale), a1};
+                    const float hQ[4] = {a1, -(a1 - 2.0f * scale), a0, -(a0 - 2.0f * scale)};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        cnt[(2 * k + 0) * 2 + p] += (dI != hI[k]) || (dQ != hQ[k]);
+                        cnt[(2 * k + 1) * 2 + p] += (dI != hI[k]) || (dQi != hQ[k]);
+                    }
+                } else {
+                    const float yi = yr[(size_t)(sp * 2 + 0) * N + m] * fac, yq = yr[(size_t)(sp * 2 + 1) * N + m] * fac;
+                    const float rI[4] = {yi, -yi, -yq, yq}, rQ[4] = {yq, -yq, yi, -yi};        // :245-262
+                    auto inside = [&](float v, float lev) {     // d_vec0[lev] <= v < d_vec1[lev]   (:267-287)
+                        const int li = min(max((int)lev, 0), NLEV - 1);
+                        return sh.lo[li] <= v && v < sh.hi[li];
+                    };
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const bool okI = inside(rI[k], dI);
+                        cnt[(2 * k + 0) * 2 + p] += !(okI && inside(rQ[k], dQ));
+                        cnt[(2 * k + 1) * 2 + p] += !(okI && inside(rQ[k], dQi));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) atomicAdd(&sh.cnt[i], cnt[i]);
+        atomicAdd(&sh.kept, kept);
+        __syncthreads();
+        if (tid < 2) {                                          // min over the 8 hypotheses (:221 / :264)
+            const float den = (float)max(sh.kept, 1);
+            float best = 2.0f;
+            for (int k = 0; k < 8; k++) best = fminf(best, (float)sh.cnt[k * 2 + tid] / den);
+            ser[(size_t)run * 4 + (path == 0 ? 2 : 0) + tid] = best;       // rows 0-1 constellation, 2-3 soft demapper (:79,89)
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace vaeq
+
+extern "C" int64_t vaeq_dp_epilogue_ws_bytes(int32_t R, int64_t N)
+{
+    if (R < 0 || N < 0) return VAEQ_ERR_SHAPE;
+    return (int64_t)R * N * (2 * 4 + 4);                        // E_q[x_I] floats [R][2][N] + hard decisions int8 [R][2][2][N]
+}
+
+extern "C" int vaeq_dp_epilogue(int32_t R, int64_t N, int32_t n_lev, int32_t batch_len, const float *q, const float *y, const void *tx_f16,
+                                const float *amp, const float *var, const float *nu_sc, float *ser, int32_t *shift, int32_t *rflag,
+                                void *workspace, void *stream)
+{
+    if (!q || !y || !tx_f16 || !amp || !var || !nu_sc || !ser || !shift || !rflag || !workspace) return VAEQ_ERR_NULL;
+    if (R < 0 || N < 2 * vaeq::EDGE + vaeq::N_SHIFT || batch_len < 0 || (batch_len > 0 && N % batch_len)) return VAEQ_ERR_SHAPE;
+    if (R == 0) return VAEQ_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float *wsE = reinterpret_cast<float *>(workspace);
+    int8_t *wsD = reinterpret_cast<int8_t *>(wsE + (size_t)R * 2 * N);
+    const __half *tx = reinterpret_cast<const __half *>(tx_f16);
+    switch (n_lev) {
+    case 2: hipLaunchKernelGGL(vaeq::dp_epilogue_kernel<2>, dim3(R), dim3(vaeq::EPI_NT), 0, st, N, batch_len, q, y, tx, amp, var, nu_sc, ser, shift, rflag, wsE, wsD); break;
+    case 4: hipLaunchKernelGGL(vaeq::dp_epilogue_kernel<4>, dim3(R), dim3(vaeq::EPI_NT), 0, st, N, batch_len, q, y, tx, amp, var, nu_sc, ser, shift, rflag, wsE, wsD); break;
+    case 8: hipLaunchKernelGGL(vaeq::dp_epilogue_kernel<8>, dim3(R), dim3(vaeq::EPI_NT), 0, st, N, batch_len, q, y, tx, amp, var, nu_sc, ser, shift, rflag, wsE, wsD); break;
+    default: return VAEQ_ERR_SHAPE;
+    }
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}

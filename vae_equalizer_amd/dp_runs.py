@@ -1,6 +1,6 @@
 """Batched driver of the DP VAE-LE / VAEflex Monte-Carlo runs: what ``processing()`` of
 optical_DP_channel/func_VAELE_DP_MQAM_shaping.py:17-95 and func_VAEflex_DP_MQAM_shaping.py:16-90 does for one run,
-done for R runs per frame with one kernel launch (engine.DPEngine) and one batched epilogue (epilogue.py).
+done for R runs per frame with one training-kernel launch (engine.DPEngine) and one epilogue-kernel launch (engine.dp_epilogue).
 
 Runs in one batch share (mod, sps, M_est, batch_len, N_frame_max, num_frames, flex_step, channel, N_lrhalf) -- the
 shape of the problem -- and may differ in SNR, nu, theta_diff, theta, lr_optim, symb_rate and seed.
@@ -12,9 +12,8 @@ import numpy as np
 import torch
 
 from . import channel as ch
-from . import epilogue as epi
 from . import shared_funcs as sfun
-from .engine import DPEngine
+from .engine import DPEngine, dp_epilogue
 
 
 @dataclass
@@ -106,7 +105,7 @@ def run_dp_batch(runs, mod, sps, M_est, batch_len, N_frame_max, num_frames, flex
         q, y = out["q"][:, 0], out["y"][:, 0]
         ve = out["var_est"][:, 0]                                               # [R,2,steps]
         Var_est[:, :, frame] = ve.mean(dim=2).cpu()                             # :69
-        res = epi.dp_frame_epilogue(q, y, data, amp, nu_sc_t, var, None if flex else batch_len)
+        res = dp_epilogue(q, y, data, amp, nu_sc_t, var, None if flex else batch_len)     # HIP kernel (vaeq_dp_epilogue)
         SER[:, :, frame] = res["SER"].cpu()
         if verbose:
             loss = out["loss"][:, 0, -1].cpu()

@@ -221,3 +221,25 @@ class AWGNEngine:
                                                   nat.ptr(self.amp_mean), nat.ptr(self.var), nat.ptr(q), nat.ptr(y),
                                                   nat.current_stream(self.device)), "vaeq_awgn_forward")
         return q, y
+
+
+def dp_epilogue(q, y, data, amp_levels, nu_sc, var, batch_len=None):
+    """Per-frame epilogue on the device (vaeq_dp_epilogue): q[R,2,2n,N], y[R,2,2,N], data[R,2,2,N] fp16 ->
+    dict(SER[R,4], shift_q[R,2], r_q[R], shift_c[R,2], r_c[R]).  batch_len None = VAEflex (no per-minibatch cut)."""
+    dev, R, N = q.device, q.shape[0], q.shape[-1]
+    amp = _f32(amp_levels, dev).reshape(-1)
+    n = amp.numel()
+    var = _f32(var, dev).expand(R, 2).contiguous()
+    nu = _f32(nu_sc, dev).expand(R).contiguous()
+    q, y = q.contiguous(), y.contiguous()
+    data = data.to(torch.float16).contiguous()
+    ser = torch.empty(R, 4, dtype=torch.float32, device=dev)
+    shift = torch.empty(R, 2, 2, dtype=torch.int32, device=dev)
+    rflag = torch.empty(R, 2, dtype=torch.int32, device=dev)
+    ws = torch.empty(int(nat.lib().vaeq_dp_epilogue_ws_bytes(R, N)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().vaeq_dp_epilogue(R, N, n, int(batch_len or 0), nat.ptr(q), nat.ptr(y), nat.ptr(data, torch.float16),
+                                             nat.ptr(amp), nat.ptr(var), nat.ptr(nu), nat.ptr(ser), nat.ptr(shift, torch.int32),
+                                             nat.ptr(rflag, torch.int32), nat.ptr(ws, torch.uint8), nat.current_stream(dev)),
+                  "vaeq_dp_epilogue")
+    return dict(SER=ser, shift_q=shift[:, 0].long(), r_q=rflag[:, 0].long(), shift_c=shift[:, 1].long(), r_c=rflag[:, 1].long())
