@@ -124,7 +124,9 @@ def main():
 
     from vae_equalizer_amd import sweep
     from vae_equalizer_amd.engine import DPEngine
-    rank, world, local_rank = sweep.init_distributed()
+    rank, world, local_rank = sweep.init_distributed(os.environ.get("VAEQ_DIST_BACKEND"))   # default nccl (= RCCL); gloo only to
+    if os.environ.get("VAEQ_BENCH_SINGLE_DEVICE"):                                          # rehearse N > 1 on a one-GPU box
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     import torch.distributed as dist
@@ -163,14 +165,14 @@ def main():
         ev[k][1].record()
     rows = torch.cat([out["loss"][:, 0, -1:], out["var_est"][:, 0, :, -1]], dim=1)             # per-run result row
     if world > 1:
-        allrows = torch.empty(world * R, rows.shape[1], device=device)
-        dist.all_gather_into_tensor(allrows, rows.contiguous())                                # the sweep's single gather (RCCL)
+        allrows = sweep.gather_rows(rows, world * R, rank, world)                              # the sweep's single gather (RCCL over xGMI)
+        assert allrows.shape[0] == world * R
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([el], device=device, dtype=torch.float64)
+        tt = torch.tensor([el], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 from vae_equalizer_amd import channel as ch, epilogue as epi, shared_funcs as sfun
-from vae_equalizer_amd.engine import DPEngine
+from vae_equalizer_amd.engine import DPEngine, dp_epilogue
 
 dev = "cuda:0"
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
@@ -24,7 +24,7 @@ for it in range(3):
     t1 = sync()
     out = eng.train(rx, 100, 100, 2.5e-3)
     t2 = sync()
-    res = epi.dp_frame_epilogue(out["q"][:, 0], out["y"][:, 0], data, amp, nu, varr, 100)
+    res = dp_epilogue(out["q"][:, 0], out["y"][:, 0], data, amp, nu, varr, 100)
     ser = res["SER"].cpu()
     t3 = sync()
     print(f"R={R} frame {it}: generate {1e3*(t1-t0):8.1f} ms | train {1e3*(t2-t1):8.1f} ms | epilogue {1e3*(t3-t2):8.1f} ms", flush=True)

@@ -21,6 +21,7 @@ namespace vaeq {
 constexpr int EPI_NT = 256, N_SHIFT = 21, HALF_SHIFT = 10, N_CUT = 10, EDGE = 11;
 constexpr int N_COMBO = 2 * N_SHIFT;          // (lag, E-polarisation)
 constexpr int N_CHUNK = EPI_NT / N_COMBO;     // symbol-axis chunks summed by different threads (6)
+constexpr int EPI_TILE = 1024;                // symbols staged in LDS per correlation tile
 
 struct EpiShared {
     float part[N_CHUNK][N_COMBO][4];          // partial correlations [chunk][(lag,b)][(a,c)]
@@ -31,28 +32,48 @@ struct EpiShared {
     int kept;
     float lo[8], hi[8];                       // decision interval of each TX level (shared_funcs.py:234-236)
     float red[64];
+    float4 txs[EPI_TILE];                     // TX tile: (pol0 I, pol0 Q, pol1 I, pol1 Q) per symbol
+    float es[2][EPI_TILE + 2 * HALF_SHIFT];   // equaliser-side tile with a 10-symbol halo on both sides
 };
 
-// correlation of the TX reference with E[b][.] rolled by lag-10 (shared_funcs.py:300-304): thread = (lag, b, chunk)
-__device__ void epi_correlate(const float *__restrict__ E /*[2][N] or strided*/, int64_t estride, const __half *__restrict__ tx, int64_t N,
+// correlation of the TX reference with E[b][.] rolled by lag-10 (shared_funcs.py:300-304): thread = (lag, b, chunk).
+// The symbol axis is walked in tiles staged in LDS (coalesced global reads once per tile; the inner loop reads one
+// 16-byte TX quad as an LDS broadcast and one E sample per 4 FMAs).
+__device__ void epi_correlate(const float *__restrict__ E /*[2][N] or strided*/, int64_t estride, const __half *__restrict__ tx, int64_t N64,
                               EpiShared &sh)
 {
-    const int tid = threadIdx.x;
-    if (tid < N_COMBO * N_CHUNK) {
-        const int chunk = tid / N_COMBO, cb = tid - chunk * N_COMBO, lag = cb >> 1, b = cb & 1;
-        const int64_t n0 = N * chunk / N_CHUNK, n1 = N * (chunk + 1) / N_CHUNK;
-        const float *Eb = E + (int64_t)b * estride;
-        float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;       // [a][c]
-        int64_t m = (n0 - (lag - HALF_SHIFT)) % N;              // roll(E, lag-10)[n] = E[(n - (lag-10)) mod N]
-        if (m < 0) m += N;
-        for (int64_t n = n0; n < n1; n++) {
-            const float e = Eb[m];
-            s00 = fmaf(__half2float(tx[0 * N + n]), e, s00);
-            s01 = fmaf(__half2float(tx[1 * N + n]), e, s01);
-            s10 = fmaf(__half2float(tx[2 * N + n]), e, s10);
-            s11 = fmaf(__half2float(tx[3 * N + n]), e, s11);
-            if (++m == N) m = 0;
+    const int tid = threadIdx.x, N = (int)N64;
+    const bool worker = tid < N_COMBO * N_CHUNK;
+    const int chunk = tid / N_COMBO, cb = tid - chunk * N_COMBO, lag = cb >> 1, b = cb & 1;
+    float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;           // [a][c]
+    for (int t0 = 0; t0 < N; t0 += EPI_TILE) {
+        const int tl = min(EPI_TILE, N - t0);
+        for (int i = tid; i < tl; i += EPI_NT)
+            sh.txs[i] = make_float4(__half2float(tx[0 * (size_t)N + t0 + i]), __half2float(tx[1 * (size_t)N + t0 + i]),
+                                    __half2float(tx[2 * (size_t)N + t0 + i]), __half2float(tx[3 * (size_t)N + t0 + i]));
+        for (int i = tid; i < 2 * (tl + 2 * HALF_SHIFT); i += EPI_NT) {     // E[b][t0 - 10 .. t0 + tl + 10), indices mod N
+            const int bb = i / (tl + 2 * HALF_SHIFT), j = i - bb * (tl + 2 * HALF_SHIFT);
+            int m = t0 + j - HALF_SHIFT;
+            if (m < 0) m += N;
+            if (m >= N) m -= N;
+            sh.es[bb][j] = E[(int64_t)bb * estride + m];
         }
+        __syncthreads();
+        if (worker) {
+            const int j0 = tl * chunk / N_CHUNK, j1 = tl * (chunk + 1) / N_CHUNK;
+            const float *eb = sh.es[b] + 2 * HALF_SHIFT - lag;  // roll(E, lag-10)[n] = E[n - (lag-10)] -> es index j + 20 - lag
+            for (int j = j0; j < j1; j++) {
+                const float e = eb[j];
+                const float4 t = sh.txs[j];
+                s00 = fmaf(t.x, e, s00);
+                s01 = fmaf(t.y, e, s01);
+                s10 = fmaf(t.z, e, s10);
+                s11 = fmaf(t.w, e, s11);
+            }
+        }
+        __syncthreads();
+    }
+    if (worker) {
         sh.part[chunk][cb][0] = s00; sh.part[chunk][cb][1] = s01; sh.part[chunk][cb][2] = s10; sh.part[chunk][cb][3] = s11;
     }
     __syncthreads();
@@ -91,12 +112,12 @@ __device__ void epi_correlate(const float *__restrict__ E /*[2][N] or strided*/,
 }
 
 // symbols that survive the per-minibatch cut (:73-77) and the frame-edge slice (:79)
-__device__ __forceinline__ bool epi_keep(int64_t n, int64_t N, int batch_len, int shift0, int ms)
+__device__ __forceinline__ bool epi_keep(int n, int N, int batch_len, int shift0, int ms)
 {
     if (batch_len <= 0) return n >= EDGE && n < N - EDGE - ms;
     int Lk = batch_len - shift0 - N_CUT;
     Lk = Lk < 0 ? 0 : (Lk > batch_len ? batch_len : Lk);
-    const int64_t mb = n / batch_len, j = n - mb * batch_len, k = mb * Lk + j, K = (N / batch_len) * Lk;
+    const int mb = n / batch_len, j = n - mb * batch_len, k = mb * Lk + j, K = (N / batch_len) * Lk;
     return j < Lk && k >= EDGE && k < K - EDGE - ms;
 }
 
@@ -161,13 +182,13 @@ __global__ __launch_bounds__(EPI_NT) void dp_epilogue_kernel(int64_t N, int batc
         float fac = 1.0f;
         if (path == 1) {                                        // mean radius of TX over mean radius of the aligned output (:242)
             float st = 0.f, sy = 0.f;
-            for (int64_t n = tid; n < N; n += EPI_NT) {
-                if (!epi_keep(n, N, batch_len, s0, ms)) continue;
+            for (int n = tid; n < (int)N; n += EPI_NT) {
+                if (!epi_keep(n, (int)N, batch_len, s0, ms)) continue;
 #pragma unroll
                 for (int p = 0; p < 2; p++) {
                     const int sp = (p - r) & 1;
-                    int64_t m = n + (p ? s1 : s0);
-                    m %= N; if (m < 0) m += N;
+                    int m = n + (p ? s1 : s0);
+                    if (m >= (int)N) m -= (int)N; if (m < 0) m += (int)N;
                     const float ti = __half2float(tx[(size_t)(p * 2 + 0) * N + n]), tq = __half2float(tx[(size_t)(p * 2 + 1) * N + n]);
                     const float yi = yr[(size_t)(sp * 2 + 0) * N + m], yq = yr[(size_t)(sp * 2 + 1) * N + m];
                     st += sqrtf(ti * ti + tq * tq);
@@ -182,14 +203,14 @@ __global__ __launch_bounds__(EPI_NT) void dp_epilogue_kernel(int64_t N, int batc
 #pragma unroll
         for (int i = 0; i < 16; i++) cnt[i] = 0;
         int kept = 0;
-        for (int64_t n = tid; n < N; n += EPI_NT) {
-            if (!epi_keep(n, N, batch_len, s0, ms)) continue;
+        for (int n = tid; n < (int)N; n += EPI_NT) {
+            if (!epi_keep(n, (int)N, batch_len, s0, ms)) continue;
             kept++;
 #pragma unroll
             for (int p = 0; p < 2; p++) {
                 const int sp = (p - r) & 1;                     // roll(r, 0): row p comes from row p - r  (:71)
-                int64_t m = n + (p ? s1 : s0);                  // roll(-shift): out[n] = in[n + shift]     (:72)
-                m %= N; if (m < 0) m += N;
+                int m = n + (p ? s1 : s0);                      // roll(-shift): out[n] = in[n + shift]     (:72)
+                if (m >= (int)N) m -= (int)N; if (m < 0) m += (int)N;
                 const float dI = rintf(scale * __half2float(tx[(size_t)(p * 2 + 0) * N + n]) + scale);       // :198
                 const float dQ = rintf(scale * __half2float(tx[(size_t)(p * 2 + 1) * N + n]) + scale);
                 const float dQi = -(dQ - 2.0f * scale);         // IQ flip (:199)
@@ -246,7 +267,7 @@ extern "C" int vaeq_dp_epilogue(int32_t R, int64_t N, int32_t n_lev, int32_t bat
                                 void *workspace, void *stream)
 {
     if (!q || !y || !tx_f16 || !amp || !var || !nu_sc || !ser || !shift || !rflag || !workspace) return VAEQ_ERR_NULL;
-    if (R < 0 || N < 2 * vaeq::EDGE + vaeq::N_SHIFT || batch_len < 0 || (batch_len > 0 && N % batch_len)) return VAEQ_ERR_SHAPE;
+    if (R < 0 || N < 2 * vaeq::EDGE + vaeq::N_SHIFT || N > 0x3fffffff || batch_len < 0 || (batch_len > 0 && N % batch_len)) return VAEQ_ERR_SHAPE;
     if (R == 0) return VAEQ_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float *wsE = reinterpret_cast<float *>(workspace);
