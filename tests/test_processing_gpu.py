@@ -152,3 +152,14 @@ def test_hip_epilogue_random_batch_vs_oracle(batch_len, n):
         assert np.array_equal(r["shift_q"][i].cpu().numpy(), o["shift_q"]) and int(r["r_q"][i]) == o["r_q"], i
         assert np.array_equal(r["shift_c"][i].cpu().numpy(), o["shift_c"]) and int(r["r_c"][i]) == o["r_c"], i
         assert np.allclose(r["SER"][i].cpu().numpy(), o["SER"], atol=2.5e-3), (i, r["SER"][i], o["SER"])     # <= 2 symbols of ~900 at a threshold
+
+
+def test_awgn_batch_equals_single_runs():
+    """AWGN runs batched in one launch per epoch == the same runs alone (independent workgroups), incl. different SNR / shaping."""
+    from vae_equalizer_amd.func_VAELE_MQAM_shaping import run_awgn_batch
+    runs = [dict(SNR=20 + 2 * i, nu=[0.0, 0.0270955][i % 2], lr_optim=5e-3, seed=300 + i) for i in range(4)]
+    kw = dict(mod="64-QAM", sps=2, M_est=25, batch_len=350, N_valid=3000, N_train=1200, num_epochs=4, epe=2, channel="h1")
+    b = run_awgn_batch(runs, **kw)
+    assert b.shape == (4, 2) and torch.isfinite(b).all()
+    for i in (1, 2):
+        assert torch.equal(run_awgn_batch([runs[i]], **kw)[0], b[i])

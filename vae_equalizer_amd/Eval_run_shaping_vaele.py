@@ -33,7 +33,7 @@ def sweep_points():
 
 def main():
     from . import sweep
-    from .func_VAELE_MQAM_shaping import processing
+    from .func_VAELE_MQAM_shaping import run_awgn_batch
 
     rank, world, local_rank = sweep.init_distributed()
     device = torch.device("cuda", local_rank if world > 1 else torch.cuda.current_device())
@@ -42,10 +42,11 @@ def main():
     points = list(sweep_points())
     mine = sweep.my_slice(len(points), rank, world)
     local = torch.zeros(len(mine), num_epochs // epe, dtype=torch.float32)
-    for k, i in enumerate(mine):
-        p = points[i][1]
-        local[k] = processing(mod, sps, p["SNR"], p["nu"], p["M"], p["lr"], p["N_train"], N_valid, train_len, num_epochs, epe, channel,
-                              seed=None if base_seed is None else base_seed + 1000 * i, device=device, verbose=False)
+    for (M, N_train) in sorted({(points[i][1]["M"], points[i][1]["N_train"]) for i in mine}):      # one batch per problem shape
+        sel = [k for k, i in enumerate(mine) if (points[i][1]["M"], points[i][1]["N_train"]) == (M, N_train)]
+        runs = [dict(SNR=points[mine[k]][1]["SNR"], nu=points[mine[k]][1]["nu"], lr_optim=points[mine[k]][1]["lr"],
+                     seed=None if base_seed is None else base_seed + 1000 * mine[k]) for k in sel]
+        local[sel] = run_awgn_batch(runs, mod, sps, M, N_train, N_valid, train_len, num_epochs, epe, channel, device=device)
     rows = sweep.gather_rows(local, len(points), rank, world)
     if rank != 0:
         return None

@@ -51,6 +51,45 @@ def SER_q(q, tx, sps, num_lev, device=None):
     return torch.stack([((data - d) != 0).any(dim=0).float().mean() for d in (dec, dec_pi, dec_pi4, dec_3pi4)]).min()
 
 
+def run_awgn_batch(runs, mod, sps, M_est, batch_len, N_valid, N_train, num_epochs, epe, channel, device=None, verbose=False):
+    """R AWGN VAE-LE runs at once: ``runs`` = list of dict(SNR, nu, lr_optim, seed).  One training launch per epoch and one
+    validation launch per evaluated epoch for all runs (:291-322).  Returns SER_valid[R, num_epochs // epe] (CPU float32)."""
+    device = default_device() if device is None else torch.device(device)
+    R = len(runs)
+    tabs = [awgn_tables(mod, r["nu"], r["SNR"], channel, sps) for r in runs]
+    t0 = tabs[0]
+    amp = torch.tensor(t0["amps"], dtype=torch.float32, device=device)
+    eng = AWGNEngine(R, M_est, amp, np.stack([t["P"] for t in tabs]), [t["amp_mean"] for t in tabs], [t["var"] for t in tabs],
+                     device, sps)
+    lr = np.array([r["lr_optim"] for r in runs], dtype=np.float32)
+    streams = [ch.SeededStreams(r["seed"]) if r.get("seed") is not None else None for r in runs]
+    SER_valid = torch.empty(R, num_epochs // epe, dtype=torch.float32)
+    steps = N_train // batch_len                                                 # :297 (the remainder is dropped)
+
+    def draw(N):
+        rxs, ds = [], []
+        for t, r, st in zip(tabs, runs, streams):
+            rx, d = ch.generate_data(N, t["M_channel"], t["amps"], r["SNR"], t["h_channel"], sps, "cpu", t["P"],
+                                     rng=st.next_rng() if st else None, noise=st.noise if st else None)
+            rxs.append(rx)
+            ds.append(d)
+        return torch.stack(rxs).to(device), torch.stack(ds).to(device)
+
+    for epoch in range(num_epochs):
+        rx, _ = draw(N_train)
+        out = eng.train(rx, batch_len, steps, lr)
+        if epoch % epe == 0:                                                     # :308-318
+            rxv, datav = draw(N_valid)
+            q, _ = eng.forward(rxv)
+            for i in range(R):
+                sh = int(find_shift(q[i], datav[i], 21, amp, t0["n"]))
+                SER_valid[i, epoch // epe] = SER_q(q[i][:, 11 + sh:-11], datav[i][:, 11:-11 - sh], sps, t0["n"]).cpu()
+                if verbose:
+                    tag = f"[run {i}] " if R > 1 else ""
+                    print(f"{tag}{epoch}", out["loss"][i, -1].item(), sh, '\t\t\t\t\t\tSER = ', SER_valid[i, epoch // epe].item())
+    return SER_valid
+
+
 def processing(mod, sps, SNR, nu, M_est, lr_optim, batch_len, N_valid, N_train, num_epochs, epe, channel, *, seed=None,
                device=None, verbose=True):
     """One AWGN VAE-LE run -> SER_valid[num_epochs//epe] (CPU float32).
@@ -60,24 +99,5 @@ def processing(mod, sps, SNR, nu, M_est, lr_optim, batch_len, N_valid, N_train, 
     device = default_device() if device is None else torch.device(device)
     if verbose:
         print("We are using the following device for learning:", device)
-    t = awgn_tables(mod, nu, SNR, channel, sps)
-    amp = torch.tensor(t["amps"], dtype=torch.float32, device=device)
-    eng = AWGNEngine(1, M_est, amp, t["P"], t["amp_mean"], t["var"], device, sps)
-    st = ch.SeededStreams(seed) if seed is not None else None
-    SER_valid = torch.empty(num_epochs // epe, dtype=torch.float32)
-    steps = N_train // batch_len                                                 # :297 (the remainder is dropped)
-    for epoch in range(num_epochs):
-        rx, _ = ch.generate_data(N_train, t["M_channel"], t["amps"], SNR, t["h_channel"], sps, "cpu", t["P"],
-                                 rng=st.next_rng() if st else None, noise=st.noise if st else None)
-        out = eng.train(rx.unsqueeze(0).to(device), batch_len, steps, lr_optim)
-        if epoch % epe == 0:                                                     # :308-318
-            rxv, datav = ch.generate_data(N_valid, t["M_channel"], t["amps"], SNR, t["h_channel"], sps, "cpu", t["P"],
-                                          rng=st.next_rng() if st else None, noise=st.noise if st else None)
-            q, _ = eng.forward(rxv.unsqueeze(0).to(device))
-            q, datav = q[0], datav.to(device)
-            shift = find_shift(q, datav, 21, amp, t["n"])
-            sh = int(shift)
-            SER_valid[epoch // epe] = SER_q(q[:, 11 + sh:-11], datav[:, 11:-11 - sh], sps, t["n"]).cpu()
-            if verbose:
-                print(epoch, out["loss"][0, -1].item(), sh, '\t\t\t\t\t\tSER = ', SER_valid[epoch // epe].item())
-    return SER_valid
+    return run_awgn_batch([dict(SNR=SNR, nu=nu, lr_optim=lr_optim, seed=seed)], mod, sps, M_est, batch_len, N_valid, N_train,
+                          num_epochs, epe, channel, device=device, verbose=verbose)[0]
