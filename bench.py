@@ -41,19 +41,11 @@ def make_frames(n_frames, R, device, seed):
     from vae_equalizer_amd import shared_funcs as sfun
     t = sfun.qam_tables(CFG["mod"], CFG["nu"])
     h_ch = sfun.upsampled_channel(CFG["channel"], CFG["sps"])
-    gen = torch.Generator(device=device)
-    gen.manual_seed(seed)
     frames = []
-    chunk = 480
-    for f in range(n_frames):
-        parts = []
-        for r0 in range(0, R, chunk):
-            r1 = min(R, r0 + chunk)
-            rx, _ = ch.generate_batch_gpu(r1 - r0, CFG["N_frame_max"], t["amps"], t["P"], CFG["SNR"], h_ch, CFG["symb_rate"], CFG["sps"],
-                                          CFG["tau_cd"], CFG["tau_pmd"], CFG["phiIQ"], CFG["theta"] + f * CFG["theta_diff"], device,
-                                          generator=gen)
-            parts.append(rx)
-        frames.append(torch.cat(parts).unsqueeze(1).contiguous())
+    for f in range(n_frames):       # HIP generator kernels + hipFFT (vaeq_gen_dp_*), Philox streams keyed by (seed, frame, run)
+        rx, _ = ch.generate_batch_hip(R, CFG["N_frame_max"], t["amps"], t["P"], CFG["SNR"], h_ch, CFG["symb_rate"], CFG["sps"], CFG["tau_cd"],
+                                      CFG["tau_pmd"], CFG["phiIQ"], CFG["theta"] + f * CFG["theta_diff"], device, seed, f)
+        frames.append(rx.unsqueeze(1))
     return frames, t
 
 
@@ -194,7 +186,7 @@ def main():
         res = {
             "metric": "equalized symbols/s/GPU, DP 64-QAM VAE-LE", "value": value, "unit": "DP-symbols/s (1 DP symbol = 2 polarisation symbols)",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic (on-device DP channel simulator: PCS draw, RRC, CD+PMD+rotation, AWGN)",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (on-device DP channel simulator vaeq_gen_dp_*: Philox PCS draw, RRC, CD+PMD+rotation via hipFFT, AWGN)",
             "per_gpu": value / world,
             "config": {"workload": "SURVEY config 3: optical DP 64-QAM VAE-LE, nu=0, SNR 23 dB, h0, 90 GBd, M_est=25, batch_len=100, "
                                    "N_frame_max=10000 (100 minibatch steps per bench step), lr in {2.5e-3,2e-3,3e-3}; seed axis raised to "

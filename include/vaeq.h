@@ -181,6 +181,25 @@ int vaeq_dp_epilogue(int32_t R, int64_t N, int32_t n_lev, int32_t batch_len, con
                      void *workspace, void *stream);
 int64_t vaeq_dp_epilogue_ws_bytes(int32_t R, int64_t N);
 
+/* ------------------------------------------------------------------------
+ * Seeded on-device DP channel simulator (input producer): optical_DP_channel/shared_funcs.py:65-90 in three stages with
+ * the FFT / inverse FFT over Ls done by the caller (hipFFT through torch.fft) between them.  Counter-based RNG (Philox4x32-10):
+ * every value is a function of (seed, frame, run, stream, index) only.
+ *   vaeq_gen_dp_tx      : PCS draw (cdf[R][n_lev] = cumulative pmf), zero-stuffing, 'valid' FIR with g[Lg] = h_pulse * h_channel
+ *                         (complex, interleaved) -> sig[R][2][Ls] complex64 (interleaved), Ls = sps*(N_conv-1)+1 - Lg + 1;
+ *                         data_f16 (nullable) [R][2][2][N]: TX reference = symbols ref_offset .. ref_offset+N-1 (:89)
+ *   vaeq_gen_dp_disperse: spectrum x H(f) (PMD + rotation theta[r] + IQ phase e_k = exp(-j phiIQ[k])) x CD phase (:38-54), in place;
+ *                         fs = symb_rate * sps
+ *   vaeq_gen_dp_finish  : sigma_n from the mean power (:83), complex AWGN (:84), planar rx[R][2][2][sps*N] (:88); power_ws[R] scratch,
+ *                         sigma_out[R] nullable */
+int vaeq_gen_dp_tx(int32_t R, int32_t N, int32_t N_conv, int32_t sps, int32_t n_lev, int32_t Lg, int32_t Ls, int32_t ref_offset,
+                   const float *amp, const float *cdf, const float *g_complex, uint64_t seed, uint32_t frame, float *sig_complex,
+                   void *data_f16, void *stream);
+int vaeq_gen_dp_disperse(int32_t R, int32_t Ls, double fs, double tau_cd, double tau_pmd, float e0_re, float e0_im, float e1_re,
+                         float e1_im, const float *theta, float *spec_complex, void *stream);
+int vaeq_gen_dp_finish(int32_t R, int32_t N, int32_t sps, int32_t Ls, const float *snr_db, uint64_t seed, uint32_t frame,
+                       const float *sig_complex, float *power_ws, float *rx, float *sigma_out, void *stream);
+
 int vaeq_version(void);
 const char *vaeq_strerror(int code);
 

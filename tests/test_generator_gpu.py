@@ -1,0 +1,91 @@
+"""HIP channel generator (vaeq_gen_dp_*, row f1) against the numpy restatement of the reference's generator chain, fed with the
+same Philox symbol stream (reproduced on the host), plus noise statistics."""
+import numpy as np
+import pytest
+import torch
+
+from vae_equalizer_amd import channel as ch
+from vae_equalizer_amd import shared_funcs as sfun
+
+pytestmark = pytest.mark.gpu
+DP = dict(symb_rate=90e9, tau_cd=-26e-24, tau_pmd=0.1e-12 * np.sqrt(1000), phiIQ=np.array([0.0314, 0.0314], dtype=np.complex64))
+M32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """numpy Philox4x32-10 (Salmon et al.), vectorised over uint64 arrays holding 32-bit words."""
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & M32 for c in np.broadcast_arrays(c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0) & M32, np.uint64(k1) & M32
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+        c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & M32, p1 & M32, ((p0 >> np.uint64(32)) ^ c3 ^ k1) & M32, p0 & M32
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & M32, (k1 + np.uint64(0xBB67AE85)) & M32
+    return c0, c1, c2, c3
+
+
+def host_symbols(seed, frame, run, pol, n_idx, cdf):
+    key = ch._mix_seed(seed, 0)
+    x, y, _, _ = philox4x32_10(n_idx, run, frame, pol, key & 0xFFFFFFFF, key >> 32)
+    u = lambda v: ((v >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    lev = lambda uu: (uu[:, None] >= cdf[None, :-1].astype(np.float32)).sum(1)
+    return lev(u(x)), lev(u(y))
+
+
+@pytest.mark.parametrize("mod,nu,channel", [("64-QAM", 0.0270955, "h0"), ("16-QAM", 0.0, "h1")])
+def test_hip_generator_matches_numpy_chain(mod, nu, channel):
+    sps, N, R, seed, frame = 2, 600, 3, 77, 5
+    h_est, h_ch, P, amp_levels, amps, pol, nu_sc, var, pow_mean = sfun.init(channel, mod, "cpu", nu, sps, 25, 23)
+    theta = np.array([0.3, 0.9, -0.4])
+    SNR = np.array([23.0, 18.0, 30.0], np.float32)
+    rx, data, sigma = ch.generate_batch_hip(R, N, amps, P, SNR, h_ch, DP["symb_rate"], sps, DP["tau_cd"], DP["tau_pmd"], DP["phiIQ"], theta,
+                                            "cuda:0", seed, frame, return_sigma=True)
+    rx2, data2 = ch.generate_batch_hip(R, N, amps, P, SNR, h_ch, DP["symb_rate"], sps, DP["tau_cd"], DP["tau_pmd"], DP["phiIQ"], theta,
+                                       "cuda:0", seed, frame)
+    assert torch.equal(rx, rx2) and torch.equal(data, data2)                    # deterministic in (seed, frame, run)
+    geo = ch.dp_frame_geometry(N, h_ch, sps)
+    cdf = np.cumsum(P)
+    amps32 = np.asarray(amps, np.float32)
+    for r in range(R):
+        lev = np.stack([np.stack(host_symbols(seed, frame, r, p, np.arange(geo["N_conv"]), cdf)) for p in range(2)])   # [pol][I/Q][n]
+        sym = amps32[lev]
+        lo = geo["ref_offset"]
+        assert np.array_equal(data[r].cpu().numpy(), sym[:, :, lo:lo + N].astype(np.float16))       # TX reference (:89)
+        tx_up = np.zeros((2, sps * (geo["N_conv"] - 1) + 1), np.complex64)
+        tx_up[:, ::sps] = sym[:, 0] + 1j * sym[:, 1]
+        clean = ch.simulate_dispersion(ch.simulate_channel(tx_up, ch.rrcfir(8, sps, 0.1), h_ch), DP["symb_rate"], sps, DP["tau_cd"],
+                                       DP["tau_pmd"], DP["phiIQ"], theta[r])                         # (:80-81)
+        sig_n = np.sqrt(np.mean(np.abs(clean) ** 2) * sps / 2 / 10 ** (SNR[r] / 10))                 # (:83)
+        assert abs(float(sigma[r]) - sig_n) / sig_n < 1e-4
+        got = rx[r].cpu().numpy()
+        noise = np.stack([got[:, 0] - clean[:, :sps * N].real, got[:, 1] - clean[:, :sps * N].imag], 1)   # [pol][I/Q][s]
+        assert abs(noise.std() / sig_n - 1) < 0.05 and abs(noise.mean()) < 4 * sig_n / np.sqrt(noise.size)
+        assert abs(np.corrcoef(noise[:, 0].ravel(), noise[:, 1].ravel())[0, 1]) < 0.08
+        assert np.abs(noise).max() < 6 * sig_n                                                        # the clean part matches to << sigma
+    # different frames / seeds give different data
+    rx3, _ = ch.generate_batch_hip(R, N, amps, P, SNR, h_ch, DP["symb_rate"], sps, DP["tau_cd"], DP["tau_pmd"], DP["phiIQ"], theta, "cuda:0", seed, frame + 1)
+    assert not torch.equal(rx, rx3)
+
+
+def test_hip_generator_clean_signal_accuracy():
+    """With SNR = 200 dB the noise vanishes: rx == numpy chain to c64-FFT accuracy."""
+    sps, N, seed, frame = 2, 512, 3, 0
+    h_est, h_ch, P, amp_levels, amps, pol, nu_sc, var, pow_mean = sfun.init("h1", "64-QAM", "cpu", 0.0872449, sps, 25, 23)
+    rx, data = ch.generate_batch_hip(1, N, amps, P, 200.0, h_ch, DP["symb_rate"], sps, DP["tau_cd"], DP["tau_pmd"], DP["phiIQ"], 0.7, "cuda:0", seed, frame)
+    geo = ch.dp_frame_geometry(N, h_ch, sps)
+    lev = np.stack([np.stack(host_symbols(seed, frame, 0, p, np.arange(geo["N_conv"]), np.cumsum(P))) for p in range(2)])
+    sym = np.asarray(amps, np.float32)[lev]
+    tx_up = np.zeros((2, sps * (geo["N_conv"] - 1) + 1), np.complex64)
+    tx_up[:, ::sps] = sym[:, 0] + 1j * sym[:, 1]
+    clean = ch.simulate_dispersion(ch.simulate_channel(tx_up, ch.rrcfir(8, sps, 0.1), h_ch), DP["symb_rate"], sps, DP["tau_cd"], DP["tau_pmd"],
+                                   DP["phiIQ"], 0.7)
+    got = rx[0].cpu().numpy()
+    ref = np.stack([clean[:, :sps * N].real, clean[:, :sps * N].imag], 1)
+    assert np.max(np.abs(got - ref)) < 2e-5 * np.max(np.abs(ref)) + 1e-5
+
+
+def test_generated_frames_train():
+    """End to end: frames from the HIP generator make the equalizer converge (loss falls, Var_est falls)."""
+    from vae_equalizer_amd.dp_runs import DPRun, run_dp_batch
+    runs = [DPRun(23, 0.0, 0.0, 0.3, 2.5e-3, 90e9, seed=9) for _ in range(4)]
+    r = run_dp_batch(runs, "64-QAM", 2, 25, 100, 2000, 4, 10, "h0", -26e-24, DP["tau_pmd"], DP["phiIQ"], 170, generator="hip")
+    assert torch.isfinite(r["SER"]).all() and (r["Var_est"][:, :, -1] < r["Var_est"][:, :, 0]).all()

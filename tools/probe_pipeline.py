@@ -19,8 +19,7 @@ gen = torch.Generator(device=dev).manual_seed(0)
 def sync(): torch.cuda.synchronize(); return time.perf_counter()
 for it in range(3):
     t0 = sync()
-    parts = [ch.generate_batch_gpu(min(512, R - r0), 10000, t["amps"], t["P"], 23.0, h_ch, 90e9, 2, C["tau_cd"], C["tau_pmd"], C["phiIQ"], 0.3, dev, generator=gen) for r0 in range(0, R, 512)]
-    rx = torch.cat([p[0] for p in parts]); data = torch.cat([p[1] for p in parts])
+    rx, data = ch.generate_batch_hip(R, 10000, t["amps"], t["P"], 23.0, h_ch, 90e9, 2, C["tau_cd"], C["tau_pmd"], C["phiIQ"], 0.3, dev, 1, it)
     t1 = sync()
     out = eng.train(rx, 100, 100, 2.5e-3)
     t2 = sync()

@@ -13,7 +13,7 @@ import torch
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("VAEQ_LIB") or os.path.join(_PKG, "libvaeq_hip.so")   # VAEQ_LIB: A/B builds of the kernels (tools/build_variant.sh)
-SOURCES = ["vaeq_dp.hip", "vaeq_dp_wave.hip", "vaeq_awgn.hip", "vaeq_misc.hip", "vaeq_epilogue.hip"]
+SOURCES = ["vaeq_dp.hip", "vaeq_dp_wave.hip", "vaeq_awgn.hip", "vaeq_misc.hip", "vaeq_epilogue.hip", "vaeq_gen.hip"]
 HEADERS = ["vaeq_common.h"]
 _LIB = None
 
@@ -71,7 +71,7 @@ class AWGNArgs(C.Structure):
 
 
 # every symbol include/vaeq.h declares; tests check the library exports all of them
-EXPORTS = ["vaeq_dp_train", "vaeq_dp_lds_bytes", "vaeq_dp_resident_runs", "vaeq_soft_demap", "vaeq_dp_forward", "vaeq_dp_loss", "vaeq_dp_epilogue", "vaeq_dp_epilogue_ws_bytes", "vaeq_awgn_train",
+EXPORTS = ["vaeq_dp_train", "vaeq_dp_lds_bytes", "vaeq_dp_resident_runs", "vaeq_soft_demap", "vaeq_dp_forward", "vaeq_dp_loss", "vaeq_dp_epilogue", "vaeq_dp_epilogue_ws_bytes", "vaeq_gen_dp_tx", "vaeq_gen_dp_disperse", "vaeq_gen_dp_finish", "vaeq_awgn_train",
            "vaeq_awgn_lds_bytes", "vaeq_awgn_forward", "vaeq_version", "vaeq_strerror"]
 
 
@@ -102,6 +102,12 @@ def lib():
         L.vaeq_dp_epilogue.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 11
         L.vaeq_dp_epilogue_ws_bytes.restype = C.c_int64
         L.vaeq_dp_epilogue_ws_bytes.argtypes = [C.c_int32, C.c_int64]
+        L.vaeq_gen_dp_tx.restype = C.c_int
+        L.vaeq_gen_dp_tx.argtypes = [C.c_int32] * 8 + [C.c_void_p] * 3 + [C.c_uint64, C.c_uint32] + [C.c_void_p] * 3
+        L.vaeq_gen_dp_disperse.restype = C.c_int
+        L.vaeq_gen_dp_disperse.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double] + [C.c_float] * 4 + [C.c_void_p] * 3
+        L.vaeq_gen_dp_finish.restype = C.c_int
+        L.vaeq_gen_dp_finish.argtypes = [C.c_int32] * 4 + [C.c_void_p, C.c_uint64, C.c_uint32] + [C.c_void_p] * 5
         if hasattr(L, "vaeq_awgn_train"):
             L.vaeq_awgn_train.restype = C.c_int
             L.vaeq_awgn_train.argtypes = [C.POINTER(AWGNArgs), C.c_void_p]

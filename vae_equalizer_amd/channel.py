@@ -192,3 +192,67 @@ def generate_batch_gpu(R, N, amps, P, SNR, h_channel, symb_rate, sps, tau_cd, ta
     lo = T + Mc - 1
     ref = torch.stack([data[:, 0::2, lo:lo + N], data[:, 1::2, lo:lo + N]], dim=2).to(torch.float16).contiguous()
     return rx.to(torch.float32), ref
+
+
+# ------------------------------------------------------------------ HIP generator (vaeq_gen_dp_*): row f1
+def dp_frame_geometry(N, h_channel, sps):
+    """Lengths of the reference's generator chain (shared_funcs.py:66-73, 56-58, 89) and the combined 'valid' FIR g = pulse * IR."""
+    T = PULSE_SPAN
+    hp = rrcfir(T, sps, ROLL_OFF)
+    hc = np.asarray(h_channel).astype(np.complex64)
+    g = np.convolve(hp.astype(np.complex128), hc.astype(np.complex128)).astype(np.complex64)
+    Lc, Lg = len(hc), len(hp) + len(hc) - 1
+    N_conv = N + Lc + 4 * T
+    Ls = sps * (N_conv - 1) + 1 - Lg + 1
+    return dict(g=g, Lg=Lg, N_conv=N_conv, Ls=Ls, ref_offset=T + Lc - 1)
+
+
+def generate_batch_hip(R, N, amps, P, SNR, h_channel, symb_rate, sps, tau_cd, tau_pmd, phiIQ, theta, device, seed, frame, chunk=2048,
+                       return_sigma=False):
+    """The DP channel model for R runs on the device with the HIP generator kernels + hipFFT (torch.fft) between the stages.
+
+    Deterministic in (seed, frame, run): counter-based Philox streams.  Returns (rx[R,2,2,sps*N] f32, data[R,2,2,N] f16[, sigma_n[R]])."""
+    import ctypes as C
+
+    from . import _native as nat
+    dev = torch.device(device)
+    geo = dp_frame_geometry(N, h_channel, sps)
+    n = len(amps)
+    amp_t = torch.as_tensor(np.asarray(amps), dtype=torch.float32, device=dev).contiguous()
+    Pn = np.asarray(P, dtype=np.float64)
+    Pn = np.tile(Pn, (R, 1)) if Pn.ndim == 1 else Pn
+    cdf = torch.as_tensor(np.cumsum(Pn, axis=1), dtype=torch.float32, device=dev).contiguous()
+    g_t = torch.view_as_real(torch.as_tensor(geo["g"], device=dev)).contiguous()
+    snr = torch.as_tensor(SNR, dtype=torch.float32, device=dev).expand(R).contiguous()
+    th = torch.as_tensor(theta, dtype=torch.float32, device=dev).expand(R).contiguous()
+    e = np.exp(-1j * np.asarray(phiIQ, dtype=np.complex128))
+    rx = torch.empty(R, 2, 2, sps * N, dtype=torch.float32, device=dev)
+    data = torch.empty(R, 2, 2, N, dtype=torch.float16, device=dev)
+    sigma = torch.empty(R, dtype=torch.float32, device=dev)
+    L = nat.lib()
+    st = nat.current_stream(dev)
+    with torch.cuda.device(dev):
+        for r0 in range(0, R, chunk):
+            r1 = min(R, r0 + chunk)
+            Rc = r1 - r0
+            sig = torch.empty(Rc, 2, geo["Ls"], dtype=torch.complex64, device=dev)
+            # the run index seen by the kernels is r0 + local run: fold r0 into the frame word would break determinism, so the
+            # kernels get run-offset pointers and a seed that already encodes the chunk start
+            nat.check(L.vaeq_gen_dp_tx(Rc, N, geo["N_conv"], sps, n, geo["Lg"], geo["Ls"], geo["ref_offset"], nat.ptr(amp_t),
+                                       nat.ptr(cdf[r0:r1].contiguous()), nat.ptr(g_t), C.c_uint64(_mix_seed(seed, r0)), C.c_uint32(frame),
+                                       C.c_void_p(sig.data_ptr()), nat.ptr(data[r0:r1], torch.float16), st), "vaeq_gen_dp_tx")
+            spec = torch.fft.fft(sig, dim=-1)
+            nat.check(L.vaeq_gen_dp_disperse(Rc, geo["Ls"], float(symb_rate) * sps, float(tau_cd), float(tau_pmd), float(e[0].real),
+                                             float(e[0].imag), float(e[1].real), float(e[1].imag), nat.ptr(th[r0:r1].contiguous()),
+                                             C.c_void_p(spec.data_ptr()), st), "vaeq_gen_dp_disperse")
+            sig = torch.fft.ifft(spec, dim=-1)
+            pw = torch.empty(Rc, dtype=torch.float32, device=dev)
+            nat.check(L.vaeq_gen_dp_finish(Rc, N, sps, geo["Ls"], nat.ptr(snr[r0:r1].contiguous()), C.c_uint64(_mix_seed(seed, r0)),
+                                           C.c_uint32(frame), C.c_void_p(sig.data_ptr()), nat.ptr(pw), nat.ptr(rx[r0:r1]),
+                                           nat.ptr(sigma[r0:r1]), st), "vaeq_gen_dp_finish")
+    return (rx, data, sigma) if return_sigma else (rx, data)
+
+
+def _mix_seed(seed, r0):
+    """Key of the Philox streams of the chunk that starts at run r0 (runs inside a chunk are told apart by the run counter word)."""
+    return (int(seed) * 0x9E3779B97F4A7C15 + int(r0) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF

@@ -40,6 +40,7 @@ def run_dp_batch(runs, mod, sps, M_est, batch_len, N_frame_max, num_frames, flex
     """Train + evaluate R runs.  Returns dict(SER[R,4,num_frames], Var_est[R,2,num_frames], var[R,2]) on the CPU.
 
     generator: "numpy" = reference-faithful host simulator per run (seeded per run when DPRun.seed is set);
+               "hip"   = on-device simulator, HIP kernels + hipFFT, Philox streams keyed by the first run's seed (row f1);
                "torch" = batched on-device simulator (channel.generate_batch_gpu), seeded from the first run's seed.
     """
     device = default_device() if device is None else torch.device(device)
@@ -82,7 +83,14 @@ def run_dp_batch(runs, mod, sps, M_est, batch_len, N_frame_max, num_frames, flex
         # lr schedule: group 0 (W) only, set (not multiplied) to lr/2 (func_VAELE_DP_MQAM_shaping.py:45-46)
         # -> lr from frame 0, lr/2 from frame N_lrhalf on (every later trigger re-sets the same value)
         cur_lr_W = lr0 * 0.5 if frame >= N_lrhalf else lr0
-        if generator == "torch":
+        if generator == "hip":                                                  # HIP generator kernels + hipFFT (row f1)
+            SNRs = np.array([r.SNR for r in runs], dtype=np.float32)
+            gseed = int(runs[0].seed) if runs[0].seed is not None else int(np.random.SeedSequence().entropy & 0xFFFFFFFF)
+            if frame == 0:
+                hip_seed = gseed
+            rx, data = ch.generate_batch_hip(R, N_frame, amps, P, SNRs, h_channel, runs[0].symb_rate, sps, tau_cd, tau_pmd, phiIQ,
+                                             theta, device, hip_seed, frame)
+        elif generator == "torch":
             SNRs = np.array([r.SNR for r in runs], dtype=np.float32)
             srate = runs[0].symb_rate
             rx, data = ch.generate_batch_gpu(R, N_frame, amps, P, SNRs, h_channel, srate, sps, tau_cd, tau_pmd, phiIQ, theta,
