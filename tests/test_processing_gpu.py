@@ -163,3 +163,24 @@ def test_awgn_batch_equals_single_runs():
     assert b.shape == (4, 2) and torch.isfinite(b).all()
     for i in (1, 2):
         assert torch.equal(run_awgn_batch([runs[i]], **kw)[0], b[i])
+
+
+def test_full_config3_run_vs_reference_statistics():
+    """SURVEY config 3 at full size (170 frames x 10 000 symbols = 17 000 Adam steps, Eval_run_DP.py defaults, lr 2.5e-3) with the
+    frames the reference saw under seed 1234 (tools/capture_golden.py --full-run: 604 s on the CPU there): SER curve and noise
+    estimate agree within Monte-Carlo error."""
+    from vae_equalizer_amd.func_VAELE_DP_MQAM_shaping import processing
+    g = load_golden("G7_full_runs")
+    SER, Var_est, var = processing("64-QAM", 2, 23, 0.0, 25, 0.06 * np.pi, np.pi / 10, 2.5e-3, 100, 10000, 170, 10, "h0", 90e9, -26e-24,
+                                   TAU_PMD, PHI, 170, seed=1234, verbose=False)
+    ref, ours = g["full_SER"], SER.numpy()
+    assert np.allclose(var.numpy(), g["full_var"])
+    conv = lambda s: int(np.argmax((s < 0.1).all(0)))
+    assert abs(conv(ours) - conv(ref)) <= 4, (conv(ours), conv(ref))                     # reference: frame 16
+    # same noise realisations on both sides -> the converged SERs agree far inside the per-frame MC sigma (1.8e-3)
+    assert np.all(np.abs(ours[:, -30:].mean(1) - ref[:, -30:].mean(1)) < 1.5e-3), (ours[:, -30:].mean(1), ref[:, -30:].mean(1))
+    assert np.max(np.abs(ours[:, 40:] - ref[:, 40:])) < 0.012
+    ve_o, ve_r = Var_est.numpy()[:, -30:].mean(1), g["full_Var_est"][:, -30:].mean(1)
+    assert np.max(np.abs(ve_o - ve_r) / ve_r) < 0.01, (ve_o, ve_r)
+    snr_est = 10 * np.log10(1.0 / ve_o.mean())                                          # pow_mean (= 1 at nu = 0) / Var_est (func_VAELE_DP...:68)
+    assert abs(snr_est - 21.97) < 0.15                                                  # the survey's measured reference value
