@@ -26,6 +26,16 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_library():
+    """The HIP library normally travels with the tree (built by __graft_entry__.build()); on a checkout without it, build it
+    once (hipcc is part of the image).  Nothing here falls back to a CPU path: if the build fails the GPU tests fail."""
+    from vae_equalizer_amd import _native as nat
+    if not os.path.exists(nat.LIB_PATH):
+        nat.build(verbose=True)
+    yield
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     return {k: z[k] for k in z.files}

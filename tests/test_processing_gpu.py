@@ -184,3 +184,21 @@ def test_full_config3_run_vs_reference_statistics():
     assert np.max(np.abs(ve_o - ve_r) / ve_r) < 0.01, (ve_o, ve_r)
     snr_est = 10 * np.log10(1.0 / ve_o.mean())                                          # pow_mean (= 1 at nu = 0) / Var_est (func_VAELE_DP...:68)
     assert abs(snr_est - 21.97) < 0.15                                                  # the survey's measured reference value
+
+
+def test_awgn_config2_run_vs_reference_statistics():
+    """SURVEY config 2 (AWGN 64-QAM + PCS nu=0.0270955, h1, SNR 24 dB, 25 taps, 500 epochs x 3 minibatches of 350, validation on
+    15 000 symbols every 2nd epoch) with the frames the reference saw under seed 73: SER curve within Monte-Carlo error."""
+    from vae_equalizer_amd.func_VAELE_MQAM_shaping import processing
+    g = load_golden("G7_awgn_cfg2")
+    SER = processing("64-QAM", 2, 24, 0.0270955, 25, 5e-3, 350, 15000, 1200, 500, 2, "h1", seed=int(g["seed"]), verbose=False).numpy()
+    ref = g["SER"]
+    assert SER.shape == ref.shape == (250,)
+    assert abs(SER[0] - ref[0]) < 0.01                                        # first validation: 3 steps in
+    # When the blind equalizer locks is chaotic: on these very frames the CPU oracle locks at validation 47-53 in fp32 and at
+    # 57 / 132 / 143 in fp64 depending on the sign of the noise-driven first step of the scale tap (reference: 56).  What is
+    # pinned is that it locks inside that band and where it ends up.
+    conv = lambda s: int(np.argmax(s < 0.01))
+    assert 30 <= conv(SER) <= 200, conv(SER)
+    assert abs(SER[-50:].mean() - ref[-50:].mean()) < 3e-4, (SER[-50:].mean(), ref[-50:].mean())   # ~1.1e-3 both
+    assert np.max(np.abs(SER[-40:] - ref[-40:])) < 1.5e-3

@@ -63,25 +63,19 @@ __device__ __forceinline__ void wave_lds_sync() { asm volatile("" ::: "memory");
 
 typedef float v2f __attribute__((ext_vector_type(2)));   // element-wise ops compile to v_pk_{add,mul,fma}_f32
 
-// Complex MACs written on 2-vectors so that each is exactly two v_pk_fma_f32 (broadcast / swap / negate ride on the
-// op_sel and neg modifiers; with scalar fmaf chains hipcc's SLP vectoriser pairs unrelated accumulators and pays a
-// v_mov per operand to line them up).
-__device__ __forceinline__ void cmac(float2 &acc, float wr, float wi, float2 x)       // acc += (wr + j wi) * x
+// Complex MACs.  A complex accumulator is kept as TWO packed partial sums,  a = sum re(t) * v  and  b = sum im(t) * v  (t = tap,
+// v = sample), so that every MAC is exactly two v_pk_fma_f32 whose scalar factor rides on op_sel: no swap, no negation, no
+// v_mov in the inner loops.  The two are combined once at the end:  t * v = (a.x - b.y, a.y + b.x),  v * conj(t) = (a.x + b.y, a.y - b.x).
+struct cacc { v2f a, b; };
+__device__ __forceinline__ cacc cacc0() { return cacc{v2f{0.f, 0.f}, v2f{0.f, 0.f}}; }
+__device__ __forceinline__ void cmac(cacc &c, float tr, float ti, float2 v)           // c += (tr, ti) (x) v
 {
-    v2f a = {acc.x, acc.y};
-    a += v2f{wr, wr} * v2f{x.x, x.y};
-    a += v2f{wi, wi} * v2f{-x.y, x.x};
-    acc.x = a.x;
-    acc.y = a.y;
+    const v2f vv = {v.x, v.y};
+    c.a += tr * vv;
+    c.b += ti * vv;
 }
-__device__ __forceinline__ void cmacc(float2 &acc, float2 a_, float br, float bi)     // acc += a * conj(br + j bi)
-{
-    v2f a = {acc.x, acc.y};
-    a += v2f{br, br} * v2f{a_.x, a_.y};
-    a += v2f{bi, bi} * v2f{a_.y, -a_.x};
-    acc.x = a.x;
-    acc.y = a.y;
-}
+__device__ __forceinline__ float2 cfin(const cacc &c) { return make_float2(c.a.x - c.b.y, c.a.y + c.b.x); }    // sum t * v
+__device__ __forceinline__ float2 cfinc(const cacc &c) { return make_float2(c.a.x + c.b.y, c.a.y - c.b.x); }   // sum v * conj(t)
 
 __device__ __forceinline__ float wave_incl_scan(float v, int lane)                    // inclusive prefix sum over lanes
 {
@@ -98,7 +92,7 @@ __device__ __forceinline__ float wave_incl_scan(float v, int lane)              
 //   FIR : T = float4 tap quads (o0.re, o0.im, o1.re, o1.im), acc[sym][o]  += w * x
 //   DU  : two float2 tap arrays (nu = 0, 1),                   acc[sym][nu] += e * conj(h)
 template <int M, bool CONJ>
-__device__ __forceinline__ void pair_fir(float2 (&acc)[2][2], const float2 *xp, int Lph, const float4 *wq, const float2 *ha,
+__device__ __forceinline__ void pair_fir(cacc (&acc)[2][2], const float2 *xp, int Lph, const float4 *wq, const float2 *ha,
                                          const float2 *hb)
 {
     auto tap = [&](int k, float &ar, float &ai, float &br, float &bi) {
@@ -111,8 +105,8 @@ __device__ __forceinline__ void pair_fir(float2 (&acc)[2][2], const float2 *xp, 
         }
     };
     auto mac = [&](int sy, float2 x, float ar, float ai, float br, float bi) {
-        if (CONJ) { cmacc(acc[sy][0], x, ar, ai); cmacc(acc[sy][1], x, br, bi); }
-        else { cmac(acc[sy][0], ar, ai, x); cmac(acc[sy][1], br, bi, x); }
+        cmac(acc[sy][0], ar, ai, x);                   // FIR: w * x;  dL/dU: e * conj(h) -- same accumulation, different final combine
+        cmac(acc[sy][1], br, bi, x);
     };
     constexpr int G = M / 4;
 #pragma unroll 1
@@ -235,10 +229,17 @@ __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
 
             // ============ P1: FIR for the lane's symbol pair, both output polarisations
             float2 y[2][2];                                    // [sym][o]
-            y[0][0] = y[0][1] = y[1][0] = y[1][1] = make_float2(0.f, 0.f);
-            if (act) {
-                pair_fir<M, false>(y, Xl, Lph, Wt, nullptr, nullptr);
-                pair_fir<M, false>(y, Xl + 4 * Lph, Lph, Wt + M, nullptr, nullptr);
+            {
+                cacc ya[2][2];
+                ya[0][0] = ya[0][1] = ya[1][0] = ya[1][1] = cacc0();
+                if (act) {
+                    pair_fir<M, false>(ya, Xl, Lph, Wt, nullptr, nullptr);
+                    pair_fir<M, false>(ya, Xl + 4 * Lph, Lph, Wt + M, nullptr, nullptr);
+                }
+#pragma unroll
+                for (int sy = 0; sy < 2; sy++)
+#pragma unroll
+                    for (int o = 0; o < 2; o++) y[sy][o] = cfin(ya[sy][o]);
             }
             // pin: hipcc otherwise sinks whole FMA chains to their (much later) use and keeps their inputs alive instead
             asm volatile("" : "+v"(y[0][0].x), "+v"(y[0][0].y), "+v"(y[0][1].x), "+v"(y[0][1].y), "+v"(y[1][0].x), "+v"(y[1][0].y),
@@ -359,11 +360,11 @@ __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
             //   D[chi, 2 tau + par] = sum_nu sum_a h[chi,nu,2a+par] U[nu, tau + mh - a],   tau in {2l', 2l'+1}, a = 0..mh
             float se0 = 0.f, se1 = 0.f;
             if (lane < nq) {
-                float2 D[2][4];                                // [chi][i], i = 2*dl + par
+                cacc D[2][4];                                  // [chi][i], i = 2*dl + par
 #pragma unroll
                 for (int chi = 0; chi < 2; chi++)
 #pragma unroll
-                    for (int i = 0; i < 4; i++) D[chi][i] = make_float2(0.f, 0.f);
+                    for (int i = 0; i < 4; i++) D[chi][i] = cacc0();
 #pragma unroll
                 for (int v = 0; v < 2; v++) {
                     const float2 *h0 = Ht + (0 * 2 + v) * MP, *h1 = Ht + (1 * 2 + v) * MP;
@@ -396,7 +397,8 @@ __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
                     for (int i = 0; i < 4; i++) {
                         const int ce = Mh + i;                 // + 4*lane: same (phase, slot) arithmetic as x
                         const float2 x = Xl[(chi * 4 + (ce & 3)) * Lph + (ce >> 2)];
-                        float2 e = make_float2(x.x - D[chi][i].x, x.y - D[chi][i].y);
+                        const float2 Dv = cfin(D[chi][i]);
+                        float2 e = make_float2(x.x - Dv.x, x.y - Dv.y);
                         if (4 * lane + i >= nm) e = make_float2(0.f, 0.f);
                         Es[(chi * 4 + (ce & 3)) * Lph + lane + (ce >> 2)] = e;
                         const float e2 = e.x * e.x + e.y * e.y;
@@ -449,8 +451,8 @@ __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
             hnew[0] = hnew[1] = make_float2(0.f, 0.f);
             float ghr[2] = {0, 0}, ghi[2] = {0, 0};
             {
-                float2 acc[2][2];
-                acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = make_float2(0.f, 0.f);
+                cacc ca[2][2];
+                ca[0][0] = ca[0][1] = ca[1][0] = ca[1][1] = cacc0();
                 if (owner) {
                     // sum over tau of e[chi, 2 tau + par] conj(U[nu, tau + mh - a]); tau runs in pairs (2m, 2m+1) so that the
                     // polyphase component of every operand is a per-lane constant and only the slot advances (by one per m).
@@ -465,16 +467,21 @@ __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
                     for (int m = ma; m < mb; m++) {
                         const float2 e0 = eA[m], e1 = eA[4 * Lph + m], u0 = uA[m], u1 = uA[2 * Uph + m];
                         const float2 f0 = eB[m], f1 = eB[4 * Lph + m], w0 = uB[m], w1 = uB[2 * Uph + m];
-                        cmacc(acc[0][0], e0, u0.x, u0.y);
-                        cmacc(acc[0][1], e0, u1.x, u1.y);
-                        cmacc(acc[1][0], e1, u0.x, u0.y);
-                        cmacc(acc[1][1], e1, u1.x, u1.y);
-                        cmacc(acc[0][0], f0, w0.x, w0.y);
-                        cmacc(acc[0][1], f0, w1.x, w1.y);
-                        cmacc(acc[1][0], f1, w0.x, w0.y);
-                        cmacc(acc[1][1], f1, w1.x, w1.y);
+                        cmac(ca[0][0], u0.x, u0.y, e0);
+                        cmac(ca[0][1], u1.x, u1.y, e0);
+                        cmac(ca[1][0], u0.x, u0.y, e1);
+                        cmac(ca[1][1], u1.x, u1.y, e1);
+                        cmac(ca[0][0], w0.x, w0.y, f0);
+                        cmac(ca[0][1], w1.x, w1.y, f0);
+                        cmac(ca[1][0], w0.x, w0.y, f1);
+                        cmac(ca[1][1], w1.x, w1.y, f1);
                     }
                 }
+                float2 acc[2][2];
+#pragma unroll
+                for (int chi = 0; chi < 2; chi++)
+#pragma unroll
+                    for (int v = 0; v < 2; v++) acc[chi][v] = cfinc(ca[chi][v]);             // e * conj(U)
                 // combine the two halves; lane (j, half) keeps chi = half
 #pragma unroll
                 for (int chi = 0; chi < 2; chi++)
@@ -513,11 +520,18 @@ __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
             float2 gy[2][2];                                   // [sym][nu]
             {
                 float2 au0[2][2], au1[2][2];                   // chi = 0 / 1: [sym][nu]
-                au0[0][0] = au0[0][1] = au0[1][0] = au0[1][1] = make_float2(0.f, 0.f);
-                au1[0][0] = au1[0][1] = au1[1][0] = au1[1][1] = make_float2(0.f, 0.f);
-                if (act) {
-                    pair_fir<M, true>(au0, El, Lph, nullptr, Ht + 0 * MP, Ht + 1 * MP);
-                    pair_fir<M, true>(au1, El + 4 * Lph, Lph, nullptr, Ht + 2 * MP, Ht + 3 * MP);
+                {
+                    cacc c0[2][2], c1[2][2];
+                    c0[0][0] = c0[0][1] = c0[1][0] = c0[1][1] = cacc0();
+                    c1[0][0] = c1[0][1] = c1[1][0] = c1[1][1] = cacc0();
+                    if (act) {
+                        pair_fir<M, true>(c0, El, Lph, nullptr, Ht + 0 * MP, Ht + 1 * MP);
+                        pair_fir<M, true>(c1, El + 4 * Lph, Lph, nullptr, Ht + 2 * MP, Ht + 3 * MP);
+                    }
+#pragma unroll
+                    for (int sy = 0; sy < 2; sy++)
+#pragma unroll
+                        for (int v = 0; v < 2; v++) { au0[sy][v] = cfinc(c0[sy][v]); au1[sy][v] = cfinc(c1[sy][v]); }   // e * conj(h)
                 }
 #pragma unroll
                 for (int sy = 0; sy < 2; sy++) {
@@ -551,8 +565,8 @@ __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
             // ============ P5: dL/dw partial sums, lane = (k = tk, half of the symbol range); acc[o][p]
             float gwr[2] = {0, 0}, gwi[2] = {0, 0};
             {
-                float2 acc[2][2];
-                acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = make_float2(0.f, 0.f);
+                cacc ca[2][2];
+                ca[0][0] = ca[0][1] = ca[1][0] = ca[1][1] = cacc0();
                 if (owner) {
                     // sum over n of gy[o, n] conj(x[p, 2n + k]); n runs in pairs (2m, 2m+1): x phase fixed per lane, gy pair = 16 bytes
                     const int Bq = ((B + 3) >> 2) << 1;                                  // even split point (B is even)
@@ -564,16 +578,21 @@ __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
                     for (int m = ma; m < mb; m++) {
                         const float4 ga = G0[m], gb = G1[m];                             // (gy[o][2m], gy[o][2m+1])
                         const float2 x0 = xA[m], x1 = xA[4 * Lph + m], z0 = xB[m], z1 = xB[4 * Lph + m];
-                        cmacc(acc[0][0], make_float2(ga.x, ga.y), x0.x, x0.y);
-                        cmacc(acc[0][1], make_float2(ga.x, ga.y), x1.x, x1.y);
-                        cmacc(acc[1][0], make_float2(gb.x, gb.y), x0.x, x0.y);
-                        cmacc(acc[1][1], make_float2(gb.x, gb.y), x1.x, x1.y);
-                        cmacc(acc[0][0], make_float2(ga.z, ga.w), z0.x, z0.y);
-                        cmacc(acc[0][1], make_float2(ga.z, ga.w), z1.x, z1.y);
-                        cmacc(acc[1][0], make_float2(gb.z, gb.w), z0.x, z0.y);
-                        cmacc(acc[1][1], make_float2(gb.z, gb.w), z1.x, z1.y);
+                        cmac(ca[0][0], x0.x, x0.y, make_float2(ga.x, ga.y));
+                        cmac(ca[0][1], x1.x, x1.y, make_float2(ga.x, ga.y));
+                        cmac(ca[1][0], x0.x, x0.y, make_float2(gb.x, gb.y));
+                        cmac(ca[1][1], x1.x, x1.y, make_float2(gb.x, gb.y));
+                        cmac(ca[0][0], z0.x, z0.y, make_float2(ga.z, ga.w));
+                        cmac(ca[0][1], z1.x, z1.y, make_float2(ga.z, ga.w));
+                        cmac(ca[1][0], z0.x, z0.y, make_float2(gb.z, gb.w));
+                        cmac(ca[1][1], z1.x, z1.y, make_float2(gb.z, gb.w));
                     }
                 }
+                float2 acc[2][2];
+#pragma unroll
+                for (int o = 0; o < 2; o++)
+#pragma unroll
+                    for (int pp = 0; pp < 2; pp++) acc[o][pp] = cfinc(ca[o][pp]);            // gy * conj(x)
 #pragma unroll
                 for (int o = 0; o < 2; o++)
 #pragma unroll
