@@ -18,7 +18,7 @@
 //     with a gradient also owns that parameter's Adam moments (registers) and writes the updated tap to LDS.
 //   * reductions (sum |e|^2, KL) are fixed-order xor butterflies: bitwise reproducible.
 //
-// Supported here: sps == 2, B even, 2*(M/2)+2 <= B <= 128, M in the instantiated set; everything else takes the
+// Supported here: sps == 2, B even, 2*(M/2)+2 <= B <= 128, M in {9, 13, 17, 21, 25, 31}; everything else takes the
 // generic kernel of vaeq_dp.hip.  BT > 0 bakes the minibatch length into the kernel (all LDS offsets immediate).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -676,7 +676,7 @@ static int launch_wave_lev(const vaeq_dp_args &a, hipStream_t st)
 bool dp_wave_supported(const vaeq_dp_args &a)
 {
     if (a.sps != 2 || (a.B & 1) || a.B > 128 || a.B < 2 * (a.M / 2) + 2) return false;
-    if (!(a.M == 25 || a.M == 13 || a.M == 9)) return false;
+    if (!(a.M == 25 || a.M == 31 || a.M == 21 || a.M == 17 || a.M == 13 || a.M == 9)) return false;
     if ((a.S & 3) || ((a.stride_sym * 2) & 3) || (reinterpret_cast<uintptr_t>(a.rx) & 15)) return false;   // 16-byte window loads
     if (a.q_out && (reinterpret_cast<uintptr_t>(a.q_out) & 7)) return false;
     if (a.y_out && (reinterpret_cast<uintptr_t>(a.y_out) & 7)) return false;
@@ -707,6 +707,9 @@ int64_t dp_wave_resident(int B, int M, int n_lev)
     return VAEQ_ERR_SHAPE;
     if (M == 25 && B == 100) { VAEQ_WR(25, 100) }
     if (M == 25) { VAEQ_WR(25, 0) }
+    if (M == 31) { VAEQ_WR(31, 0) }
+    if (M == 21) { VAEQ_WR(21, 0) }
+    if (M == 17) { VAEQ_WR(17, 0) }
     if (M == 13) { VAEQ_WR(13, 0) }
     if (M == 9) { VAEQ_WR(9, 0) }
 #undef VAEQ_WR
@@ -717,6 +720,9 @@ int launch_dp_wave(const vaeq_dp_args &a, hipStream_t st)
 {
     switch (a.M) {
     case 25: return a.B == 100 ? launch_wave_lev<25, 100>(a, st) : launch_wave_lev<25, 0>(a, st);
+    case 31: return launch_wave_lev<31, 0>(a, st);
+    case 21: return launch_wave_lev<21, 0>(a, st);
+    case 17: return launch_wave_lev<17, 0>(a, st);
     case 13: return launch_wave_lev<13, 0>(a, st);
     case 9: return launch_wave_lev<9, 0>(a, st);
     }
