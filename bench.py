@@ -198,7 +198,7 @@ def main():
                          "traffic": traffic, "kernel": "vaeq::dp_wave_kernel<25,8,100,true>" if args.threads in (0, 1) else "vaeq::dp_train_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_DP_SYMBOL * sym_per_launch},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
             cb, cpu_loss = cpu_baseline(frames[0], t, var, lr, args.cpu_seconds, 0)
             res["cpu_baseline"] = cb
         print(json.dumps(res), flush=True)

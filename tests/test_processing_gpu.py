@@ -202,3 +202,26 @@ def test_awgn_config2_run_vs_reference_statistics():
     assert 30 <= conv(SER) <= 200, conv(SER)
     assert abs(SER[-50:].mean() - ref[-50:].mean()) < 3e-4, (SER[-50:].mean(), ref[-50:].mean())   # ~1.1e-3 both
     assert np.max(np.abs(SER[-40:] - ref[-40:])) < 1.5e-3
+
+
+def test_eval_run_dp_sharded_two_ranks(tmp_path):
+    """The sweep script under torch.distributed.run with 2 ranks (gloo, both on this GPU): run r -> rank r % 2, one all_gather, rank 0
+    writes the .mat -- identical to the single-process result (runs are independent and seeded per sweep point)."""
+    import glob
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from vae_equalizer_amd import Eval_run_DP as ev
+    import os
+    env = dict(os.environ, VAEQ_DIST_BACKEND="gloo", VAEQ_SINGLE_DEVICE="1", MPLBACKEND="Agg")
+    d2, d1 = str(tmp_path / "two") + "/", str(tmp_path / "one") + "/"
+    os.makedirs(d2); os.makedirs(d1)
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29533", os.path.join(ROOT, "tests", "_run_eval_dp_small.py"), d2], check=True, env=env, timeout=600,
+                   cwd=ROOT)
+    subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_run_eval_dp_small.py"), d1], check=True, timeout=600, cwd=ROOT)
+    m2 = io.loadmat(glob.glob(d2 + "*.mat")[0])["dict"]
+    m1 = io.loadmat(glob.glob(d1 + "*.mat")[0])["dict"]
+    for k in ("SER", "Var_est", "var_real"):
+        assert np.array_equal(m2[k][0, 0], m1[k][0, 0]), k
+    assert m2["SER"][0, 0].shape == (4, 2, 1, 1, 1, 1, 2, 1, 1, 1, 2, 2)

@@ -57,7 +57,7 @@ def main():
     from . import sweep
 
     rank, world, local_rank = sweep.init_distributed()
-    device = torch.device("cuda", local_rank if world > 1 else torch.cuda.current_device())
+    device = sweep.device_for_rank(local_rank, world)
     if rank == 0:
         print('Run code on: ', device, f'({world} rank(s))')
     shape_tail = (len(SNR_vec), len(symb_rate_vec), len(nu_vec), len(theta_diff_vec), len(M_vec), len(lr_optim_vec),

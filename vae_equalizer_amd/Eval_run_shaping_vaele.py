@@ -36,7 +36,7 @@ def main():
     from .func_VAELE_MQAM_shaping import run_awgn_batch
 
     rank, world, local_rank = sweep.init_distributed()
-    device = torch.device("cuda", local_rank if world > 1 else torch.cuda.current_device())
+    device = sweep.device_for_rank(local_rank, world)
     if rank == 0:
         print('Run code on: ', device, f'({world} rank(s))')
     points = list(sweep_points())

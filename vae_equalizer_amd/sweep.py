@@ -24,11 +24,18 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("VAEQ_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
         dist.init_process_group(backend=backend)
     return dist_info()
+
+
+def device_for_rank(local_rank, world):
+    """cuda:LOCAL_RANK (one process per GPU); VAEQ_SINGLE_DEVICE=1 maps every rank to cuda:0 to rehearse N > 1 on a one-GPU box."""
+    if os.environ.get("VAEQ_SINGLE_DEVICE") or os.environ.get("VAEQ_BENCH_SINGLE_DEVICE"):
+        return torch.device("cuda", 0)
+    return torch.device("cuda", local_rank if world > 1 else torch.cuda.current_device())
 
 
 def my_slice(n_runs, rank=None, world=None):
