@@ -125,6 +125,19 @@ int vaeq_dp_loss(int32_t R, int32_t B, int32_t sps, int32_t M, int32_t n_lev, co
                  const float *h, const float *amp, const float *P, float *loss, float *var_est, void *stream);
 
 /* ------------------------------------------------------------------------
+ * Backward passes of the two stand-alone operators (for torch.autograd.Function wrappers: a reference-style
+ * `loss.backward(); optimizer.step()` loop on HIP kernels; the fused vaeq_dp_train does not use them).
+ *   vaeq_dp_loss_bwd   : loss_function_shaping (shared_funcs.py:92-137): g_up[R] = upstream d/dloss ->
+ *                        gq[R][2][2*n_lev][B] = dL/dq, gh[R][2][2][2][M] = dL/dh_est
+ *   vaeq_dp_forward_bwd: twoXtwoFIR.forward (shared_funcs.py:500-527): gq = dL/dq, gy = dL/dout (nullable), with the forward's
+ *                        q, y -> gW[R][2][4][M] = dL/dW (softmin backward, then the conv weight gradient)
+ */
+int vaeq_dp_loss_bwd(int32_t R, int32_t B, int32_t sps, int32_t M, int32_t n_lev, const float *q, const float *x, const float *h,
+                     const float *amp, const float *P, const float *g_up, float *gq, float *gh, void *stream);
+int vaeq_dp_forward_bwd(int32_t R, int32_t N, int32_t sps, int32_t M, int32_t n_lev, const float *x, const float *q, const float *y,
+                        const float *gq, const float *gy, const float *amp, const float *var, float *gW, void *stream);
+
+/* ------------------------------------------------------------------------
  * Single-polarisation (AWGN / ISI channel) VAE-LE training loop.
  *
  * Replaces, for R independent runs at once, the minibatch loop

@@ -1,0 +1,75 @@
+"""The reference's operator-level training loop, written exactly like func_VAELE_DP_MQAM_shaping.py:57-66 against the mirrors
+(twoXtwoFIR module, loss_function_shaping, torch.optim.Adam, loss.backward()), runs on HIP kernels and reproduces the reference's
+gradients and taps (G1 / G2 fixtures)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+G1 = ["G1_dp_step_64qam_pcs", "G1_dp_step_64qam", "G1_dp_step_16qam", "G1_dp_step_4qam"]
+
+
+@pytest.mark.parametrize("name", G1)
+def test_operator_level_backward_matches_reference_autograd(name):
+    from vae_equalizer_amd import shared_funcs as sfun
+    g = load_golden(name)
+    B, sps, M = int(g["B"]), int(g["sps"]), int(g["M_est"])
+    net = sfun.twoXtwoFIR(M, sps).to(DEV)
+    with torch.no_grad():
+        net.conv_w.weight.copy_(torch.from_numpy(g["W0"]))
+    h_est = torch.tensor(g["h0"], device=DEV, requires_grad=True)
+    amp, P, var = (torch.from_numpy(g[k]).to(DEV) for k in ("amp_levels", "P", "var"))
+    opt = torch.optim.Adam(net.parameters(), lr=float(g["lr"]))
+    opt.add_param_group({"params": h_est})
+    rx = torch.from_numpy(g["rx"]).to(DEV)
+    for s in range(3):
+        mb = rx[:, :, s * B * sps:(s + 1) * B * sps].clone()
+        opt.zero_grad()
+        q, out = net(mb, amp, var, float(g["nu_sc"]))
+        loss, var_est = sfun.loss_function_shaping(q.squeeze(), mb.squeeze(), h_est, amp, P)
+        loss.backward()
+        if s == 0:
+            assert abs(loss.item() - g["loss0"]) / abs(g["loss0"]) < 1e-5
+            assert relerr(var_est.cpu().numpy(), g["var_est0"]) < 1e-5 and not var_est.requires_grad
+            assert relerr(h_est.grad.cpu().numpy(), g["gh0"]) < 2e-5
+            assert relerr(net.conv_w.weight.grad.cpu().numpy(), g["gW0"]) < 1e-4
+        opt.step()
+    assert np.max(np.abs(net.conv_w.weight.detach().cpu().numpy() - g["W3"])) < 2e-5
+    assert np.max(np.abs(h_est.detach().cpu().numpy() - g["h3"])) < 2e-5
+
+
+def test_operator_level_loop_equals_fused_kernel():
+    """20 free steps from the Dirac start through the operator-level loop == the fused kernel == the reference (G2)."""
+    from vae_equalizer_amd import shared_funcs as sfun
+    g = load_golden("G2_dp_freerun")
+    B, sps, M = int(g["B"]), int(g["sps"]), int(g["M_est"])
+    net = sfun.twoXtwoFIR(M, sps).to(DEV)
+    h_est, h_ch, P, amp_levels, amps, pol, nu_sc, var, pow_mean = sfun.init("h0", "64-QAM", DEV, 0.0, sps, M, 23)
+    opt = torch.optim.Adam(net.parameters(), lr=float(g["lr"]))
+    opt.add_param_group({"params": h_est})
+    P_t = torch.tensor(P, dtype=torch.float32, device=DEV)
+    rx = torch.from_numpy(g["rx"]).to(DEV)
+    losses = []
+    for m in range(20):
+        mb = rx[:, :, m * B * sps:(m + 1) * B * sps]
+        opt.zero_grad()
+        q, out = net(mb, amp_levels, var, nu_sc)
+        loss, _ = sfun.loss_function_shaping(q, mb, h_est, amp_levels, P_t)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert np.max(np.abs(np.array(losses) - g["loss"][:20]) / np.abs(g["loss"][:20])) < 1e-5
+    assert np.max(np.abs(net.conv_w.weight.detach().cpu().numpy() - g["W_after20"])) < 1e-5
+    assert np.max(np.abs(h_est.detach().cpu().numpy() - g["h_after20"])) < 1e-5
+
+
+def test_eval_mode_builds_no_graph():
+    from vae_equalizer_amd import shared_funcs as sfun
+    g = load_golden(G1[0])
+    net = sfun.twoXtwoFIR(int(g["M_est"]), 2).to(DEV)
+    with torch.no_grad():
+        q, out = net(torch.from_numpy(g["rx"][:, :, :200]).to(DEV), torch.from_numpy(g["amp_levels"]).to(DEV), torch.from_numpy(g["var"]).to(DEV), 0.0)
+    assert not q.requires_grad and not out.requires_grad

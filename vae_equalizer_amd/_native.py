@@ -71,7 +71,7 @@ class AWGNArgs(C.Structure):
 
 
 # every symbol include/vaeq.h declares; tests check the library exports all of them
-EXPORTS = ["vaeq_dp_train", "vaeq_dp_lds_bytes", "vaeq_dp_resident_runs", "vaeq_soft_demap", "vaeq_dp_forward", "vaeq_dp_loss", "vaeq_dp_epilogue", "vaeq_dp_epilogue_ws_bytes", "vaeq_gen_dp_tx", "vaeq_gen_dp_disperse", "vaeq_gen_dp_finish", "vaeq_awgn_train",
+EXPORTS = ["vaeq_dp_train", "vaeq_dp_lds_bytes", "vaeq_dp_resident_runs", "vaeq_soft_demap", "vaeq_dp_forward", "vaeq_dp_loss", "vaeq_dp_loss_bwd", "vaeq_dp_forward_bwd", "vaeq_dp_epilogue", "vaeq_dp_epilogue_ws_bytes", "vaeq_gen_dp_tx", "vaeq_gen_dp_disperse", "vaeq_gen_dp_finish", "vaeq_awgn_train",
            "vaeq_awgn_lds_bytes", "vaeq_awgn_forward", "vaeq_version", "vaeq_strerror"]
 
 
@@ -98,6 +98,10 @@ def lib():
         L.vaeq_dp_forward.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 8
         L.vaeq_dp_loss.restype = C.c_int
         L.vaeq_dp_loss.argtypes = [C.c_int32] * 5 + [C.c_void_p] * 8
+        L.vaeq_dp_loss_bwd.restype = C.c_int
+        L.vaeq_dp_loss_bwd.argtypes = [C.c_int32] * 5 + [C.c_void_p] * 9
+        L.vaeq_dp_forward_bwd.restype = C.c_int
+        L.vaeq_dp_forward_bwd.argtypes = [C.c_int32] * 5 + [C.c_void_p] * 9
         L.vaeq_dp_epilogue.restype = C.c_int
         L.vaeq_dp_epilogue.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 11
         L.vaeq_dp_epilogue_ws_bytes.restype = C.c_int64

@@ -77,8 +77,10 @@ class twoXtwoFIR(nn.Module):
         nn.init.dirac_(self.conv_w.weight)
 
     def forward(self, x, amp_levels, var, nu_sc):
-        with torch.no_grad():
-            q, y = _engine.dp_forward(x, self.conv_w.weight.detach(), amp_levels, var, nu_sc, self.sps)
+        if torch.is_grad_enabled() and self.conv_w.weight.requires_grad:
+            from .autograd_ops import fir_demap                  # HIP forward + HIP backward (vaeq_dp_forward / _bwd)
+            return fir_demap(x, self.conv_w.weight, amp_levels, var, nu_sc, self.sps)
+        q, y = _engine.dp_forward(x, self.conv_w.weight.detach(), amp_levels, var, nu_sc, self.sps)
         return q, y
 
 
@@ -90,7 +92,10 @@ def soft_dec(out, var, amp_levels, nu_sc):
 def loss_function_shaping(q, rx, h_est, amp_levels, P):
     """ELBO of one minibatch (shared_funcs.py:92-137) -> (loss, var_est[2]); q[2,2n,B], rx[2,2,B*sps], h_est[2,2,2,M].
 
-    Evaluated by the HIP kernel vaeq_dp_loss; values only (the gradient path of the product is the fused kernel)."""
+    HIP kernels: vaeq_dp_loss (values) and, when q or h_est require grad, vaeq_dp_loss_bwd through autograd_ops.elbo_loss."""
+    if torch.is_grad_enabled() and (q.requires_grad or h_est.requires_grad):
+        from .autograd_ops import elbo_loss
+        return elbo_loss(q, rx, h_est, amp_levels, P)
     return _engine.dp_loss(q, rx, h_est.detach(), amp_levels, P)
 
 
