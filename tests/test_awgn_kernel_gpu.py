@@ -82,3 +82,55 @@ def test_awgn_forward_validation_pass():
     qo, yo = oracle.awgn_forward(x, g["W3"], g["amp_levels"], float(g["amp_mean"]), float(g["var"]), int(g["sps"]), np.float64)
     assert relerr(_np(y)[0], yo) < 2e-6
     assert np.max(np.abs(_np(q)[0] - qo)) < 5e-4
+
+
+# ------------------------------------------------------------------ wave-per-run fast path (vaeq_awgn_wave.hip)
+@pytest.mark.parametrize("name", AWGN[:2])
+def test_awgn_wave_teacher_forced_step(name):
+    """threads=1 forces the wave kernel (B = 350 -> 3 rounds of symbol pairs per lane): same golden checks as above."""
+    test_awgn_teacher_forced_step(name, 1)
+
+
+def test_awgn_wave_refuses_unsupported_shape():
+    from vae_equalizer_amd._native import VaeqError
+    g = load_golden("G4_awgn_4qam_small")                      # B = 41 is odd: only the generic kernel takes it
+    eng = _engine(g, 1)
+    with pytest.raises(VaeqError):
+        eng.train(torch.from_numpy(g["rx"][None]).to(DEV), int(g["B"]), 1, float(g["lr"]))
+
+
+@pytest.mark.parametrize("B,M,nlev", [(26, 25, 8), (100, 25, 4), (128, 25, 8), (130, 17, 2), (254, 9, 8), (256, 25, 2), (258, 25, 8),
+                                      (350, 25, 8), (384, 17, 4), (10, 9, 4)])
+def test_awgn_wave_matches_generic(B, M, nlev):
+    """Every round count (1..3), partial last rounds, all supported tap counts: 4 free steps, 3 runs, wave vs generic kernel."""
+    from vae_equalizer_amd.engine import AWGNEngine
+    rng = np.random.default_rng(B * 100 + M)
+    R, steps, sps = 3, 4, 2
+    amp = np.arange(-(nlev - 1), nlev, 2).astype(np.float32)
+    amp /= np.sqrt(2 * np.mean(amp ** 2))
+    P = rng.uniform(0.5, 1.5, (R, nlev)).astype(np.float32)
+    P /= P.sum(1, keepdims=True)
+    amp_mean, var = float(np.mean(np.abs(amp))), 0.02
+    sym = rng.choice(amp, (R, 2, steps * B))
+    rx = np.repeat(sym, sps, axis=-1).astype(np.float32)
+    rx = (0.5 * rx + 0.3 * np.roll(rx, 1, -1) + 0.05 * rng.standard_normal(rx.shape)).astype(np.float32)
+    W0 = (0.05 * rng.standard_normal((R, 2, M))).astype(np.float32)
+    W0[:, 0, M // 2] += 1.0
+    h0 = (0.05 * rng.standard_normal((R, 2, M))).astype(np.float32)
+    h0[:, 0, M // 2] += 1.0
+    out = []
+    for threads in (256, 1):
+        eng = AWGNEngine(R, M, amp, P, amp_mean, var, DEV, sps, threads)
+        eng.W.copy_(torch.from_numpy(W0)); eng.h.copy_(torch.from_numpy(h0))
+        r = eng.train(torch.from_numpy(rx).to(DEV), B, steps, 1e-3, want_q=True, want_y=True, debug_grads=True)
+        torch.cuda.synchronize()
+        out.append({k: _np(v) for k, v in r.items() if torch.is_tensor(v)} | {"W": _np(eng.W), "h": _np(eng.h), "xW": _np(eng.xW), "xh": _np(eng.xh),
+                                                         "step": _np(eng.step)})
+    g, w = out
+    assert np.array_equal(g["step"], w["step"])
+    assert np.max(np.abs(w["loss"] - g["loss"]) / np.abs(g["loss"])) < 2e-5
+    assert relerr(w["y"], g["y"]) < 1e-5
+    assert np.max(np.abs(w["q"] - g["q"])) < 2e-3
+    assert np.max(np.abs(w["W"] - g["W"])) < 2e-5 and np.max(np.abs(w["h"] - g["h"])) < 2e-5
+    assert relerr(w["gW"], g["gW"]) < 1e-3 and relerr(w["gh"], g["gh"]) < 1e-3
+    assert relerr(w["xW"], g["xW"]) < 1e-3 and relerr(w["xh"], g["xh"]) < 1e-3

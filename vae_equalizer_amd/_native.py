@@ -13,8 +13,8 @@ import torch
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("VAEQ_LIB") or os.path.join(_PKG, "libvaeq_hip.so")   # VAEQ_LIB: A/B builds of the kernels (tools/build_variant.sh)
-SOURCES = ["vaeq_dp.hip", "vaeq_dp_wave.hip", "vaeq_awgn.hip", "vaeq_misc.hip", "vaeq_epilogue.hip", "vaeq_gen.hip"]
-HEADERS = ["vaeq_common.h"]
+SOURCES = ["vaeq_dp.hip", "vaeq_dp_wave.hip", "vaeq_awgn.hip", "vaeq_awgn_wave.hip", "vaeq_misc.hip", "vaeq_epilogue.hip", "vaeq_gen.hip"]
+HEADERS = ["vaeq_common.h", "vaeq_wave.h"]
 _LIB = None
 
 

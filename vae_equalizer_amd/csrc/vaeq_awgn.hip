@@ -19,6 +19,10 @@
 
 namespace vaeq {
 
+// wave-per-run fast path (vaeq_awgn_wave.hip)
+bool awgn_wave_supported(const vaeq_awgn_args &a);
+int launch_awgn_wave(const vaeq_awgn_args &a, hipStream_t st);
+
 struct AWGNLayout {
     int L, mh, Mh, nm, Lp;
     int xs, Ws, hs, mW, vW, xW, mH, vH, xH, gW, gH, ys, mu, vr, t3, kc, gy, es, VS, red, total;
@@ -363,6 +367,8 @@ extern "C" int vaeq_awgn_train(const vaeq_awgn_args *pa, void *stream)
     if ((int64_t)a.steps * a.B * a.sps > a.S) return VAEQ_ERR_SHAPE;
     if (a.R == 0) return VAEQ_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (a.threads == 1 && !vaeq::awgn_wave_supported(a)) return VAEQ_ERR_SHAPE;
+    if ((a.threads == 0 || a.threads == 1) && vaeq::awgn_wave_supported(a)) return vaeq::launch_awgn_wave(a, st);
     switch (a.threads) {
     case 0:
     case 256: return vaeq::launch_awgn_lev<256>(a, (size_t)lds, st);

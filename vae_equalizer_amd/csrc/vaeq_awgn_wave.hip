@@ -1,0 +1,561 @@
+// vaeq_awgn_wave.hip -- wave-per-run fast path of the single-polarisation (AWGN / ISI channel) VAE-LE training loop (gfx950).
+//
+// Same math as vaeq_awgn.hip (AWGN_channel/func_VAELE_MQAM_shaping.py: twoFIR.forward :214-231, loss_function :63-95,
+// Adam(amsgrad=True) :283) and the same mapping ideas as vaeq_dp_wave.hip, with two differences:
+//   * minibatches are longer (350 symbols in the reference's sweep), so a lane owns one symbol PAIR PER ROUND, NR = ceil(B/128)
+//     rounds; the convolution-shaped phases walk the taps once and feed all rounds from each tap read;
+//   * the equaliser output is normalised to the constellation's mean amplitude before the demapper (:228), which adds a
+//     wave-wide sum of |y| on the way forward and its Jacobian (one more dot product) on the way back.
+// Lane (tap k, half) computes one half of the sum of dL/dw[k] and dL/dh[k]; after the cross-half shuffle, half 0 owns w[k] and
+// half 1 owns h[k]: parameter, Adam first/second moment and AMSGrad maximum all live in that lane's registers.
+//
+// Supported here: sps == 2, B even, 2*(M/2)+2 <= B <= 384, M in {9, 17, 25}; everything else takes the generic kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vaeq.h"
+#include "vaeq_common.h"
+#include "vaeq_wave.h"
+
+namespace vaeq {
+
+struct AwgnWaveLayout {
+    int Lph, Uph;
+    int X, E, U, PSv, W, H, PSh, VS, total;            // byte offsets (the dL/dy buffer aliases U)
+};
+
+__host__ __device__ inline AwgnWaveLayout awgn_wave_layout(int B, int M)
+{
+    AwgnWaveLayout l;
+    l.Lph = wave_lph(2 * B + M - 1);
+    l.Uph = B / 2 + 1;
+    int o = 0;
+    auto take = [&](int bytes) { int r = o; o += (bytes + 15) & ~15; return r; };
+    l.X = take(4 * l.Lph * 8);
+    l.E = take(4 * l.Lph * 8);
+    const int ubytes = 2 * l.Uph * 8, gbytes = B * 8;
+    l.U = take(ubytes > gbytes ? ubytes : gbytes);
+    l.PSv = take((B + 1) * 4);
+    l.W = take(M * 8);
+    l.H = take((M + 1) * 8);                           // one zero pad tap: j = M
+    l.PSh = take((M + 1) * 4);
+    l.VS = take(M * 4);
+    l.total = o;
+    return l;
+}
+
+// acc[r][sym] += sum_k taps[k] (x) x_r[2*sym + k] for the symbol pair of every round; xp[r] = the lane's phase-0 pointer in round r.
+template <int M, int NR>
+__device__ __forceinline__ void wave_fir(cacc (&acc)[NR][2], const float2 *(&xp)[NR], int Lph, const float2 *taps)
+{
+    constexpr int G = M / 4;
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {                      // taps 4g..4g+3, samples c' = 4g..4g+5
+        const float2 t0 = taps[4 * g], t1 = taps[4 * g + 1], t2 = taps[4 * g + 2], t3 = taps[4 * g + 3];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const float2 *xg = xp[r] + g;
+            const float2 x0 = xg[0], x1 = xg[Lph], x2 = xg[2 * Lph], x3 = xg[3 * Lph], x4 = xg[1], x5 = xg[Lph + 1];
+            cmac(acc[r][0], t0.x, t0.y, x0); cmac(acc[r][1], t0.x, t0.y, x2);
+            cmac(acc[r][0], t1.x, t1.y, x1); cmac(acc[r][1], t1.x, t1.y, x3);
+            cmac(acc[r][0], t2.x, t2.y, x2); cmac(acc[r][1], t2.x, t2.y, x4);
+            cmac(acc[r][0], t3.x, t3.y, x3); cmac(acc[r][1], t3.x, t3.y, x5);
+        }
+    }
+#pragma unroll
+    for (int k = 4 * G; k < M; k++) {                  // remaining 1 or 3 taps
+        const float2 t = taps[k];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            cmac(acc[r][0], t.x, t.y, xp[r][(k & 3) * Lph + (k >> 2)]);
+            cmac(acc[r][1], t.x, t.y, xp[r][((k + 2) & 3) * Lph + ((k + 2) >> 2)]);
+        }
+    }
+}
+
+__device__ __forceinline__ void amsgrad_fast(float &p, float &m, float &v, float &vmax, float g, float step_size, float rbc2s)
+{
+    m = fmaf(g - m, 0.1f, m);
+    v = v * 0.999f;
+    v = v + (0.001f * g) * g;
+    vmax = fmaxf(vmax, v);
+    const float denom = fmaf(__builtin_amdgcn_sqrtf(vmax), rbc2s, 1e-8f);
+    p = fmaf(-step_size * m, __builtin_amdgcn_rcpf(denom), p);
+}
+
+template <int M, int NLEV, int NR>
+__global__ __launch_bounds__(64, 2) void awgn_wave_kernel(const vaeq_awgn_args a)
+{
+    constexpr int mh = M / 2, Mh = 2 * mh;
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    extern __shared__ float4 smem4[];
+    char *sm = reinterpret_cast<char *>(smem4);
+    const int lane = threadIdx.x, run = blockIdx.x;
+    const int B = a.B, L = 2 * B, nm = L - Mh, P2 = B / 2, nq = (nm + 3) / 4;
+    const AwgnWaveLayout lay = awgn_wave_layout(B, M);
+    const int Lph = lay.Lph, Uph = lay.Uph;
+    float2 *Xs = reinterpret_cast<float2 *>(sm + lay.X), *Es = reinterpret_cast<float2 *>(sm + lay.E);
+    float2 *Us = reinterpret_cast<float2 *>(sm + lay.U), *GY = Us;
+    float2 *Wt = reinterpret_cast<float2 *>(sm + lay.W);       // [k] = (W0[k], -W1[k]): y = sum_k Wt[k] * x   (w = W0 - j W1)
+    float2 *Ht = reinterpret_cast<float2 *>(sm + lay.H);       // [j] = (re, im), j = 0..M (j = M: zero pad)
+    float *PSv = reinterpret_cast<float *>(sm + lay.PSv);      // [B+1] exclusive prefix sums of v_I + v_Q
+    float *PSh = reinterpret_cast<float *>(sm + lay.PSh);      // [M+1] exclusive prefix sums of gC |h_j|^2
+    float *VS = reinterpret_cast<float *>(sm + lay.VS);        // [M]
+
+    float amp[NLEV], nlogP[NLEV];
+#pragma unroll
+    for (int i = 0; i < NLEV; i++) {
+        amp[i] = a.amp[i];
+        nlogP[i] = -logf(a.P[(size_t)run * NLEV + i]);
+    }
+    const float A = a.amp_mean[run], var = a.var[run];
+    const float c2 = LOG2E / var, ivar2 = 2.0f / var;          // z_i = -(yhat - a_i)^2 / var: no 1/2, no PCS term (:229)
+    const float lr = a.lr[run];
+
+    for (int i = lane; i < (lay.W - lay.X) / 8; i += 64) Xs[i] = make_float2(0.f, 0.f);     // X, E, U, PSv
+    for (int i = lane; i < (lay.PSh - lay.H) / 8; i += 64) Ht[i] = make_float2(0.f, 0.f);   // incl. the pad tap
+    __syncthreads();
+    const int tk = lane & 31, half = lane >> 5;
+    const bool owner = tk < M, wown = owner && half == 0, hown = owner && half == 1;
+    const size_t g0 = (size_t)run * 2 * M + tk, g1 = g0 + M;
+    float p0 = 0.f, p1 = 0.f, am0 = 0.f, am1 = 0.f, av0 = 0.f, av1 = 0.f, ax0 = 0.f, ax1 = 0.f;   // parameter pair + Adam state
+    {
+        float *pp = half ? a.h : a.W, *pm = half ? a.adam_mh : a.adam_mW, *pv = half ? a.adam_vh : a.adam_vW,
+              *px = half ? a.adam_xh : a.adam_xW;
+        if (owner) {
+            p0 = pp[g0]; p1 = pp[g1];
+            am0 = pm[g0]; am1 = pm[g1];
+            av0 = pv[g0]; av1 = pv[g1];
+            ax0 = px[g0]; ax1 = px[g1];
+            if (half) Ht[tk] = make_float2(p0, p1); else Wt[tk] = make_float2(p0, -p1);
+        }
+    }
+    int step = a.step[run];
+    double b1t = pow(0.9, (double)step), b2t = pow(0.999, (double)step);
+    __syncthreads();
+
+    const size_t No = (size_t)a.steps * B;
+    float *qf = a.q_out ? a.q_out + (size_t)run * 2 * NLEV * No : nullptr;
+    float *yf = a.y_out ? a.y_out + (size_t)run * 2 * No : nullptr;
+    bool act[NR], qa[NR];
+    const float2 *xp[NR], *ep[NR], *up[NR], *xq[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const int pr = lane + 64 * r;
+        act[r] = pr < P2;                                      // lane owns symbols 2 pr, 2 pr + 1 in round r
+        qa[r] = pr < nq;                                       // ... and the residual quad t = 4 pr .. 4 pr + 3
+        xp[r] = Xs + (act[r] ? pr : 0);                        // idle lanes shadow lane 0 (reads stay inside the arrays)
+        ep[r] = Es + (act[r] ? pr : 0);
+        up[r] = Us + (qa[r] ? pr : 0);
+        xq[r] = Xs + (qa[r] ? pr : 0);
+    }
+
+    // the window of the NEXT step is fetched into registers while the current step computes
+    float4 pf[NR][2];
+    auto fetch = [&](int s) {
+        const float *src = a.rx + (size_t)run * 2 * (size_t)a.S + (size_t)s * L + 4 * lane;
+#pragma unroll
+        for (int r = 0; r < NR; r++)
+#pragma unroll
+            for (int row = 0; row < 2; row++)
+                pf[r][row] = act[r] ? *reinterpret_cast<const float4 *>(src + (size_t)row * a.S + 256 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    fetch(0);
+#pragma unroll 1
+    for (int s = 0; s < a.steps; s++) {
+        // ============ P0: prefetched window -> LDS (polyphase scatter; halo stays zero)
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            if (act[r]) {
+                const float4 I4 = pf[r][0], Q4 = pf[r][1];
+                const float xi[4] = {I4.x, I4.y, I4.z, I4.w}, xq_[4] = {Q4.x, Q4.y, Q4.z, Q4.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int c = mh + i;                      // + 4*pr: phase (c & 3) is lane independent
+                    Xs[(c & 3) * Lph + lane + 64 * r + (c >> 2)] = make_float2(xi[i], xq_[i]);
+                }
+            }
+        }
+        wave_lds_sync();
+
+        // ============ P1: FIR for the lane's symbol pairs; mean |y| per axis (:228)
+        float2 y[NR][2];
+        {
+            cacc ya[NR][2];
+#pragma unroll
+            for (int r = 0; r < NR; r++) ya[r][0] = ya[r][1] = cacc0();
+            wave_fir<M, NR>(ya, xp, Lph, Wt);
+#pragma unroll
+            for (int r = 0; r < NR; r++)
+#pragma unroll
+                for (int sy = 0; sy < 2; sy++) {
+                    const float2 v = cfin(ya[r][sy]);
+                    y[r][sy] = act[r] ? v : make_float2(0.f, 0.f);
+                }
+        }
+        float sa0 = 0.f, sa1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            asm volatile("" : "+v"(y[r][0].x), "+v"(y[r][0].y), "+v"(y[r][1].x), "+v"(y[r][1].y));   // pin (see vaeq_dp_wave.hip)
+            sa0 += fabsf(y[r][0].x) + fabsf(y[r][1].x);
+            sa1 += fabsf(y[r][0].y) + fabsf(y[r][1].y);
+            if (yf && act[r]) {                                // un-normalised output (:227,231)
+                float *rI = yf + (size_t)s * B + 2 * (lane + 64 * r);
+                *reinterpret_cast<float2 *>(rI) = make_float2(y[r][0].x, y[r][1].x);
+                *reinterpret_cast<float2 *>(rI + No) = make_float2(y[r][0].y, y[r][1].y);
+            }
+        }
+        const float m0 = wave_sum(sa0) / (float)B, m1 = wave_sum(sa1) / (float)B;
+        const float sc0 = A / m0, sc1 = A / m1;
+
+        // ============ P2: soft demap + moments (registers), mu -> LDS, prefix sums of the variances
+        float mv[NR][2][2], mt3[NR][2][2], mkc[NR][2][2];      // [round][sym][c]
+        float klsum = 0.f, vv[NR][2];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int n0 = 2 * (lane + 64 * r);
+            const bool inr0 = (n0 >= mh) && (n0 < B - mh) && act[r];                  // KL slice (:91)
+            const bool inr1 = (n0 + 1 >= mh) && (n0 + 1 < B - mh) && act[r];
+            float2 muv[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const v2f yy = (c ? v2f{y[r][0].y, y[r][1].y} : v2f{y[r][0].x, y[r][1].x}) * (c ? sc1 : sc0);
+                v2f z[NLEV], q[NLEV];
+                float zm0 = -3.0e38f, zm1 = -3.0e38f;
+#pragma unroll
+                for (int i = 0; i < NLEV; i++) {
+                    const v2f d = yy - amp[i];
+                    z[i] = -(d * d * c2);
+                    zm0 = fmaxf(zm0, z[i].x);
+                    zm1 = fmaxf(zm1, z[i].y);
+                }
+                const v2f zmax = {zm0, zm1};
+                v2f ssum = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < NLEV; i++) {
+                    z[i] -= zmax;
+                    q[i] = v2f{__builtin_amdgcn_exp2f(z[i].x), __builtin_amdgcn_exp2f(z[i].y)};
+                    ssum += q[i];
+                }
+                const v2f rs = {__builtin_amdgcn_rcpf(ssum.x), __builtin_amdgcn_rcpf(ssum.y)};
+                v2f e1 = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < NLEV; i++) {
+                    q[i] *= rs;
+                    e1 += q[i] * amp[i];
+                }
+                // log(q_i/P_i) from the softmax's own logits (see vaeq_dp_wave.hip / DESIGN.md)
+                v2f e2 = {0.f, 0.f}, e3 = {0.f, 0.f}, kk = {0.f, 0.f}, kl = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < NLEV; i++) {
+                    const v2f d = amp[i] - e1, qd = q[i] * d, g = z[i] * LN2 + nlogP[i];
+                    e2 += qd * d;
+                    e3 += qd * d * d;
+                    kk += qd * g;
+                    kl += q[i] * g;
+                }
+                if (inr0) klsum += kl.x - __builtin_amdgcn_logf(ssum.x) * LN2;
+                if (inr1) klsum += kl.y - __builtin_amdgcn_logf(ssum.y) * LN2;
+                asm volatile("" : "+v"(e2), "+v"(e3), "+v"(kk), "+v"(klsum));           // pin
+                mv[r][0][c] = e2.x; mv[r][1][c] = e2.y;
+                mt3[r][0][c] = e3.x; mt3[r][1][c] = e3.y;
+                mkc[r][0][c] = inr0 ? kk.x : 0.f;
+                mkc[r][1][c] = inr1 ? kk.y : 0.f;
+                if (c) { muv[0].y = e1.x; muv[1].y = e1.y; } else { muv[0].x = e1.x; muv[1].x = e1.y; }
+                if (qf && act[r]) {
+#pragma unroll
+                    for (int i = 0; i < NLEV; i++)
+                        *reinterpret_cast<v2f *>(qf + (size_t)(c * NLEV + i) * No + (size_t)s * B + n0) = q[i];
+                }
+            }
+            vv[r][0] = act[r] ? mv[r][0][0] + mv[r][0][1] : 0.f;
+            vv[r][1] = act[r] ? mv[r][1][0] + mv[r][1][1] : 0.f;
+            if (act[r]) {                                      // U[n]: even symbols in phase 0, odd in phase 1
+                Us[lane + 64 * r] = muv[0];
+                Us[Uph + lane + 64 * r] = muv[1];
+            }
+        }
+        {
+            float carry = 0.f;
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const int n0 = 2 * (lane + 64 * r);
+                const float inc = wave_incl_scan(vv[r][0] + vv[r][1], lane) + carry;
+                if (act[r]) {
+                    PSv[n0 + 1] = inc - vv[r][1];
+                    PSv[n0 + 2] = inc;
+                }
+                carry = __shfl(inc, 63, 64);
+            }
+            if (lane == 0) PSv[0] = 0.f;
+        }
+        wave_lds_sync();
+        if (wown) {
+            const int lo = (Mh - tk + 1) >> 1, hi_ = (nm - 1 + Mh - tk) >> 1;
+            VS[tk] = PSv[hi_ + 1] - PSv[lo];
+        }
+        wave_lds_sync();
+
+        // ============ P3: residual e = x - D for the quads t = 4 pr .. 4 pr + 3
+        //   D[2 tau + par] = sum_a h[2a + par] U[tau + mh - a],   tau in {2 pr, 2 pr + 1}, a = 0..mh
+        float se = 0.f;
+        {
+            cacc D[NR][4];
+#pragma unroll
+            for (int r = 0; r < NR; r++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) D[r][i] = cacc0();
+            auto step_a = [&](int r, float2 he, float2 ho, float2 ulo, float2 uhi) {
+                cmac(D[r][0], he.x, he.y, ulo); cmac(D[r][1], ho.x, ho.y, ulo);
+                cmac(D[r][2], he.x, he.y, uhi); cmac(D[r][3], ho.x, ho.y, uhi);
+            };
+            constexpr int NA = mh + 1, NB = NA / 2;
+#pragma unroll 1
+            for (int b = 0; b < NB; b++) {                     // a = 2b, 2b+1;  d = mh - 2b: samples d+1, d, d-1
+                const float2 he0 = Ht[4 * b], ho0 = Ht[4 * b + 1], he1 = Ht[4 * b + 2], ho1 = Ht[4 * b + 3];
+                constexpr int ph = mh & 1;
+                const int sl = (mh >> 1) - b;
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    const float2 ud = up[r][ph * Uph + sl];
+                    const float2 udp = up[r][(ph ^ 1) * Uph + sl + ph];
+                    const float2 udm = up[r][(ph ^ 1) * Uph + sl + ph - 1];
+                    step_a(r, he0, ho0, ud, udp);
+                    step_a(r, he1, ho1, udm, ud);
+                }
+            }
+            if (NA & 1) {                                      // a = mh: d = 0
+                const float2 he = Ht[2 * mh], ho = Ht[2 * mh + 1];
+#pragma unroll
+                for (int r = 0; r < NR; r++) step_a(r, he, ho, up[r][0], up[r][Uph]);
+            }
+#pragma unroll
+            for (int r = 0; r < NR; r++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int ce = Mh + i;
+                    const float2 x = xq[r][(ce & 3) * Lph + (ce >> 2)];
+                    const float2 Dv = cfin(D[r][i]);
+                    float2 e = make_float2(x.x - Dv.x, x.y - Dv.y);
+                    if (!qa[r] || 4 * (lane + 64 * r) + i >= nm) e = make_float2(0.f, 0.f);
+                    if (qa[r]) Es[(ce & 3) * Lph + lane + 64 * r + (ce >> 2)] = e;
+                    se += e.x * e.x + e.y * e.y;
+                }
+        }
+        se = wave_sum(se);
+        klsum = wave_sum(klsum);
+        float hq = 0.f;
+        if (owner) {
+            const float2 hc = Ht[tk];
+            hq = hc.x * hc.x + hc.y * hc.y;
+        }
+        const float vsl = owner ? VS[tk] : 0.f;
+        const float C = se + wave_sum(half ? 0.f : hq * vsl);
+        const float gC = (float)nm / C;
+        if (lane == 0 && a.loss) a.loss[(size_t)run * a.steps + s] = (float)nm * logf(C) + klsum;
+        {
+            float inc = gC * hq;                               // inclusive scan within each 32-lane half
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) {
+                const float t = __shfl_up(inc, d, 32);
+                if (tk >= d) inc += t;
+            }
+            if (wown) PSh[tk + 1] = inc;
+            if (lane == 0) PSh[0] = 0.f;
+        }
+        wave_lds_sync();
+
+        // ============ P4a: dL/dh, lane = (j = tk, half of the tau range)
+        step += 1;
+        b1t *= 0.9;
+        b2t *= 0.999;
+        const float ss = lr * __builtin_amdgcn_rcpf((float)(1.0 - b1t));
+        const float rbc2s = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf((float)(1.0 - b2t)));
+        float gh0 = 0.f, gh1 = 0.f;
+        {
+            cacc ca = cacc0();
+            if (owner) {
+                const int par = tk & 1, aa = tk >> 1;
+                const int T = (nm - par + 1) >> 1, Th = ((T + 3) >> 2) << 1;
+                const int ma = (half * Th) >> 1, mb = (min(T, half * Th + Th) + 1) >> 1;
+                const int ceA = par + Mh, ceB = par + Mh + 2, npA = mh - aa, npB = mh - aa + 1;
+                const float2 *eA = Es + (ceA & 3) * Lph + (ceA >> 2), *eB = Es + (ceB & 3) * Lph + (ceB >> 2);
+                const float2 *uA = Us + (npA & 1) * Uph + (npA >> 1), *uB = Us + (npB & 1) * Uph + (npB >> 1);
+#pragma unroll 4
+                for (int m = ma; m < mb; m++) {
+                    const float2 e0 = eA[m], u0 = uA[m], f0 = eB[m], w0 = uB[m];
+                    cmac(ca, u0.x, u0.y, e0);
+                    cmac(ca, w0.x, w0.y, f0);
+                }
+            }
+            float2 acc = cfinc(ca);                            // e * conj(U)
+            acc.x += __shfl_xor(acc.x, 32, 64);
+            acc.y += __shfl_xor(acc.y, 32, 64);
+            if (hown) {
+                gh0 = gC * (-2.0f * acc.x + 2.0f * p0 * vsl);
+                gh1 = gC * (-2.0f * acc.y + 2.0f * p1 * vsl);
+                if (!a.no_update) {
+                    amsgrad_fast(p0, am0, av0, ax0, gh0, ss, rbc2s);
+                    amsgrad_fast(p1, am1, av1, ax1, gh1, ss, rbc2s);
+                }
+            }
+        }
+        asm volatile("" : "+v"(p0), "+v"(p1), "+v"(gh0), "+v"(gh1));
+        if (s + 1 < a.steps) fetch(s + 1);
+
+        // ============ P4b: dL/dU (the FIR shape on e with conj(h)), dL/dyhat, normalisation backward
+        float2 gy[NR][2];
+        {
+            float dt0 = 0.f, dt1 = 0.f;
+            {
+                cacc cu[NR][2];
+#pragma unroll
+                for (int r = 0; r < NR; r++) cu[r][0] = cu[r][1] = cacc0();
+                wave_fir<M, NR>(cu, ep, Lph, Ht);
+#pragma unroll
+                for (int r = 0; r < NR; r++)
+#pragma unroll
+                    for (int sy = 0; sy < 2; sy++) {
+                        const float2 au = cfinc(cu[r][sy]);    // e * conj(h)
+                        const int sx = 2 * (2 * (lane + 64 * r) + sy);
+                        const int jlo = max(0, Mh - sx), jhi = max(jlo - 1, min(Mh, nm - 1 + Mh - sx));
+                        const float gv = PSh[jhi + 1] - PSh[jlo];
+                        const float ur = -2.0f * gC * au.x, ui = -2.0f * gC * au.y;
+                        float gI = ivar2 * (ur * mv[r][sy][0] + gv * mt3[r][sy][0] + mkc[r][sy][0]);
+                        float gQ = ivar2 * (ui * mv[r][sy][1] + gv * mt3[r][sy][1] + mkc[r][sy][1]);
+                        if (!act[r]) gI = gQ = 0.f;
+                        gy[r][sy] = make_float2(gI, gQ);
+                        dt0 = fmaf(gI, y[r][sy].x, dt0);
+                        dt1 = fmaf(gQ, y[r][sy].y, dt1);
+                    }
+            }
+            dt0 = wave_sum(dt0);
+            dt1 = wave_sum(dt1);
+            const float k0_ = dt0 * A / (m0 * m0) / (float)B, k1_ = dt1 * A / (m1 * m1) / (float)B;
+#pragma unroll
+            for (int r = 0; r < NR; r++)
+#pragma unroll
+                for (int sy = 0; sy < 2; sy++) {
+                    const float yI = y[r][sy].x, yQ = y[r][sy].y;
+                    const float sgI = (float)(yI > 0.f) - (float)(yI < 0.f), sgQ = (float)(yQ > 0.f) - (float)(yQ < 0.f);
+                    gy[r][sy].x = gy[r][sy].x * sc0 - k0_ * sgI;
+                    gy[r][sy].y = gy[r][sy].y * sc1 - k1_ * sgQ;
+                }
+        }
+        wave_lds_sync();                                       // every read of U / old h is done (GY aliases U)
+#pragma unroll
+        for (int r = 0; r < NR; r++)
+            if (act[r]) {
+                GY[2 * (lane + 64 * r)] = gy[r][0];
+                GY[2 * (lane + 64 * r) + 1] = gy[r][1];
+            }
+        if (hown && !a.no_update) Ht[tk] = make_float2(p0, p1);
+        wave_lds_sync();
+
+        // ============ P5: dL/dw, lane = (k = tk, half of the symbol range)
+        float gw0 = 0.f, gw1 = 0.f;
+        {
+            cacc ca = cacc0();
+            if (owner) {
+                const int Bq = ((B + 3) >> 2) << 1;
+                const int ma = (half * Bq) >> 1, mb = min(B, half * Bq + Bq) >> 1;
+                const int cA = tk, cB = tk + 2;
+                const float2 *xA = Xs + (cA & 3) * Lph + (cA >> 2), *xB = Xs + (cB & 3) * Lph + (cB >> 2);
+                const float4 *G = reinterpret_cast<const float4 *>(GY);
+#pragma unroll 4
+                for (int m = ma; m < mb; m++) {
+                    const float4 g = G[m];                     // (gy[2m], gy[2m+1])
+                    const float2 x0 = xA[m], z0 = xB[m];
+                    cmac(ca, x0.x, x0.y, make_float2(g.x, g.y));
+                    cmac(ca, z0.x, z0.y, make_float2(g.z, g.w));
+                }
+            }
+            float2 acc = cfinc(ca);                            // gy * conj(x) = (dL/dW0, -dL/dW1)
+            acc.x += __shfl_xor(acc.x, 32, 64);
+            acc.y += __shfl_xor(acc.y, 32, 64);
+            if (wown) {
+                gw0 = acc.x;
+                gw1 = -acc.y;
+                if (!a.no_update) {
+                    amsgrad_fast(p0, am0, av0, ax0, gw0, ss, rbc2s);
+                    amsgrad_fast(p1, am1, av1, ax1, gw1, ss, rbc2s);
+                    Wt[tk] = make_float2(p0, -p1);
+                }
+            }
+        }
+        if (s == a.steps - 1 && owner) {
+            if (a.dbg_gW && !half) { a.dbg_gW[g0] = gw0; a.dbg_gW[g1] = gw1; }
+            if (a.dbg_gh && half) { a.dbg_gh[g0] = gh0; a.dbg_gh[g1] = gh1; }
+        }
+        wave_lds_sync();
+    }
+
+    if (owner && !a.no_update) {
+        float *pp = half ? a.h : a.W, *pm = half ? a.adam_mh : a.adam_mW, *pv = half ? a.adam_vh : a.adam_vW,
+              *px = half ? a.adam_xh : a.adam_xW;
+        pp[g0] = p0; pp[g1] = p1;
+        pm[g0] = am0; pm[g1] = am1;
+        pv[g0] = av0; pv[g1] = av1;
+        px[g0] = ax0; px[g1] = ax1;
+    }
+    if (lane == 0 && !a.no_update) a.step[run] = step;
+}
+
+template <int M, int NLEV, int NR>
+static int launch_awgn_wave_k(const vaeq_awgn_args &a, hipStream_t st)
+{
+    const size_t lds = (size_t)awgn_wave_layout(a.B, M).total;
+    auto k = awgn_wave_kernel<M, NLEV, NR>;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return VAEQ_ERR_LDS;
+    hipLaunchKernelGGL(k, dim3(a.R), dim3(64), lds, st, a);
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}
+
+template <int M, int NLEV>
+static int launch_awgn_wave_r(const vaeq_awgn_args &a, hipStream_t st)
+{
+    switch ((a.B / 2 + 63) / 64) {
+    case 1: return launch_awgn_wave_k<M, NLEV, 1>(a, st);
+    case 2: return launch_awgn_wave_k<M, NLEV, 2>(a, st);
+    case 3: return launch_awgn_wave_k<M, NLEV, 3>(a, st);
+    }
+    return VAEQ_ERR_SHAPE;
+}
+
+template <int M>
+static int launch_awgn_wave_lev(const vaeq_awgn_args &a, hipStream_t st)
+{
+    switch (a.n_lev) {
+    case 2: return launch_awgn_wave_r<M, 2>(a, st);
+    case 4: return launch_awgn_wave_r<M, 4>(a, st);
+    case 8: return launch_awgn_wave_r<M, 8>(a, st);
+    }
+    return VAEQ_ERR_SHAPE;
+}
+
+// Whether the wave-per-run kernel covers this call (else the generic kernel runs).
+bool awgn_wave_supported(const vaeq_awgn_args &a)
+{
+    if (a.sps != 2 || (a.B & 1) || a.B > 384 || a.B < 2 * (a.M / 2) + 2) return false;
+    if (!(a.M == 25 || a.M == 17 || a.M == 9)) return false;
+    if ((a.S & 3) || (reinterpret_cast<uintptr_t>(a.rx) & 15)) return false;              // 16-byte window loads
+    if (a.q_out && (reinterpret_cast<uintptr_t>(a.q_out) & 7)) return false;
+    if (a.y_out && (reinterpret_cast<uintptr_t>(a.y_out) & 7)) return false;
+    return true;
+}
+
+int launch_awgn_wave(const vaeq_awgn_args &a, hipStream_t st)
+{
+    switch (a.M) {
+    case 25: return launch_awgn_wave_lev<25>(a, st);
+    case 17: return launch_awgn_wave_lev<17>(a, st);
+    case 9: return launch_awgn_wave_lev<9>(a, st);
+    }
+    return VAEQ_ERR_SHAPE;
+}
+
+int64_t awgn_wave_lds(int B, int M) { return (int64_t)awgn_wave_layout(B, M).total; }
+
+}  // namespace vaeq
