@@ -28,13 +28,17 @@ def test_vaele_processing_vs_reference_trajectory():
     # identical input frames (seeded generator) -> the first frames agree closely before chaos sets in
     assert np.max(np.abs(Var_est.numpy()[:, :3] - g["vaele_Var_est"][:, :3]) / g["vaele_Var_est"][:, :3]) < 1e-3
     assert np.max(np.abs(ours[:, :3] - ref[:, :3])) < 0.02
-    # converged regime: mean SER over the last 20 frames (4 x 20 x ~870 symbols -> MC sigma ~ 1.2e-3 per row)
-    assert np.all(np.abs(ours[:, -20:].mean(1) - ref[:, -20:].mean(1)) < 6e-3), (ours[:, -20:].mean(1), ref[:, -20:].mean(1))
-    assert ours[:, -20:].mean() < 0.04
-    # convergence happens at a similar frame (first frame with all four SERs < 0.1)
+    # convergence happens at a similar frame (first frame with all four SERs < 0.1).  The escape from the initial plateau is
+    # the chaotic part: on the same seed the wave and the generic kernel differ by up to +-9 frames (tools/probe_convergence.py:
+    # 116..131 over 8 seeds), the reference converges at 118 here
     conv = lambda s: int(np.argmax((s < 0.1).all(0)))
     assert abs(conv(ours) - conv(ref)) <= 25, (conv(ours), conv(ref))
-    assert np.max(np.abs(Var_est.numpy()[:, -20:].mean(1) - g["vaele_Var_est"][:, -20:].mean(1)) / g["vaele_Var_est"][:, -20:].mean(1)) < 0.05
+    # converged regime: mean SER over the frames after BOTH have converged (4 rows x >= 10 frames x ~870 symbols)
+    lo = max(conv(ours), conv(ref)) + 4
+    assert F - lo >= 10, (conv(ours), conv(ref))
+    assert np.all(np.abs(ours[:, lo:].mean(1) - ref[:, lo:].mean(1)) < 6e-3), (ours[:, lo:].mean(1), ref[:, lo:].mean(1))
+    assert ours[:, lo:].mean() < 0.04
+    assert np.max(np.abs(Var_est.numpy()[:, lo:].mean(1) - g["vaele_Var_est"][:, lo:].mean(1)) / g["vaele_Var_est"][:, lo:].mean(1)) < 0.05
 
 
 def test_vaeflex_processing_vs_reference_trajectory():
