@@ -213,6 +213,21 @@ int vaeq_gen_dp_disperse(int32_t R, int32_t Ls, double fs, double tau_cd, double
 int vaeq_gen_dp_finish(int32_t R, int32_t N, int32_t sps, int32_t Ls, const float *snr_db, uint64_t seed, uint32_t frame,
                        const float *sig_complex, float *power_ws, float *rx, float *sigma_out, void *stream);
 
+/* Single-polarisation AWGN / ISI channel of AWGN_channel/func_VAELE_MQAM_shaping.py:39-61 (generate_data) for R runs, same three
+ * stages without the dispersion step: g[Lg] = rrc * h_channel; sig_ws [R][Ls] complex64 and power_ws [R] are scratch;
+ * rx[R][2][sps*N] (:57), data_f16 (nullable) [R][2][N] = symbols ref_offset .. ref_offset+N-1 (:59), sigma_out[R] nullable. */
+int vaeq_gen_awgn(int32_t R, int32_t N, int32_t N_conv, int32_t sps, int32_t n_lev, int32_t Lg, int32_t Ls, int32_t ref_offset,
+                  const float *amp, const float *cdf, const float *g_complex, const float *snr_db, uint64_t seed, uint32_t frame,
+                  float *sig_ws, float *power_ws, float *rx, void *data_f16, float *sigma_out, void *stream);
+
+/* Fused validation pass of one AWGN epoch (func_VAELE_MQAM_shaping.py:308-318): twoFIR.forward in eval mode on N symbols per run,
+ * find_shift (:188-204, n_shift circular lags over the first 1000 symbols) and SER_q (:97-123, argmax decisions, minimum over the
+ * four quadrant rotations, 11 symbols trimmed at both ends) without materialising q.
+ * x[R][2][N*sps], W[R][2][M], data_f16[R][2][N] -> ser[R], shift[R] (nullable); y_ws[R][2][N] receives the un-normalised output. */
+int vaeq_awgn_validate(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, int32_t n_shift, const float *x, const float *W,
+                       const float *amp, const float *amp_mean, const float *var, const void *data_f16, float *y_ws, float *ser,
+                       int32_t *shift, void *stream);
+
 int vaeq_version(void);
 const char *vaeq_strerror(int code);
 

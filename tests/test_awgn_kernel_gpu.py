@@ -134,3 +134,57 @@ def test_awgn_wave_matches_generic(B, M, nlev):
     assert np.max(np.abs(w["W"] - g["W"])) < 2e-5 and np.max(np.abs(w["h"] - g["h"])) < 2e-5
     assert relerr(w["gW"], g["gW"]) < 1e-3 and relerr(w["gh"], g["gh"]) < 1e-3
     assert relerr(w["xW"], g["xW"]) < 1e-3 and relerr(w["xh"], g["xh"]) < 1e-3
+
+
+# ------------------------------------------------------------------ fused validation pass (vaeq_awgn_validate)
+@pytest.mark.parametrize("mod,M,N", [("64-QAM", 25, 15000), ("16-QAM", 17, 4001), ("4-QAM", 9, 700), ("16-QAM", 13, 2500)])
+def test_awgn_validate_matches_torch_mirror(mod, M, N):
+    """forward + find_shift + SER_q in one kernel == the torch restatement of the reference's three calls on the q tensor of
+    vaeq_awgn_forward; runs cover delays (TX reference shifted by -6..+7 symbols), all four quadrant rotations and an
+    unconverged equaliser (SER near 1, shift found on noise)."""
+    from vae_equalizer_amd import channel as ch
+    from vae_equalizer_amd.engine import AWGNEngine
+    from vae_equalizer_amd.func_VAELE_MQAM_shaping import SER_q, awgn_tables, find_shift
+    rng = np.random.default_rng(M * 1000 + N)
+    sps, R = 2, 8
+    t = awgn_tables(mod, 0.02 if mod == "64-QAM" else 0.0, 22, "h1", sps)
+    rxs, ds = [], []
+    for r in range(R):
+        rx, d = ch.generate_data(N + 16, t["M_channel"], t["amps"], 22, t["h_channel"], sps, "cpu", t["P"], rng=np.random.default_rng(r),
+                                 noise=np.random.RandomState(r))
+        k = [0, 3, -6, 7, 1, -2, 0, 5][r]                                     # delay between the RX stream and the TX reference
+        rx = rx[:, 2 * 8:2 * (8 + N)]
+        d = d[:, 8 + k:8 + k + N]
+        rot = [1, 1j, -1, -1j, 1, 1j, 1, -1][r]                               # residual quadrant rotation of the equaliser output
+        c = (rx[0].numpy() + 1j * rx[1].numpy()) * rot
+        rxs.append(torch.from_numpy(np.stack([c.real, c.imag]).astype(np.float32)))
+        ds.append(d)
+    rx, data = torch.stack(rxs).to(DEV), torch.stack(ds).to(DEV).contiguous()
+    eng = AWGNEngine(R, M, t["amps"], np.tile(t["P"], (R, 1)), t["amp_mean"], t["var"], DEV, sps)
+    # a rough zero-forcing start so that most runs decide mostly right: a few training epochs from the Dirac taps
+    for _ in range(40):
+        eng.train(rx, 350, N // 350, 5e-3)
+    eng.W[6].zero_(); eng.W[6, 0, M // 2] = 1.0                               # run 6: back to the unconverged start
+    ser, sh, y = eng.validate(rx, data, 21)
+    q, y2 = eng.forward(rx)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)                                                 # same FMA order as vaeq_awgn_forward
+    amp = torch.tensor(t["amps"], dtype=torch.float32, device=DEV)
+    for i in range(R):
+        s_ref = int(find_shift(q[i], data[i], 21, amp, t["n"]))
+        assert int(sh[i]) == s_ref, (i, int(sh[i]), s_ref)
+        e_ref = float(SER_q(q[i][:, 11 + s_ref:-11], data[i][:, 11:-11 - s_ref], sps, t["n"]))
+        assert abs(float(ser[i]) - e_ref) <= 2.0 / N, (i, float(ser[i]), e_ref)
+    if N >= 2500:                                                             # enough training above: most delayed runs locked and were realigned
+        assert int((ser[:6] < 0.05).sum()) >= 3 and {int(v) for v in sh[:6]} != {0}, (ser, sh)
+
+
+def test_awgn_validate_rejects_bad_shapes():
+    from vae_equalizer_amd._native import VaeqError
+    from vae_equalizer_amd.engine import AWGNEngine
+    eng = AWGNEngine(2, 25, np.array([-1.0, 1.0], np.float32), np.full((2, 2), 0.5, np.float32), 1.0, 0.01, DEV, 2)
+    x = torch.zeros(2, 2, 2 * 32, device=DEV)
+    with pytest.raises(VaeqError):
+        eng.validate(x, torch.zeros(2, 2, 32, dtype=torch.float16, device=DEV))          # N < 64
+    with pytest.raises(ValueError):
+        eng.validate(torch.zeros(2, 2, 2 * 100, device=DEV), torch.zeros(2, 2, 99, dtype=torch.float16, device=DEV))

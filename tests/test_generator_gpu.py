@@ -89,3 +89,44 @@ def test_generated_frames_train():
     runs = [DPRun(23, 0.0, 0.0, 0.3, 2.5e-3, 90e9, seed=9) for _ in range(4)]
     r = run_dp_batch(runs, "64-QAM", 2, 25, 100, 2000, 4, 10, "h0", -26e-24, DP["tau_pmd"], DP["phiIQ"], 170, generator="hip")
     assert torch.isfinite(r["SER"]).all() and (r["Var_est"][:, :, -1] < r["Var_est"][:, :, 0]).all()
+
+
+# ------------------------------------------------------------------ AWGN / ISI channel generator (vaeq_gen_awgn)
+def test_awgn_generator_statistics_and_structure():
+    """vaeq_gen_awgn against the model of AWGN_channel/func_VAELE_MQAM_shaping.py:39-61: PCS pmf of the symbols, rx = (zero-stuffed
+    symbols * rrc * h_channel) + white noise with sigma_n from the measured mean power, reference aligned at T + M_channel - 1."""
+    import numpy as np
+    import torch
+    from vae_equalizer_amd import channel as ch
+    from vae_equalizer_amd.func_VAELE_MQAM_shaping import awgn_tables
+    R, N, sps = 6, 6000, 2
+    snr = np.array([10, 14, 18, 22, 26, 30], np.float32)
+    t = awgn_tables("64-QAM", 0.0270955, 20, "h1", sps)
+    rx, data, sigma = ch.generate_awgn_batch_hip(R, N, t["amps"], t["P"], snr, t["h_channel"], sps, "cuda:0", 1234, 3, return_sigma=True)
+    rx2, data2 = ch.generate_awgn_batch_hip(R, N, t["amps"], t["P"], snr, t["h_channel"], sps, "cuda:0", 1234, 3)
+    assert torch.equal(rx, rx2) and torch.equal(data, data2)                  # counter-based: reproducible
+    rx3, _ = ch.generate_awgn_batch_hip(R, N, t["amps"], t["P"], snr, t["h_channel"], sps, "cuda:0", 1234, 4)
+    assert not torch.equal(rx, rx3)
+    assert rx.shape == (R, 2, sps * N) and data.shape == (R, 2, N) and data.dtype == torch.float16
+    rx, data, sigma = rx.cpu().numpy().astype(np.float64), data.cpu().numpy().astype(np.float64), sigma.cpu().numpy()
+    amps = np.asarray(t["amps"])
+    lev = np.argmin(np.abs(data[..., None] - amps), axis=-1)
+    assert np.max(np.abs(data - amps[lev])) < 1e-3                            # fp16 levels
+    pmf = np.bincount(lev.reshape(-1), minlength=len(amps)) / lev.size
+    assert np.max(np.abs(pmf - t["P"])) < 4 * np.sqrt(0.25 / lev.size)
+    assert not np.array_equal(lev[0], lev[1]) and not np.array_equal(lev[0, 0], lev[0, 1])
+    geo = ch.awgn_frame_geometry(N, t["h_channel"], sps)
+    for r in range(R):
+        up = np.zeros(sps * (N - 1) + 1, complex)
+        up[::sps] = data[r, 0] + 1j * data[r, 1]
+        clean = np.convolve(up, geo["g"].astype(complex), mode="valid")      # samples whose pulse support lies inside the reference
+        o = sps * geo["ref_offset"]
+        got = (rx[r, 0] + 1j * rx[r, 1])[o:o + len(clean)]
+        noise = got - clean[:len(got)]
+        p_sig = np.mean(np.abs(clean) ** 2)
+        want_sigma = np.sqrt(sps * p_sig / 2 / 10 ** (snr[r] / 10))
+        assert abs(sigma[r] / want_sigma - 1) < 0.03                          # mean power over the run's own (slightly longer) sequence
+        assert abs(np.std(noise.real) / sigma[r] - 1) < 0.03 and abs(np.std(noise.imag) / sigma[r] - 1) < 0.03
+        assert abs(np.mean(noise)) < 4 * sigma[r] / np.sqrt(len(noise))
+        ac = np.abs(np.vdot(noise[1:], noise[:-1])) / np.vdot(noise, noise).real
+        assert ac < 5 / np.sqrt(len(noise))                                   # white

@@ -229,3 +229,18 @@ def test_eval_run_dp_sharded_two_ranks(tmp_path):
     for k in ("SER", "Var_est", "var_real"):
         assert np.array_equal(m2[k][0, 0], m1[k][0, 0]), k
     assert m2["SER"][0, 0].shape == (4, 2, 1, 1, 1, 1, 2, 1, 1, 1, 2, 2)
+
+
+def test_awgn_config2_device_pipeline_monte_carlo():
+    """Config 2 end to end on the device -- vaeq_gen_awgn -> vaeq_awgn_train (wave kernel) -> vaeq_awgn_validate -- for 24 independent
+    runs: every run locks, and the converged SER agrees with the reference's curve (G7_awgn_cfg2, ~1.1e-3) within Monte-Carlo error."""
+    from vae_equalizer_amd.func_VAELE_MQAM_shaping import run_awgn_batch
+    g = load_golden("G7_awgn_cfg2")
+    runs = [dict(SNR=24, nu=0.0270955, lr_optim=5e-3, seed=None) for _ in range(24)]
+    SER = run_awgn_batch(runs, "64-QAM", 2, 25, 350, 15000, 1200, 500, 2, "h1", generator="hip", seed=99).numpy()
+    assert SER.shape == (24, 250)
+    conv = np.array([int(np.argmax(s < 0.01)) for s in SER])
+    assert np.all((SER[:, -50:] < 0.01).all(1)), conv                         # all locked ...
+    assert np.all(conv >= 20) and np.median(conv) < 160, conv                 # ... neither instantly nor never (reference: 56)
+    tail = SER[:, -50:].mean()                                                # 24 x 50 x 15000 symbols
+    assert abs(tail - g["SER"][-50:].mean()) < 1.5e-4, (tail, g["SER"][-50:].mean())

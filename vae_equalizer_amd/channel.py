@@ -253,6 +253,47 @@ def generate_batch_hip(R, N, amps, P, SNR, h_channel, symb_rate, sps, tau_cd, ta
     return (rx, data, sigma) if return_sigma else (rx, data)
 
 
+def awgn_frame_geometry(N, h_channel, sps):
+    """Lengths of generate_data (AWGN_channel/func_VAELE_MQAM_shaping.py:39-61): combined pulse g = rrc * h_channel, its 'valid'
+    output length Ls and the offset of the TX reference (M_channel = number of symbol-spaced channel taps)."""
+    T = PULSE_SPAN
+    h = np.asarray(h_channel, dtype=np.complex64)
+    M_channel = (len(h) - 1) // sps + 1
+    N_conv = N + len(h) + 4 * T
+    g = np.convolve(rrcfir(T, sps, ROLL_OFF).astype(np.complex64), h).astype(np.complex64)
+    Ls = sps * (N_conv - 1) + 1 - len(g) + 1
+    return dict(N_conv=N_conv, g=g, Lg=len(g), Ls=Ls, ref_offset=T + M_channel - 1)
+
+
+def generate_awgn_batch_hip(R, N, amps, P, SNR, h_channel, sps, device, seed, frame, return_sigma=False):
+    """The AWGN/ISI channel model for R runs on the device (vaeq_gen_awgn): deterministic in (seed, frame, run).
+
+    amps[n]; P[R,n] or [n]; SNR scalar or [R].  Returns (rx[R,2,sps*N] f32, data[R,2,N] f16[, sigma_n[R]])."""
+    import ctypes as C
+
+    from . import _native as nat
+    dev = torch.device(device)
+    geo = awgn_frame_geometry(N, h_channel, sps)
+    n = len(amps)
+    amp_t = torch.as_tensor(np.asarray(amps), dtype=torch.float32, device=dev).contiguous()
+    Pn = np.asarray(P, dtype=np.float64)
+    Pn = np.tile(Pn, (R, 1)) if Pn.ndim == 1 else Pn
+    cdf = torch.as_tensor(np.cumsum(Pn, axis=1), dtype=torch.float32, device=dev).contiguous()
+    g_t = torch.view_as_real(torch.as_tensor(geo["g"], device=dev)).contiguous()
+    snr = torch.as_tensor(SNR, dtype=torch.float32, device=dev).expand(R).contiguous()
+    rx = torch.empty(R, 2, sps * N, dtype=torch.float32, device=dev)
+    data = torch.empty(R, 2, N, dtype=torch.float16, device=dev)
+    sigma = torch.empty(R, dtype=torch.float32, device=dev)
+    sig = torch.empty(R, geo["Ls"], 2, dtype=torch.float32, device=dev)
+    pw = torch.empty(R, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().vaeq_gen_awgn(R, N, geo["N_conv"], sps, n, geo["Lg"], geo["Ls"], geo["ref_offset"], nat.ptr(amp_t), nat.ptr(cdf),
+                                          nat.ptr(g_t), nat.ptr(snr), C.c_uint64(_mix_seed(seed, 0)), C.c_uint32(frame), nat.ptr(sig),
+                                          nat.ptr(pw), nat.ptr(rx), nat.ptr(data, torch.float16), nat.ptr(sigma),
+                                          nat.current_stream(dev)), "vaeq_gen_awgn")
+    return (rx, data, sigma) if return_sigma else (rx, data)
+
+
 def _mix_seed(seed, r0):
     """Key of the Philox streams of the chunk that starts at run r0 (runs inside a chunk are told apart by the run counter word)."""
     return (int(seed) * 0x9E3779B97F4A7C15 + int(r0) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF

@@ -11,6 +11,7 @@
 // the normalisation's Jacobian:
 //   dL/dy_c[n] = g_c[n] A/m_c - (sum_n' g_c[n'] y_c[n']) A / m_c^2 * sign(y_c[n]) / B,   g = dL/dyhat, m_c = mean|y_c|
 //   dL/dW0[k] = sum_n gI x0 + gQ x1,   dL/dW1[k] = sum_n gI x1 - gQ x0        (w = W0 - j W1)
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -322,6 +323,178 @@ __global__ __launch_bounds__(256) void awgn_forward_kernel(int64_t N, int sps, i
     }
 }
 
+
+// Fused validation pass of one epoch (func_VAELE_MQAM_shaping.py:308-318) for all runs, one workgroup per run:
+//   twoFIR.forward in eval mode on N symbols (:311-313)  -> y (workspace; also the un-normalised output), mean |y| per axis
+//   hard decisions = argmax_i q_i = nearest level of yhat (q itself is never materialised: 16 floats per symbol saved)
+//   find_shift (:188-204): E_q[x_I] of the first 1000 symbols against the TX I (else Q) row over n_shift circular lags
+//   SER_q (:97-123) on q[:, 11+sh : -11] vs data[:, 11 : -11-sh], minimum over the four quadrant rotations
+// MT > 0: tap count baked in, four symbols per thread from one register window (sps == 2).
+constexpr int VAL_NE = 1000, VAL_MAXSHIFT = 32;
+
+template <int NLEV, int MT>
+__global__ __launch_bounds__(256) void awgn_validate_kernel(int N, int sps, int Mrt, int n_shift, const float *__restrict__ x,
+                                                            const float *__restrict__ W, const float *__restrict__ amp_g,
+                                                            const float *__restrict__ amp_mean, const float *__restrict__ var,
+                                                            const __half *__restrict__ data, float *__restrict__ yws, float *__restrict__ ser_out,
+                                                            int *__restrict__ shift_out)
+{
+    extern __shared__ unsigned char decs[];            // [2][N] level decisions
+    __shared__ float Ws[2 * 64];
+    __shared__ float red[64];
+    __shared__ float E[VAL_NE];
+    __shared__ float corr[2][VAL_MAXSHIFT];
+    __shared__ int sh_s;
+    const int run = blockIdx.x, tid = threadIdx.x;
+    const int M = MT ? MT : Mrt;
+    for (int i = tid; i < 2 * M; i += 256) Ws[i] = W[(size_t)run * 2 * M + i];
+    __syncthreads();
+    const int64_t L = (int64_t)N * sps;
+    const int pad = (M - 1) / 2;
+    const float *x0 = x + (size_t)run * 2 * L, *x1 = x0 + L;
+    float *y0 = yws + (size_t)run * 2 * N, *y1 = y0 + N;
+    float sa0 = 0.f, sa1 = 0.f;
+    if (MT) {
+        constexpr int WN = (MT ? MT : 1) + 6;
+        for (int g = tid; 4 * g < N; g += 256) {
+            const int n0 = 4 * g;
+            const int64_t sb = 2 * (int64_t)n0 - pad;
+            float xi[WN], xq[WN];
+#pragma unroll
+            for (int k = 0; k < WN; k++) {
+                const int64_t sx = sb + k;
+                const bool ok = sx >= 0 && sx < L;
+                xi[k] = ok ? x0[sx] : 0.f;
+                xq[k] = ok ? x1[sx] : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                float yI = 0.f, yQ = 0.f;
+#pragma unroll
+                for (int k = 0; k < (MT ? MT : 1); k++) {
+                    const float a_ = xi[2 * t + k], b_ = xq[2 * t + k], c_ = Ws[k], d_ = Ws[M + k];
+                    yI = fmaf(c_, a_, yI); yI = fmaf(d_, b_, yI);
+                    yQ = fmaf(c_, b_, yQ); yQ = fmaf(-d_, a_, yQ);
+                }
+                if (n0 + t < N) {
+                    y0[n0 + t] = yI; y1[n0 + t] = yQ;
+                    sa0 += fabsf(yI); sa1 += fabsf(yQ);
+                }
+            }
+        }
+    } else {
+        for (int n = tid; n < N; n += 256) {
+            float yI = 0.f, yQ = 0.f;
+            for (int k = 0; k < M; k++) {
+                const int64_t sx = (int64_t)n * sps + k - pad;
+                if (sx < 0 || sx >= L) continue;
+                const float a_ = x0[sx], b_ = x1[sx];
+                yI = fmaf(Ws[k], a_, yI); yI = fmaf(Ws[M + k], b_, yI);
+                yQ = fmaf(Ws[k], b_, yQ); yQ = fmaf(-Ws[M + k], a_, yQ);
+            }
+            y0[n] = yI; y1[n] = yQ;
+            sa0 += fabsf(yI); sa1 += fabsf(yQ);
+        }
+    }
+    block_reduce3<256>(sa0, sa1, 0.f, red);               // (its barriers also order the y writes before the reads below)
+    float amp[NLEV];
+#pragma unroll
+    for (int i = 0; i < NLEV; i++) amp[i] = amp_g[i];
+    const float A = amp_mean[run], ivar = 1.0f / var[run];
+    const float s0 = A / (red[0] / (float)N), s1 = A / (red[1] / (float)N);
+    const int NE = N < VAL_NE ? N : VAL_NE;
+    for (int n = tid; n < N; n += 256) {
+        const float yI = y0[n] * s0, yQ = y1[n] * s1;
+        int dI = 0, dQ = 0;
+        float bI = 3.0e38f, bQ = 3.0e38f;
+#pragma unroll
+        for (int i = 0; i < NLEV; i++) {
+            const float eI = (yI - amp[i]) * (yI - amp[i]), eQ = (yQ - amp[i]) * (yQ - amp[i]);
+            if (eI < bI) { bI = eI; dI = i; }
+            if (eQ < bQ) { bQ = eQ; dQ = i; }
+        }
+        decs[n] = (unsigned char)dI;
+        decs[N + n] = (unsigned char)dQ;
+        if (n < NE) {
+            float ssum = 0.f, e1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NLEV; i++) {
+                const float d = yI - amp[i], w = __expf(bI * ivar - d * d * ivar);
+                ssum += w;
+                e1 = fmaf(amp[i], w, e1);
+            }
+            E[n] = e1 / ssum;
+        }
+    }
+    __syncthreads();
+    const __half *tI = data + (size_t)run * 2 * N, *tQ = tI + N;
+    const int half_ = n_shift / 2;
+    for (int i = 0; i < n_shift; i++) {                  // corr[i] = <tx[:NE], roll(E, i - half)>,  roll(E, s)[n] = E[(n - s) mod NE]
+        float cI = 0.f, cQ = 0.f;
+        for (int n = tid; n < NE; n += 256) {
+            int m = n - (i - half_);
+            m = m < 0 ? m + NE : (m >= NE ? m - NE : m);
+            const float e = E[m];
+            cI = fmaf(__half2float(tI[n]), e, cI);
+            cQ = fmaf(__half2float(tQ[n]), e, cQ);
+        }
+        __syncthreads();
+        block_reduce3<256>(cI, cQ, 0.f, red);
+        if (tid == 0) { corr[0][i] = fabsf(red[0]); corr[1][i] = fabsf(red[1]); }
+    }
+    if (tid == 0) {
+        int aI = 0, aQ = 0;
+        for (int i = 1; i < n_shift; i++) {
+            if (corr[0][i] > corr[0][aI]) aI = i;
+            if (corr[1][i] > corr[1][aQ]) aQ = i;
+        }
+        int sh = half_ - aI;
+        if (!(corr[0][aI] >= (float)(0.02 * (double)N)) && corr[1][aQ] >= corr[0][aI]) sh = half_ - aQ;
+        sh_s = sh;
+        if (shift_out) shift_out[run] = sh;
+    }
+    __syncthreads();
+    const int sh = sh_s, len = N - 22 - sh, K = NLEV - 1;
+    const float scale = 0.5f * (float)K;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+    for (int j = tid; j < len; j += 256) {
+        const int dI = decs[11 + sh + j], dQ = decs[N + 11 + sh + j];
+        const int aI = (int)rintf(__fadd_rn(__fmul_rn(scale, __half2float(tI[11 + j])), scale));
+        const int aQ = (int)rintf(__fadd_rn(__fmul_rn(scale, __half2float(tQ[11 + j])), scale));
+        c0 += (aI != dI) | (aQ != dQ);
+        c1 += (aI != K - dI) | (aQ != K - dQ);
+        c2 += (aI != K - dQ) | (aQ != dI);
+        c3 += (aI != dQ) | (aQ != K - dI);
+    }
+    __syncthreads();
+    block_reduce3<256>(c0, c1, c2, red);
+    const float r0 = red[0], r1 = red[1], r2 = red[2];
+    __syncthreads();
+    block_reduce3<256>(c3, 0.f, 0.f, red);
+    if (tid == 0) ser_out[run] = fminf(fminf(r0, r1), fminf(r2, red[0])) / (float)len;
+}
+
+template <int NLEV>
+static int launch_validate(int R, int N, int sps, int M, int n_shift, const float *x, const float *W, const float *amp, const float *amp_mean,
+                           const float *var, const __half *data, float *yws, float *ser, int *shift, hipStream_t st)
+{
+    const size_t lds = ((size_t)2 * N + 15) & ~(size_t)15;
+#define VAEQ_VAL(MM)                                                                                                         \
+    {                                                                                                                        \
+        auto k = awgn_validate_kernel<NLEV, MM>;                                                                             \
+        if (lds > 32 * 1024 &&                                                                                               \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return VAEQ_ERR_LDS;                                                                                             \
+        hipLaunchKernelGGL(k, dim3(R), dim3(256), lds, st, N, sps, M, n_shift, x, W, amp, amp_mean, var, data, yws, ser, shift); \
+    }
+    if (sps == 2 && M == 25) VAEQ_VAL(25)
+    else if (sps == 2 && M == 17) VAEQ_VAL(17)
+    else if (sps == 2 && M == 9) VAEQ_VAL(9)
+    else VAEQ_VAL(0)
+#undef VAEQ_VAL
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}
+
 template <int NT, int NLEV>
 static int launch_awgn(const vaeq_awgn_args &a, size_t lds, hipStream_t st)
 {
@@ -392,4 +565,22 @@ extern "C" int vaeq_awgn_forward(int32_t R, int64_t N, int32_t sps, int32_t M, i
     default: return VAEQ_ERR_SHAPE;
     }
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}
+
+extern "C" int vaeq_awgn_validate(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, int32_t n_shift, const float *x, const float *W,
+                                  const float *amp, const float *amp_mean, const float *var, const void *data_f16, float *y_ws, float *ser,
+                                  int32_t *shift, void *stream)
+{
+    if (!x || !W || !amp || !amp_mean || !var || !data_f16 || !y_ws || !ser) return VAEQ_ERR_NULL;
+    if (R < 0 || sps <= 0 || M <= 0 || (M & 1) == 0 || M > 63 || n_shift <= 0 || n_shift > vaeq::VAL_MAXSHIFT) return VAEQ_ERR_SHAPE;
+    if (N < 64 || N > 65536) return VAEQ_ERR_SHAPE;           // decisions live in LDS (2 N bytes); 22 + n_shift symbols are trimmed
+    if (R == 0) return VAEQ_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const __half *d = reinterpret_cast<const __half *>(data_f16);
+    switch (n_lev) {
+    case 2: return vaeq::launch_validate<2>(R, (int)N, sps, M, n_shift, x, W, amp, amp_mean, var, d, y_ws, ser, shift, st);
+    case 4: return vaeq::launch_validate<4>(R, (int)N, sps, M, n_shift, x, W, amp, amp_mean, var, d, y_ws, ser, shift, st);
+    case 8: return vaeq::launch_validate<8>(R, (int)N, sps, M, n_shift, x, W, amp, amp_mean, var, d, y_ws, ser, shift, st);
+    }
+    return VAEQ_ERR_SHAPE;
 }

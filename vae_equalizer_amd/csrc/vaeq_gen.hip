@@ -54,7 +54,7 @@ constexpr int TX_TILE = 1024, TX_NT = 256, TX_MAXG = 96;
 // stage 1: sig[r][p][s] = sum_k g[k] * up[s + Lg-1-k],  up[j] = symbol[j/sps] if j % sps == 0 else 0   (np.convolve 'valid')
 __global__ __launch_bounds__(TX_NT) void gen_tx_kernel(int N_conv, int sps, int n_lev, int Lg, int Ls, const float *__restrict__ amp,
                                                        const float *__restrict__ cdf_g, const float2 *__restrict__ g, uint64_t seed,
-                                                       uint32_t frame, float2 *__restrict__ sig)
+                                                       uint32_t frame, int npol, float2 *__restrict__ sig)
 {
     __shared__ float2 sym[(TX_TILE + TX_MAXG) / 2 + 4];
     __shared__ float2 gs[TX_MAXG];
@@ -81,13 +81,13 @@ __global__ __launch_bounds__(TX_NT) void gen_tx_kernel(int N_conv, int sps, int 
             ar = fmaf(c.x, x.x, ar); ar = fmaf(-c.y, x.y, ar);
             ai = fmaf(c.x, x.y, ai); ai = fmaf(c.y, x.x, ai);
         }
-        sig[((size_t)run * 2 + pol) * Ls + s] = make_float2(ar, ai);
+        sig[((size_t)run * npol + pol) * Ls + s] = make_float2(ar, ai);
     }
 }
 
 // TX reference data[r][p][c][n'] = amplitude of symbol n' + lo (shared_funcs.py:89), fp16
 __global__ __launch_bounds__(256) void gen_ref_kernel(int N, int lo, int n_lev, const float *__restrict__ amp, const float *__restrict__ cdf_g,
-                                                      uint64_t seed, uint32_t frame, __half *__restrict__ data)
+                                                      uint64_t seed, uint32_t frame, int npol, __half *__restrict__ data)
 {
     const int run = blockIdx.z, pol = blockIdx.y;
     float cdf[8];
@@ -95,8 +95,8 @@ __global__ __launch_bounds__(256) void gen_ref_kernel(int N, int lo, int n_lev, 
     for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
         int li, lq;
         draw_symbol(seed, frame, run, pol, n + lo, cdf, n_lev, li, lq);
-        data[((size_t)(run * 2 + pol) * 2 + 0) * N + n] = __float2half(amp[li]);
-        data[((size_t)(run * 2 + pol) * 2 + 1) * N + n] = __float2half(amp[lq]);
+        data[((size_t)(run * npol + pol) * 2 + 0) * N + n] = __float2half(amp[li]);
+        data[((size_t)(run * npol + pol) * 2 + 1) * N + n] = __float2half(amp[lq]);
     }
 }
 
@@ -133,27 +133,27 @@ __global__ __launch_bounds__(256) void gen_disperse_kernel(int Ls, double fs_ove
 }
 
 // stage 3a: mean |sig|^2 per run over both polarisations and all Ls samples (:83)
-__global__ __launch_bounds__(256) void gen_power_kernel(int Ls, const float2 *__restrict__ sig, float *__restrict__ power)
+__global__ __launch_bounds__(256) void gen_power_kernel(int Ls, int npol, const float2 *__restrict__ sig, float *__restrict__ power)
 {
     __shared__ float red[64];
     const int run = blockIdx.x;
-    const float2 *s = sig + (size_t)run * 2 * Ls;
+    const float2 *s = sig + (size_t)run * npol * Ls;
     float acc = 0.f;
-    for (int i = threadIdx.x; i < 2 * Ls; i += 256) acc += s[i].x * s[i].x + s[i].y * s[i].y;
+    for (int i = threadIdx.x; i < npol * Ls; i += 256) acc += s[i].x * s[i].x + s[i].y * s[i].y;
     block_reduce3<256>(acc, 0.f, 0.f, red);
-    if (threadIdx.x == 0) power[run] = red[0] / (float)(2 * Ls);
+    if (threadIdx.x == 0) power[run] = red[0] / (float)(npol * Ls);
 }
 
 // stage 3b: AWGN + planar split: rx[r][p][0/1][s] = Re/Im(sig + sigma_n (n1 + j n2)), s < sps*N   (:84-88)
 __global__ __launch_bounds__(256) void gen_finish_kernel(int Ls, int Lout, int sps, const float *__restrict__ snr_db, const float *__restrict__ power,
-                                                         uint64_t seed, uint32_t frame, const float2 *__restrict__ sig, float *__restrict__ rx,
-                                                         float *__restrict__ sigma_out)
+                                                         uint64_t seed, uint32_t frame, int npol, const float2 *__restrict__ sig,
+                                                         float *__restrict__ rx, float *__restrict__ sigma_out)
 {
     const int run = blockIdx.z, pol = blockIdx.y;
     const float sigma = sqrtf(power[run] * (float)sps * 0.5f / exp10f(snr_db[run] * 0.1f));
     if (sigma_out && pol == 0 && blockIdx.x == 0 && threadIdx.x == 0) sigma_out[run] = sigma;
-    const float2 *s = sig + ((size_t)run * 2 + pol) * Ls;
-    float *rI = rx + ((size_t)(run * 2 + pol) * 2 + 0) * Lout, *rQ = rI + Lout;
+    const float2 *s = sig + ((size_t)run * npol + pol) * Ls;
+    float *rI = rx + ((size_t)(run * npol + pol) * 2 + 0) * Lout, *rQ = rI + Lout;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Lout; i += gridDim.x * blockDim.x) {
         const Philox4 r = philox4x32_10((uint32_t)i, run, frame, (uint32_t)(STREAM_NOISE * 2 + pol), (uint32_t)seed, (uint32_t)(seed >> 32));
         float sn, cs;                                           // Box-Muller: two independent N(0,1)
@@ -177,10 +177,10 @@ extern "C" int vaeq_gen_dp_tx(int32_t R, int32_t N, int32_t N_conv, int32_t sps,
     if (R == 0) return VAEQ_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(vaeq::gen_tx_kernel, dim3((Ls + vaeq::TX_TILE - 1) / vaeq::TX_TILE, 2, R), dim3(vaeq::TX_NT), 0, st, N_conv, sps, n_lev, Lg,
-                       Ls, amp, cdf, reinterpret_cast<const float2 *>(g_complex), seed, frame, reinterpret_cast<float2 *>(sig_complex));
+                       Ls, amp, cdf, reinterpret_cast<const float2 *>(g_complex), seed, frame, 2, reinterpret_cast<float2 *>(sig_complex));
     if (data_f16)
         hipLaunchKernelGGL(vaeq::gen_ref_kernel, dim3((N + 255) / 256 > 64 ? 64 : (N + 255) / 256, 2, R), dim3(256), 0, st, N, ref_offset, n_lev,
-                           amp, cdf, seed, frame, reinterpret_cast<__half *>(data_f16));
+                           amp, cdf, seed, frame, 2, reinterpret_cast<__half *>(data_f16));
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
 
@@ -204,8 +204,35 @@ extern "C" int vaeq_gen_dp_finish(int32_t R, int32_t N, int32_t sps, int32_t Ls,
     if (R == 0) return VAEQ_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int Lout = sps * N;
-    hipLaunchKernelGGL(vaeq::gen_power_kernel, dim3(R), dim3(256), 0, st, Ls, reinterpret_cast<const float2 *>(sig_complex), power_ws);
+    hipLaunchKernelGGL(vaeq::gen_power_kernel, dim3(R), dim3(256), 0, st, Ls, 2, reinterpret_cast<const float2 *>(sig_complex), power_ws);
     hipLaunchKernelGGL(vaeq::gen_finish_kernel, dim3((Lout + 255) / 256 > 64 ? 64 : (Lout + 255) / 256, 2, R), dim3(256), 0, st, Ls, Lout, sps,
-                       snr_db, power_ws, seed, frame, reinterpret_cast<const float2 *>(sig_complex), rx, sigma_out);
+                       snr_db, power_ws, seed, frame, 2, reinterpret_cast<const float2 *>(sig_complex), rx, sigma_out);
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}
+
+// Single-polarisation AWGN / ISI channel (AWGN_channel/func_VAELE_MQAM_shaping.py:39-61) for R runs: the same three stages with one
+// polarisation and no dispersion step: PCS symbols (:45), zero-stuffing + pulse shaping + channel impulse response as one 'valid'
+// FIR with g = rrc * h_channel (:47-52), sigma_n from the mean power (:54), complex AWGN (:55), planar rx[R][2][sps*N] (:57) and the
+// TX reference data[R][2][N] (fp16, :59).  sig_ws: [R][Ls] complex64 scratch, power_ws: [R] floats.
+extern "C" int vaeq_gen_awgn(int32_t R, int32_t N, int32_t N_conv, int32_t sps, int32_t n_lev, int32_t Lg, int32_t Ls, int32_t ref_offset,
+                             const float *amp, const float *cdf, const float *g_complex, const float *snr_db, uint64_t seed, uint32_t frame,
+                             float *sig_ws, float *power_ws, float *rx, void *data_f16, float *sigma_out, void *stream)
+{
+    if (!amp || !cdf || !g_complex || !snr_db || !sig_ws || !power_ws || !rx) return VAEQ_ERR_NULL;
+    if (R < 0 || N <= 0 || sps <= 0 || Lg <= 0 || Lg > vaeq::TX_MAXG || !(n_lev == 2 || n_lev == 4 || n_lev == 8) || ref_offset < 0)
+        return VAEQ_ERR_SHAPE;
+    if (Ls != sps * (N_conv - 1) + 1 - Lg + 1 || ref_offset + N > N_conv || Ls < sps * N) return VAEQ_ERR_SHAPE;
+    if (R == 0) return VAEQ_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int Lout = sps * N;
+    float2 *sig = reinterpret_cast<float2 *>(sig_ws);
+    hipLaunchKernelGGL(vaeq::gen_tx_kernel, dim3((Ls + vaeq::TX_TILE - 1) / vaeq::TX_TILE, 1, R), dim3(vaeq::TX_NT), 0, st, N_conv, sps, n_lev, Lg,
+                       Ls, amp, cdf, reinterpret_cast<const float2 *>(g_complex), seed, frame, 1, sig);
+    if (data_f16)
+        hipLaunchKernelGGL(vaeq::gen_ref_kernel, dim3((N + 255) / 256 > 64 ? 64 : (N + 255) / 256, 1, R), dim3(256), 0, st, N, ref_offset, n_lev,
+                           amp, cdf, seed, frame, 1, reinterpret_cast<__half *>(data_f16));
+    hipLaunchKernelGGL(vaeq::gen_power_kernel, dim3(R), dim3(256), 0, st, Ls, 1, sig, power_ws);
+    hipLaunchKernelGGL(vaeq::gen_finish_kernel, dim3((Lout + 255) / 256 > 64 ? 64 : (Lout + 255) / 256, 1, R), dim3(256), 0, st, Ls, Lout, sps,
+                       snr_db, power_ws, seed, frame, 1, sig, rx, sigma_out);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }

@@ -222,6 +222,23 @@ class AWGNEngine:
                                                   nat.current_stream(self.device)), "vaeq_awgn_forward")
         return q, y
 
+    def validate(self, x, data, n_shift=21):
+        """Fused validation pass (:308-318) -> (SER[R] f32, shift[R] i32, y[R,2,N]): forward, find_shift and SER_q in one
+        kernel (vaeq_awgn_validate); x[R,2,N*sps] f32, data[R,2,N] f16."""
+        R, N = x.shape[0], x.shape[-1] // self.sps
+        if tuple(data.shape) != (R, 2, N):
+            raise ValueError(f"data must be [R={R}, 2, N={N}], got {tuple(data.shape)}")
+        x, data = x.contiguous(), data.contiguous()
+        ser = torch.empty(R, dtype=torch.float32, device=self.device)
+        shift = torch.empty(R, dtype=torch.int32, device=self.device)
+        y = torch.empty(R, 2, N, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().vaeq_awgn_validate(R, N, self.sps, self.M, self.n_lev, int(n_shift), nat.ptr(x), nat.ptr(self.W),
+                                                   nat.ptr(self.amp), nat.ptr(self.amp_mean), nat.ptr(self.var),
+                                                   nat.ptr(data, torch.float16), nat.ptr(y), nat.ptr(ser), nat.ptr(shift, torch.int32),
+                                                   nat.current_stream(self.device)), "vaeq_awgn_validate")
+        return ser, shift, y
+
 
 def dp_epilogue(q, y, data, amp_levels, nu_sc, var, batch_len=None):
     """Per-frame epilogue on the device (vaeq_dp_epilogue): q[R,2,2n,N], y[R,2,2,N], data[R,2,2,N] fp16 ->

@@ -51,9 +51,14 @@ def SER_q(q, tx, sps, num_lev, device=None):
     return torch.stack([((data - d) != 0).any(dim=0).float().mean() for d in (dec, dec_pi, dec_pi4, dec_3pi4)]).min()
 
 
-def run_awgn_batch(runs, mod, sps, M_est, batch_len, N_valid, N_train, num_epochs, epe, channel, device=None, verbose=False):
-    """R AWGN VAE-LE runs at once: ``runs`` = list of dict(SNR, nu, lr_optim, seed).  One training launch per epoch and one
-    validation launch per evaluated epoch for all runs (:291-322).  Returns SER_valid[R, num_epochs // epe] (CPU float32)."""
+def run_awgn_batch(runs, mod, sps, M_est, batch_len, N_valid, N_train, num_epochs, epe, channel, device=None, verbose=False,
+                   generator="numpy", seed=0):
+    """R AWGN VAE-LE runs at once: ``runs`` = list of dict(SNR, nu, lr_optim, seed).  Per epoch ONE training launch and, on evaluated
+    epochs, ONE fused validation launch (forward + find_shift + SER_q, vaeq_awgn_validate) for all runs (:291-322).
+
+    generator: "numpy" = the bit-faithful host channel model per run (seeded like tools/capture_golden.py when the run has a seed);
+               "hip"   = the on-device generator (vaeq_gen_awgn), Philox streams keyed by ``seed``, the draw counter and the run index.
+    Returns SER_valid[R, num_epochs // epe] (CPU float32)."""
     device = default_device() if device is None else torch.device(device)
     R = len(runs)
     tabs = [awgn_tables(mod, r["nu"], r["SNR"], channel, sps) for r in runs]
@@ -63,10 +68,19 @@ def run_awgn_batch(runs, mod, sps, M_est, batch_len, N_valid, N_train, num_epoch
                      device, sps)
     lr = np.array([r["lr_optim"] for r in runs], dtype=np.float32)
     streams = [ch.SeededStreams(r["seed"]) if r.get("seed") is not None else None for r in runs]
-    SER_valid = torch.empty(R, num_epochs // epe, dtype=torch.float32)
     steps = N_train // batch_len                                                 # :297 (the remainder is dropped)
+    n_eval = num_epochs // epe
+    SER_dev = torch.empty(R, max(n_eval, 1), dtype=torch.float32, device=device)
+    P_all = np.stack([t["P"] for t in tabs])
+    snr_all = np.array([r["SNR"] for r in runs], dtype=np.float32)
+    draws = [0]
 
     def draw(N):
+        if generator == "hip":
+            draws[0] += 1
+            return ch.generate_awgn_batch_hip(R, N, t0["amps"], P_all, snr_all, t0["h_channel"], sps, device, seed, draws[0] - 1)
+        if generator != "numpy":
+            raise ValueError(f"unknown generator {generator!r}")
         rxs, ds = [], []
         for t, r, st in zip(tabs, runs, streams):
             rx, d = ch.generate_data(N, t["M_channel"], t["amps"], r["SNR"], t["h_channel"], sps, "cpu", t["P"],
@@ -78,16 +92,16 @@ def run_awgn_batch(runs, mod, sps, M_est, batch_len, N_valid, N_train, num_epoch
     for epoch in range(num_epochs):
         rx, _ = draw(N_train)
         out = eng.train(rx, batch_len, steps, lr)
-        if epoch % epe == 0:                                                     # :308-318
+        if epoch % epe == 0 and epoch // epe < n_eval:                           # :308-318
             rxv, datav = draw(N_valid)
-            q, _ = eng.forward(rxv)
-            for i in range(R):
-                sh = int(find_shift(q[i], datav[i], 21, amp, t0["n"]))
-                SER_valid[i, epoch // epe] = SER_q(q[i][:, 11 + sh:-11], datav[i][:, 11:-11 - sh], sps, t0["n"]).cpu()
-                if verbose:
+            ser, sh, _ = eng.validate(rxv, datav, 21)
+            SER_dev[:, epoch // epe] = ser
+            if verbose:
+                loss, ser_h, sh_h = out["loss"][:, -1].cpu(), ser.cpu(), sh.cpu()
+                for i in range(R):
                     tag = f"[run {i}] " if R > 1 else ""
-                    print(f"{tag}{epoch}", out["loss"][i, -1].item(), sh, '\t\t\t\t\t\tSER = ', SER_valid[i, epoch // epe].item())
-    return SER_valid
+                    print(f"{tag}{epoch}", loss[i].item(), int(sh_h[i]), '\t\t\t\t\t\tSER = ', ser_h[i].item())
+    return SER_dev[:, :n_eval].cpu()
 
 
 def processing(mod, sps, SNR, nu, M_est, lr_optim, batch_len, N_valid, N_train, num_epochs, epe, channel, *, seed=None,
