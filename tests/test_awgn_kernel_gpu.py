@@ -168,7 +168,7 @@ def test_awgn_validate_matches_torch_mirror(mod, M, N):
     ser, sh, y = eng.validate(rx, data, 21)
     q, y2 = eng.forward(rx)
     torch.cuda.synchronize()
-    assert torch.equal(y, y2)                                                 # same FMA order as vaeq_awgn_forward
+    assert relerr(_np(y), _np(y2)) < 1e-6                                     # packed complex MACs vs the scalar FMA chain of vaeq_awgn_forward
     amp = torch.tensor(t["amps"], dtype=torch.float32, device=DEV)
     for i in range(R):
         s_ref = int(find_shift(q[i], data[i], 21, amp, t["n"]))

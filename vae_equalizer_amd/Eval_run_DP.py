@@ -40,7 +40,7 @@ N_frame_max = 10000
 
 savePATH = ""
 base_seed = None    # int -> reproducible runs (run i of the flattened sweep uses base_seed + 1000*i); None = like the reference
-generator = "numpy"  # "numpy": reference-faithful host channel simulator; "torch": batched on-device simulator
+generator = "numpy"  # "numpy": reference-faithful host channel simulator; "hip" / "torch": batched on-device simulators
 
 
 def sweep_points():

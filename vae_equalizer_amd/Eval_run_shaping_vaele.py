@@ -22,6 +22,7 @@ epe = 2                 # epochs per evaluation
 
 savePATH = ""
 base_seed = None        # int -> reproducible runs; None = like the reference
+generator = "numpy"     # "numpy": reference-faithful host channel simulator per run; "hip": on-device generator (vaeq_gen_awgn)
 
 
 def sweep_points():
@@ -46,7 +47,8 @@ def main():
         sel = [k for k, i in enumerate(mine) if (points[i][1]["M"], points[i][1]["N_train"]) == (M, N_train)]
         runs = [dict(SNR=points[mine[k]][1]["SNR"], nu=points[mine[k]][1]["nu"], lr_optim=points[mine[k]][1]["lr"],
                      seed=None if base_seed is None else base_seed + 1000 * mine[k]) for k in sel]
-        local[sel] = run_awgn_batch(runs, mod, sps, M, N_train, N_valid, train_len, num_epochs, epe, channel, device=device)
+        local[sel] = run_awgn_batch(runs, mod, sps, M, N_train, N_valid, train_len, num_epochs, epe, channel, device=device,
+                                    generator=generator, seed=(base_seed or 0) + 7919 * rank)
     rows = sweep.gather_rows(local, len(points), rank, world)
     if rank != 0:
         return None

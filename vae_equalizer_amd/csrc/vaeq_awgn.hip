@@ -17,6 +17,7 @@
 
 #include "vaeq.h"
 #include "vaeq_common.h"
+#include "vaeq_wave.h"
 
 namespace vaeq {
 
@@ -333,13 +334,13 @@ __global__ __launch_bounds__(256) void awgn_forward_kernel(int64_t N, int sps, i
 constexpr int VAL_NE = 1000, VAL_MAXSHIFT = 32;
 
 template <int NLEV, int MT>
-__global__ __launch_bounds__(256) void awgn_validate_kernel(int N, int sps, int Mrt, int n_shift, const float *__restrict__ x,
+__global__ __launch_bounds__(256, 4) void awgn_validate_kernel(int N, int sps, int Mrt, int n_shift, const float *__restrict__ x,
                                                             const float *__restrict__ W, const float *__restrict__ amp_g,
                                                             const float *__restrict__ amp_mean, const float *__restrict__ var,
                                                             const __half *__restrict__ data, float *__restrict__ yws, float *__restrict__ ser_out,
                                                             int *__restrict__ shift_out)
 {
-    extern __shared__ unsigned char decs[];            // [2][N] level decisions
+    extern __shared__ unsigned char decs[];            // [N] level decisions, I in the low and Q in the high nibble
     __shared__ float Ws[2 * 64];
     __shared__ float red[64];
     __shared__ float E[VAL_NE];
@@ -355,30 +356,59 @@ __global__ __launch_bounds__(256) void awgn_validate_kernel(int N, int sps, int 
     float *y0 = yws + (size_t)run * 2 * N, *y1 = y0 + N;
     float sa0 = 0.f, sa1 = 0.f;
     if (MT) {
-        constexpr int WN = (MT ? MT : 1) + 6;
-        for (int g = tid; 4 * g < N; g += 256) {
-            const int n0 = 4 * g;
-            const int64_t sb = 2 * (int64_t)n0 - pad;
-            float xi[WN], xq[WN];
+        // Tiles of 1024 symbols staged in LDS as (I, Q) pairs, 8-way polyphase (sample c -> [c & 7][c >> 3]): thread g computes the
+        // four symbols 4g..4g+3 of the tile from one window of MT + 6 samples; for a fixed window position all lanes read the same
+        // phase at consecutive slots (conflict free), a tap is one broadcast read feeding 8 packed FMAs.
+        constexpr int MM = MT ? MT : 1, TS = 1024, XPH = (2 * TS + MM - 1 + 7) / 8 + 1, NCH = (2 * TS + MM - 1 + 3) / 4;
+        __shared__ float2 xt[8 * XPH];
+        __shared__ float2 Wt[MM];
+        if (tid < MM) Wt[tid] = make_float2(Ws[tid], -Ws[M + tid]);          // y = sum_k Wt[k] * x  (w = W0 - j W1)
+        for (int n0 = 0; n0 < N; n0 += TS) {
+            const int64_t sb = 2 * (int64_t)n0 - pad;                          // first sample of the tile window
+            __syncthreads();
+            for (int v = tid; v < NCH; v += 256) {
 #pragma unroll
-            for (int k = 0; k < WN; k++) {
-                const int64_t sx = sb + k;
-                const bool ok = sx >= 0 && sx < L;
-                xi[k] = ok ? x0[sx] : 0.f;
-                xq[k] = ok ? x1[sx] : 0.f;
+                for (int i = 0; i < 4; i++) {
+                    const int64_t sx = sb + 4 * v + i;
+                    const bool ok = sx >= 0 && sx < L;
+                    const int c = 4 * v + i;
+                    xt[(c & 7) * XPH + (c >> 3)] = make_float2(ok ? x0[sx] : 0.f, ok ? x1[sx] : 0.f);
+                }
+            }
+            __syncthreads();
+            cacc acc[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) acc[t] = cacc0();
+            constexpr int G8 = MM / 8;
+#pragma unroll 1
+            for (int g = 0; g < G8; g++) {                                     // taps 8g..8g+7: window positions 8g..8g+13
+                const float2 *xg = xt + tid + g;
+                float2 xw[14];
+#pragma unroll
+                for (int j = 0; j < 14; j++) xw[j] = xg[(j & 7) * XPH + (j >> 3)];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const float2 w = Wt[8 * g + k];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) cmac(acc[t], w.x, w.y, xw[2 * t + k]);
+                }
+            }
+#pragma unroll
+            for (int k = 8 * G8; k < MM; k++) {                                // remaining taps
+                const float2 w = Wt[k];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int j = 2 * t + k;
+                    cmac(acc[t], w.x, w.y, xt[(j & 7) * XPH + tid + (j >> 3)]);
+                }
             }
 #pragma unroll
             for (int t = 0; t < 4; t++) {
-                float yI = 0.f, yQ = 0.f;
-#pragma unroll
-                for (int k = 0; k < (MT ? MT : 1); k++) {
-                    const float a_ = xi[2 * t + k], b_ = xq[2 * t + k], c_ = Ws[k], d_ = Ws[M + k];
-                    yI = fmaf(c_, a_, yI); yI = fmaf(d_, b_, yI);
-                    yQ = fmaf(c_, b_, yQ); yQ = fmaf(-d_, a_, yQ);
-                }
-                if (n0 + t < N) {
-                    y0[n0 + t] = yI; y1[n0 + t] = yQ;
-                    sa0 += fabsf(yI); sa1 += fabsf(yQ);
+                const int n = n0 + 4 * tid + t;
+                if (n < N) {
+                    const float2 yv = cfin(acc[t]);
+                    y0[n] = yv.x; y1[n] = yv.y;
+                    sa0 += fabsf(yv.x); sa1 += fabsf(yv.y);
                 }
             }
         }
@@ -403,18 +433,29 @@ __global__ __launch_bounds__(256) void awgn_validate_kernel(int N, int sps, int 
     const float A = amp_mean[run], ivar = 1.0f / var[run];
     const float s0 = A / (red[0] / (float)N), s1 = A / (red[1] / (float)N);
     const int NE = N < VAL_NE ? N : VAL_NE;
+    // square-QAM levels are equidistant: the nearest level is a rounding (any other level set takes the search loop)
+    const float a0 = amp[0], delta = amp[1] - amp[0], rdelta = 1.0f / delta;
+    bool uniform = delta > 0.f;
+#pragma unroll
+    for (int i = 2; i < NLEV; i++) uniform = uniform && fabsf(amp[i] - (a0 + (float)i * delta)) <= 1e-6f * delta;
     for (int n = tid; n < N; n += 256) {
         const float yI = y0[n] * s0, yQ = y1[n] * s1;
         int dI = 0, dQ = 0;
         float bI = 3.0e38f, bQ = 3.0e38f;
+        if (uniform) {
+            dI = min(max((int)rintf((yI - a0) * rdelta), 0), NLEV - 1);
+            dQ = min(max((int)rintf((yQ - a0) * rdelta), 0), NLEV - 1);
+            const float dd = yI - (a0 + (float)dI * delta);                    // only stabilises the softmax of E below
+            bI = dd * dd;
+        } else {
 #pragma unroll
-        for (int i = 0; i < NLEV; i++) {
-            const float eI = (yI - amp[i]) * (yI - amp[i]), eQ = (yQ - amp[i]) * (yQ - amp[i]);
-            if (eI < bI) { bI = eI; dI = i; }
-            if (eQ < bQ) { bQ = eQ; dQ = i; }
+            for (int i = 0; i < NLEV; i++) {
+                const float eI = (yI - amp[i]) * (yI - amp[i]), eQ = (yQ - amp[i]) * (yQ - amp[i]);
+                if (eI < bI) { bI = eI; dI = i; }
+                if (eQ < bQ) { bQ = eQ; dQ = i; }
+            }
         }
-        decs[n] = (unsigned char)dI;
-        decs[N + n] = (unsigned char)dQ;
+        decs[n] = (unsigned char)(dI | (dQ << 4));
         if (n < NE) {
             float ssum = 0.f, e1 = 0.f;
 #pragma unroll
@@ -458,7 +499,7 @@ __global__ __launch_bounds__(256) void awgn_validate_kernel(int N, int sps, int 
     const float scale = 0.5f * (float)K;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
     for (int j = tid; j < len; j += 256) {
-        const int dI = decs[11 + sh + j], dQ = decs[N + 11 + sh + j];
+        const int dd = decs[11 + sh + j], dI = dd & 15, dQ = dd >> 4;
         const int aI = (int)rintf(__fadd_rn(__fmul_rn(scale, __half2float(tI[11 + j])), scale));
         const int aQ = (int)rintf(__fadd_rn(__fmul_rn(scale, __half2float(tQ[11 + j])), scale));
         c0 += (aI != dI) | (aQ != dQ);
@@ -478,7 +519,7 @@ template <int NLEV>
 static int launch_validate(int R, int N, int sps, int M, int n_shift, const float *x, const float *W, const float *amp, const float *amp_mean,
                            const float *var, const __half *data, float *yws, float *ser, int *shift, hipStream_t st)
 {
-    const size_t lds = ((size_t)2 * N + 15) & ~(size_t)15;
+    const size_t lds = ((size_t)N + 15) & ~(size_t)15;
 #define VAEQ_VAL(MM)                                                                                                         \
     {                                                                                                                        \
         auto k = awgn_validate_kernel<NLEV, MM>;                                                                             \
@@ -573,7 +614,7 @@ extern "C" int vaeq_awgn_validate(int32_t R, int64_t N, int32_t sps, int32_t M, 
 {
     if (!x || !W || !amp || !amp_mean || !var || !data_f16 || !y_ws || !ser) return VAEQ_ERR_NULL;
     if (R < 0 || sps <= 0 || M <= 0 || (M & 1) == 0 || M > 63 || n_shift <= 0 || n_shift > vaeq::VAL_MAXSHIFT) return VAEQ_ERR_SHAPE;
-    if (N < 64 || N > 65536) return VAEQ_ERR_SHAPE;           // decisions live in LDS (2 N bytes); 22 + n_shift symbols are trimmed
+    if (N < 64 || N > 65536) return VAEQ_ERR_SHAPE;           // decisions live in LDS (N bytes); 22 + n_shift symbols are trimmed
     if (R == 0) return VAEQ_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const __half *d = reinterpret_cast<const __half *>(data_f16);
