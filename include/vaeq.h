@@ -202,15 +202,18 @@ int64_t vaeq_dp_epilogue_ws_bytes(int32_t R, int64_t N);
  *                         (complex, interleaved) -> sig[R][2][Ls] complex64 (interleaved), Ls = sps*(N_conv-1)+1 - Lg + 1;
  *                         data_f16 (nullable) [R][2][2][N]: TX reference = symbols ref_offset .. ref_offset+N-1 (:89)
  *   vaeq_gen_dp_disperse: spectrum x H(f) (PMD + rotation theta[r] + IQ phase e_k = exp(-j phiIQ[k])) x CD phase (:38-54), in place;
- *                         fs = symb_rate * sps
+ *                         fs = symb_rate * sps; scale multiplies the result (1/Ls folds the inverse FFT's normalisation in)
  *   vaeq_gen_dp_finish  : sigma_n from the mean power (:83), complex AWGN (:84), planar rx[R][2][2][sps*N] (:88); power_ws[R] scratch,
- *                         sigma_out[R] nullable */
-int vaeq_gen_dp_tx(int32_t R, int32_t N, int32_t N_conv, int32_t sps, int32_t n_lev, int32_t Lg, int32_t Ls, int32_t ref_offset,
-                   const float *amp, const float *cdf, const float *g_complex, uint64_t seed, uint32_t frame, float *sig_complex,
-                   void *data_f16, void *stream);
+ *                         sigma_out[R] nullable
+ * Rows of sig are Lrow >= Ls complex samples long; stage 1 zero-fills [Ls, Lrow).  Lrow == Ls reproduces the reference's circular
+ * filtering over the exact sequence length; a padded Lrow (a fast FFT length) turns it into linear filtering -- only the few samples
+ * within the dispersion's impulse-response length of the frame edges differ. */
+int vaeq_gen_dp_tx(int32_t R, int32_t N, int32_t N_conv, int32_t sps, int32_t n_lev, int32_t Lg, int32_t Ls, int32_t Lrow,
+                   int32_t ref_offset, const float *amp, const float *cdf, const float *g_complex, uint64_t seed, uint32_t frame,
+                   float *sig_complex, void *data_f16, void *stream);
 int vaeq_gen_dp_disperse(int32_t R, int32_t Ls, double fs, double tau_cd, double tau_pmd, float e0_re, float e0_im, float e1_re,
-                         float e1_im, const float *theta, float *spec_complex, void *stream);
-int vaeq_gen_dp_finish(int32_t R, int32_t N, int32_t sps, int32_t Ls, const float *snr_db, uint64_t seed, uint32_t frame,
+                         float e1_im, float scale, const float *theta, float *spec_complex, void *stream);
+int vaeq_gen_dp_finish(int32_t R, int32_t N, int32_t sps, int32_t Ls, int32_t Lrow, const float *snr_db, uint64_t seed, uint32_t frame,
                        const float *sig_complex, float *power_ws, float *rx, float *sigma_out, void *stream);
 
 /* Single-polarisation AWGN / ISI channel of AWGN_channel/func_VAELE_MQAM_shaping.py:39-61 (generate_data) for R runs, same three

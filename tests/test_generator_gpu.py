@@ -24,11 +24,13 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def host_symbols(seed, frame, run, pol, n_idx, cdf):
+    """Host replica of draw_symbol_pair (vaeq_gen.hip): Philox counter n >> 1, words (x, y) for even n and (z, w) for odd n."""
     key = ch._mix_seed(seed, 0)
-    x, y, _, _ = philox4x32_10(n_idx, run, frame, pol, key & 0xFFFFFFFF, key >> 32)
+    x, y, z, w = philox4x32_10(n_idx >> 1, run, frame, pol, key & 0xFFFFFFFF, key >> 32)
+    odd = (n_idx & 1).astype(bool)
     u = lambda v: ((v >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
     lev = lambda uu: (uu[:, None] >= cdf[None, :-1].astype(np.float32)).sum(1)
-    return lev(u(x)), lev(u(y))
+    return lev(u(np.where(odd, z, x))), lev(u(np.where(odd, w, y)))
 
 
 @pytest.mark.parametrize("mod,nu,channel", [("64-QAM", 0.0270955, "h0"), ("16-QAM", 0.0, "h1")])
@@ -38,9 +40,9 @@ def test_hip_generator_matches_numpy_chain(mod, nu, channel):
     theta = np.array([0.3, 0.9, -0.4])
     SNR = np.array([23.0, 18.0, 30.0], np.float32)
     rx, data, sigma = ch.generate_batch_hip(R, N, amps, P, SNR, h_ch, DP["symb_rate"], sps, DP["tau_cd"], DP["tau_pmd"], DP["phiIQ"], theta,
-                                            "cuda:0", seed, frame, return_sigma=True)
+                                            "cuda:0", seed, frame, return_sigma=True, fft="exact")
     rx2, data2 = ch.generate_batch_hip(R, N, amps, P, SNR, h_ch, DP["symb_rate"], sps, DP["tau_cd"], DP["tau_pmd"], DP["phiIQ"], theta,
-                                       "cuda:0", seed, frame)
+                                       "cuda:0", seed, frame, fft="exact")
     assert torch.equal(rx, rx2) and torch.equal(data, data2)                    # deterministic in (seed, frame, run)
     geo = ch.dp_frame_geometry(N, h_ch, sps)
     cdf = np.cumsum(P)
@@ -62,7 +64,8 @@ def test_hip_generator_matches_numpy_chain(mod, nu, channel):
         assert abs(np.corrcoef(noise[:, 0].ravel(), noise[:, 1].ravel())[0, 1]) < 0.08
         assert np.abs(noise).max() < 6 * sig_n                                                        # the clean part matches to << sigma
     # different frames / seeds give different data
-    rx3, _ = ch.generate_batch_hip(R, N, amps, P, SNR, h_ch, DP["symb_rate"], sps, DP["tau_cd"], DP["tau_pmd"], DP["phiIQ"], theta, "cuda:0", seed, frame + 1)
+    rx3, _ = ch.generate_batch_hip(R, N, amps, P, SNR, h_ch, DP["symb_rate"], sps, DP["tau_cd"], DP["tau_pmd"], DP["phiIQ"], theta, "cuda:0", seed, frame + 1,
+                                   fft="exact")
     assert not torch.equal(rx, rx3)
 
 
@@ -70,7 +73,8 @@ def test_hip_generator_clean_signal_accuracy():
     """With SNR = 200 dB the noise vanishes: rx == numpy chain to c64-FFT accuracy."""
     sps, N, seed, frame = 2, 512, 3, 0
     h_est, h_ch, P, amp_levels, amps, pol, nu_sc, var, pow_mean = sfun.init("h1", "64-QAM", "cpu", 0.0872449, sps, 25, 23)
-    rx, data = ch.generate_batch_hip(1, N, amps, P, 200.0, h_ch, DP["symb_rate"], sps, DP["tau_cd"], DP["tau_pmd"], DP["phiIQ"], 0.7, "cuda:0", seed, frame)
+    rx, data = ch.generate_batch_hip(1, N, amps, P, 200.0, h_ch, DP["symb_rate"], sps, DP["tau_cd"], DP["tau_pmd"], DP["phiIQ"], 0.7, "cuda:0", seed, frame,
+                                      fft="exact")
     geo = ch.dp_frame_geometry(N, h_ch, sps)
     lev = np.stack([np.stack(host_symbols(seed, frame, 0, p, np.arange(geo["N_conv"]), np.cumsum(P))) for p in range(2)])
     sym = np.asarray(amps, np.float32)[lev]
@@ -81,6 +85,22 @@ def test_hip_generator_clean_signal_accuracy():
     got = rx[0].cpu().numpy()
     ref = np.stack([clean[:, :sps * N].real, clean[:, :sps * N].imag], 1)
     assert np.max(np.abs(got - ref)) < 2e-5 * np.max(np.abs(ref)) + 1e-5
+
+
+def test_hip_generator_padded_fft_differs_only_at_the_frame_edges():
+    """fft="padded" (fast FFT length, linear filtering) vs fft="exact" (the reference's circular filtering over Ls): same symbols,
+    same noise; the clean signals differ only within the dispersion's impulse-response length of the frame edges."""
+    sps, N, seed, frame = 2, 4000, 11, 2
+    h_est, h_ch, P, amp_levels, amps, pol, nu_sc, var, pow_mean = sfun.init("h0", "64-QAM", "cpu", 0.0, sps, 25, 23)
+    args = (2, N, amps, P, 200.0, h_ch, DP["symb_rate"], sps, DP["tau_cd"], DP["tau_pmd"], DP["phiIQ"], np.array([0.3, 1.1]), "cuda:0", seed, frame)
+    rxe, de = ch.generate_batch_hip(*args, fft="exact")
+    rxp, dp_ = ch.generate_batch_hip(*args, fft="padded")
+    assert torch.equal(de, dp_)
+    e, p = rxe.cpu().numpy(), rxp.cpu().numpy()
+    scale = np.abs(e).max()
+    assert np.max(np.abs(e - p)[..., 64:-64]) < 1e-3 * scale                   # interior: equal up to the tails of the response
+    assert np.max(np.abs(e - p)) < 0.5 * scale                                 # edges: wrapped-around vs. absent neighbours
+    assert ch.fast_fft_len(20034 + 64) == 20480 and ch.fast_fft_len(1024) == 1024 and ch.fast_fft_len(1025) == 1280
 
 
 def test_generated_frames_train():

@@ -107,11 +107,11 @@ def lib():
         L.vaeq_dp_epilogue_ws_bytes.restype = C.c_int64
         L.vaeq_dp_epilogue_ws_bytes.argtypes = [C.c_int32, C.c_int64]
         L.vaeq_gen_dp_tx.restype = C.c_int
-        L.vaeq_gen_dp_tx.argtypes = [C.c_int32] * 8 + [C.c_void_p] * 3 + [C.c_uint64, C.c_uint32] + [C.c_void_p] * 3
+        L.vaeq_gen_dp_tx.argtypes = [C.c_int32] * 9 + [C.c_void_p] * 3 + [C.c_uint64, C.c_uint32] + [C.c_void_p] * 3
         L.vaeq_gen_dp_disperse.restype = C.c_int
-        L.vaeq_gen_dp_disperse.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double] + [C.c_float] * 4 + [C.c_void_p] * 3
+        L.vaeq_gen_dp_disperse.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double] + [C.c_float] * 5 + [C.c_void_p] * 3
         L.vaeq_gen_dp_finish.restype = C.c_int
-        L.vaeq_gen_dp_finish.argtypes = [C.c_int32] * 4 + [C.c_void_p, C.c_uint64, C.c_uint32] + [C.c_void_p] * 5
+        L.vaeq_gen_dp_finish.argtypes = [C.c_int32] * 5 + [C.c_void_p, C.c_uint64, C.c_uint32] + [C.c_void_p] * 5
         if hasattr(L, "vaeq_awgn_train"):
             L.vaeq_awgn_train.restype = C.c_int
             L.vaeq_awgn_train.argtypes = [C.POINTER(AWGNArgs), C.c_void_p]

@@ -207,10 +207,26 @@ def dp_frame_geometry(N, h_channel, sps):
     return dict(g=g, Lg=Lg, N_conv=N_conv, Ls=Ls, ref_offset=T + Lc - 1)
 
 
+def fast_fft_len(n):
+    """Smallest m * 2^a >= n with m in {1, 3, 5}: lengths hipFFT runs as one radix-2/4/8-dominated kernel chain (measured on MI355X
+    for [2048, 2, L] c2c: L = 20480 takes 1.6 ms per fft+ifft, 20250 = 2*3^4*5^3 3.3 ms, the Bluestein length 20034 6.6 ms)."""
+    best = None
+    for m in (1, 3, 5):
+        v = m
+        while v < n:
+            v *= 2
+        best = v if best is None else min(best, v)
+    return best
+
+
 def generate_batch_hip(R, N, amps, P, SNR, h_channel, symb_rate, sps, tau_cd, tau_pmd, phiIQ, theta, device, seed, frame, chunk=2048,
-                       return_sigma=False):
+                       return_sigma=False, fft="padded"):
     """The DP channel model for R runs on the device with the HIP generator kernels + hipFFT (torch.fft) between the stages.
 
+    fft: "exact"  -- dispersion applied on the FFT of the exact sequence length Ls like the reference (circular filtering; Ls = 20457
+                     for the default frame is 3*3*2273, which costs hipFFT a Bluestein transform: ~6x the time of everything else);
+         "padded" -- rows zero-padded to the next {1,3,5} * 2^a length >= Ls + 64 (linear filtering): the dispersion's impulse response
+                     spans a few samples, so only samples that close to the frame edges differ from "exact".
     Deterministic in (seed, frame, run): counter-based Philox streams.  Returns (rx[R,2,2,sps*N] f32, data[R,2,2,N] f16[, sigma_n[R]])."""
     import ctypes as C
 
@@ -231,23 +247,26 @@ def generate_batch_hip(R, N, amps, P, SNR, h_channel, symb_rate, sps, tau_cd, ta
     sigma = torch.empty(R, dtype=torch.float32, device=dev)
     L = nat.lib()
     st = nat.current_stream(dev)
+    if fft not in ("exact", "padded"):
+        raise ValueError(f"fft must be 'exact' or 'padded', got {fft!r}")
+    Lrow = geo["Ls"] if fft == "exact" else fast_fft_len(geo["Ls"] + 64)
     with torch.cuda.device(dev):
         for r0 in range(0, R, chunk):
             r1 = min(R, r0 + chunk)
             Rc = r1 - r0
-            sig = torch.empty(Rc, 2, geo["Ls"], dtype=torch.complex64, device=dev)
+            sig = torch.empty(Rc, 2, Lrow, dtype=torch.complex64, device=dev)
             # the run index seen by the kernels is r0 + local run: fold r0 into the frame word would break determinism, so the
             # kernels get run-offset pointers and a seed that already encodes the chunk start
-            nat.check(L.vaeq_gen_dp_tx(Rc, N, geo["N_conv"], sps, n, geo["Lg"], geo["Ls"], geo["ref_offset"], nat.ptr(amp_t),
+            nat.check(L.vaeq_gen_dp_tx(Rc, N, geo["N_conv"], sps, n, geo["Lg"], geo["Ls"], Lrow, geo["ref_offset"], nat.ptr(amp_t),
                                        nat.ptr(cdf[r0:r1].contiguous()), nat.ptr(g_t), C.c_uint64(_mix_seed(seed, r0)), C.c_uint32(frame),
                                        C.c_void_p(sig.data_ptr()), nat.ptr(data[r0:r1], torch.float16), st), "vaeq_gen_dp_tx")
-            spec = torch.fft.fft(sig, dim=-1)
-            nat.check(L.vaeq_gen_dp_disperse(Rc, geo["Ls"], float(symb_rate) * sps, float(tau_cd), float(tau_pmd), float(e[0].real),
-                                             float(e[0].imag), float(e[1].real), float(e[1].imag), nat.ptr(th[r0:r1].contiguous()),
+            spec = torch.fft.fft(sig, dim=-1, out=sig)
+            nat.check(L.vaeq_gen_dp_disperse(Rc, Lrow, float(symb_rate) * sps, float(tau_cd), float(tau_pmd), float(e[0].real),
+                                             float(e[0].imag), float(e[1].real), float(e[1].imag), 1.0 / Lrow, nat.ptr(th[r0:r1].contiguous()),
                                              C.c_void_p(spec.data_ptr()), st), "vaeq_gen_dp_disperse")
-            sig = torch.fft.ifft(spec, dim=-1)
+            sig = torch.fft.ifft(spec, dim=-1, norm="forward", out=spec)              # 1/Lrow already applied by the disperse kernel
             pw = torch.empty(Rc, dtype=torch.float32, device=dev)
-            nat.check(L.vaeq_gen_dp_finish(Rc, N, sps, geo["Ls"], nat.ptr(snr[r0:r1].contiguous()), C.c_uint64(_mix_seed(seed, r0)),
+            nat.check(L.vaeq_gen_dp_finish(Rc, N, sps, geo["Ls"], Lrow, nat.ptr(snr[r0:r1].contiguous()), C.c_uint64(_mix_seed(seed, r0)),
                                            C.c_uint32(frame), C.c_void_p(sig.data_ptr()), nat.ptr(pw), nat.ptr(rx[r0:r1]),
                                            nat.ptr(sigma[r0:r1]), st), "vaeq_gen_dp_finish")
     return (rx, data, sigma) if return_sigma else (rx, data)

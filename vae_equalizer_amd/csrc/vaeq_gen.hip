@@ -18,6 +18,7 @@
 
 #include "vaeq.h"
 #include "vaeq_common.h"
+#include "vaeq_wave.h"
 
 namespace vaeq {
 
@@ -39,53 +40,113 @@ __host__ __device__ inline float u01(uint32_t x) { return ((x >> 8) + 0.5f) * (1
 
 enum { STREAM_SYMBOLS = 0, STREAM_NOISE = 1 };
 
-// level index of symbol n of (run, pol): inverse CDF of the PCS pmf on u ~ U(0,1); x -> I, y -> Q
-__device__ __forceinline__ void draw_symbol(uint64_t seed, uint32_t frame, uint32_t run, int pol, uint32_t n, const float *cdf, int n_lev,
-                                            int &li, int &lq)
+// level indices of symbols n (even) and n + 1 of (run, pol): one Philox call, inverse CDF of the PCS pmf on u ~ U(0,1)
+__device__ __forceinline__ void draw_symbol_pair(uint64_t seed, uint32_t frame, uint32_t run, int pol, uint32_t n_even, const float *cdf,
+                                                 int n_lev, int (&lv)[4])      // (I_n, Q_n, I_n+1, Q_n+1)
 {
-    const Philox4 r = philox4x32_10(n, run, frame, (uint32_t)(STREAM_SYMBOLS * 2 + pol), (uint32_t)seed, (uint32_t)(seed >> 32));
-    const float ui = u01(r.x), uq = u01(r.y);
-    li = 0; lq = 0;
-    for (int i = 0; i < n_lev - 1; i++) { li += ui >= cdf[i]; lq += uq >= cdf[i]; }
+    const Philox4 r = philox4x32_10(n_even >> 1, run, frame, (uint32_t)(STREAM_SYMBOLS * 2 + pol), (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float u[4] = {u01(r.x), u01(r.y), u01(r.z), u01(r.w)};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        lv[c] = 0;
+        for (int i = 0; i < n_lev - 1; i++) lv[c] += u[c] >= cdf[i];
+    }
 }
 
-constexpr int TX_TILE = 1024, TX_NT = 256, TX_MAXG = 96;
+constexpr int TX_TILE = 2048, TX_NT = 256, TX_MAXG = 96, TX_SYMPH = (TX_TILE / 2 + TX_MAXG / 2 + 16) / 4 + 1, TX_GLO = 24, TX_GHI = 8;
 
-// stage 1: sig[r][p][s] = sum_k g[k] * up[s + Lg-1-k],  up[j] = symbol[j/sps] if j % sps == 0 else 0   (np.convolve 'valid')
-__global__ __launch_bounds__(TX_NT) void gen_tx_kernel(int N_conv, int sps, int n_lev, int Lg, int Ls, const float *__restrict__ amp,
+// stage 1 (sps == 2): sig[r][p][s] = sum_n sym[n] g[s + Lg-1 - 2n]   (np.convolve 'valid' of the zero-stuffed symbols with g), s < Ls;
+// zeros for Ls <= s < Lrow (row padding for a fast FFT length).  One tile = 2048 samples; the tile's symbols are drawn into LDS
+// (4-way polyphase) and -- for the symbols the tile owns -- written out as the TX reference data[r][p][c][n - ref_lo] (fp16).
+// Thread t computes the 8 consecutive samples 8t..8t+7: per symbol one LDS read feeds 8 complex MACs; the taps g[kb-6 .. kb+7] of
+// four consecutive symbols come from 14 broadcast reads.
+__global__ __launch_bounds__(TX_NT) void gen_tx_kernel(int N_conv, int n_lev, int Lg, int Ls, int Lrow, const float *__restrict__ amp,
                                                        const float *__restrict__ cdf_g, const float2 *__restrict__ g, uint64_t seed,
-                                                       uint32_t frame, int npol, float2 *__restrict__ sig)
+                                                       uint32_t frame, int npol, float2 *__restrict__ sig, int N, int ref_lo,
+                                                       __half *__restrict__ data)
 {
-    __shared__ float2 sym[(TX_TILE + TX_MAXG) / 2 + 4];
-    __shared__ float2 gs[TX_MAXG];
+    __shared__ float2 sym[4 * TX_SYMPH];
+    __shared__ float2 gsp[TX_GLO + TX_MAXG + TX_GHI];
     __shared__ float cdf[8];
+    __shared__ float amps[8];
     const int run = blockIdx.z, pol = blockIdx.y, s0 = blockIdx.x * TX_TILE, tid = threadIdx.x;
-    if (tid < n_lev) cdf[tid] = cdf_g[(size_t)run * n_lev + tid];
-    for (int i = tid; i < Lg; i += TX_NT) gs[i] = g[i];
-    __syncthreads();
-    // symbols touched by this tile: up-index j in [s0, s0 + TILE + Lg - 1)  ->  n in [ceil(s0/sps), ...]
-    const int nlo = (s0 + sps - 1) / sps, nhi = min(N_conv - 1, (s0 + TX_TILE + Lg - 2) / sps);
-    for (int n = nlo + tid; n <= nhi; n += TX_NT) {
-        int li, lq;
-        draw_symbol(seed, frame, run, pol, n, cdf, n_lev, li, lq);
-        sym[n - nlo] = make_float2(amp[li], amp[lq]);
+    if (tid < n_lev) { cdf[tid] = cdf_g[(size_t)run * n_lev + tid]; amps[tid] = amp[tid]; }
+    for (int i = tid; i < TX_GLO + TX_MAXG + TX_GHI; i += TX_NT) {
+        const int k = i - TX_GLO;
+        gsp[i] = (k >= 0 && k < Lg) ? g[k] : make_float2(0.f, 0.f);
     }
     __syncthreads();
-    for (int s = s0 + tid; s < min(Ls, s0 + TX_TILE); s += TX_NT) {
+    const int nlo = s0 / 2;                                                    // even (TX_TILE / 2 is)
+    const int cnt = TX_TILE / 2 + (Lg + 7) / 2 + 8;                            // symbols this tile may touch (<= 4 * TX_SYMPH)
+    const bool last = s0 + TX_TILE >= Lrow;
+    __half *dI = data ? data + ((size_t)(run * npol + pol) * 2 + 0) * N : nullptr, *dQ = dI ? dI + N : nullptr;
+    for (int pi = tid; 2 * pi < cnt; pi += TX_NT) {
+        const int n = nlo + 2 * pi;
+        int lv[4];
+        draw_symbol_pair(seed, frame, run, pol, (uint32_t)n, cdf, n_lev, lv);
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int ne = n + e, m = 2 * pi + e;
+            const bool in = ne < N_conv;
+            const float aI = amps[lv[2 * e]], aQ = amps[lv[2 * e + 1]];
+            sym[(m & 3) * TX_SYMPH + (m >> 2)] = in ? make_float2(aI, aQ) : make_float2(0.f, 0.f);
+            const int nr = ne - ref_lo;
+            if (dI && in && nr >= 0 && nr < N && (m < TX_TILE / 2 || last)) {   // each symbol is owned by exactly one tile
+                dI[nr] = __float2half(aI);
+                dQ[nr] = __float2half(aQ);
+            }
+        }
+    }
+    __syncthreads();
+    const int sb = s0 + 8 * tid;
+    if (sb >= Lrow) return;
+    cacc acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = cacc0();
+    const int MW = ((Lg + 7) / 2 + 1 + 3) & ~3;                                // symbols m = 0 .. MW-1 relative to 4 tid
+    const float2 *gp = gsp + TX_GLO;
+#pragma unroll 1
+    for (int m0 = 0; m0 < MW; m0 += 4) {
+        const int kb = Lg - 1 - 2 * m0;                                        // sample i of symbol m0 + mm uses tap kb - 2 mm + i
+        float2 tp[14];
+#pragma unroll
+        for (int j = 0; j < 14; j++) tp[j] = gp[kb - 6 + j];
+#pragma unroll
+        for (int mm = 0; mm < 4; mm++) {
+            const float2 sv = sym[mm * TX_SYMPH + tid + (m0 >> 2)];
+#pragma unroll
+            for (int i = 0; i < 8; i++) cmac(acc[i], tp[6 - 2 * mm + i].x, tp[6 - 2 * mm + i].y, sv);
+        }
+    }
+    float2 *o = sig + ((size_t)run * npol + pol) * Lrow + sb;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (sb + i < Lrow) o[i] = sb + i < Ls ? cfin(acc[i]) : make_float2(0.f, 0.f);
+}
+
+// any sps: one thread per output sample, symbols and reference drawn per use
+__global__ __launch_bounds__(256) void gen_tx_generic_kernel(int N_conv, int sps, int n_lev, int Lg, int Ls, int Lrow, const float *__restrict__ amp,
+                                                             const float *__restrict__ cdf_g, const float2 *__restrict__ g, uint64_t seed,
+                                                             uint32_t frame, int npol, float2 *__restrict__ sig)
+{
+    const int run = blockIdx.z, pol = blockIdx.y;
+    float cdf[8];
+    for (int i = 0; i < n_lev; i++) cdf[i] = cdf_g[(size_t)run * n_lev + i];
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < Lrow; s += gridDim.x * blockDim.x) {
         float ar = 0.f, ai = 0.f;
-        // j = s + Lg-1-k must be a multiple of sps: k = (s + Lg - 1) - sps*n
-        const int jhi = s + Lg - 1;
-        for (int n = (s + sps - 1) / sps; n * sps <= jhi && n < N_conv; n++) {
-            const int k = jhi - n * sps;
-            const float2 x = sym[n - nlo], c = gs[k];
+        const int jhi = s + Lg - 1;                                            // j = s + Lg-1-k must be a multiple of sps
+        for (int n = (s + sps - 1) / sps; s < Ls && n * sps <= jhi && n < N_conv; n++) {
+            int lv[4];
+            draw_symbol_pair(seed, frame, run, pol, (uint32_t)(n & ~1), cdf, n_lev, lv);
+            const float2 x = make_float2(amp[lv[2 * (n & 1)]], amp[lv[2 * (n & 1) + 1]]), c = g[jhi - n * sps];
             ar = fmaf(c.x, x.x, ar); ar = fmaf(-c.y, x.y, ar);
             ai = fmaf(c.x, x.y, ai); ai = fmaf(c.y, x.x, ai);
         }
-        sig[((size_t)run * npol + pol) * Ls + s] = make_float2(ar, ai);
+        sig[((size_t)run * npol + pol) * Lrow + s] = make_float2(ar, ai);
     }
 }
 
-// TX reference data[r][p][c][n'] = amplitude of symbol n' + lo (shared_funcs.py:89), fp16
+// TX reference data[r][p][c][n'] = amplitude of symbol n' + lo (shared_funcs.py:89), fp16 -- generic-sps companion of the kernel above
 __global__ __launch_bounds__(256) void gen_ref_kernel(int N, int lo, int n_lev, const float *__restrict__ amp, const float *__restrict__ cdf_g,
                                                       uint64_t seed, uint32_t frame, int npol, __half *__restrict__ data)
 {
@@ -93,10 +154,11 @@ __global__ __launch_bounds__(256) void gen_ref_kernel(int N, int lo, int n_lev, 
     float cdf[8];
     for (int i = 0; i < n_lev; i++) cdf[i] = cdf_g[(size_t)run * n_lev + i];
     for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
-        int li, lq;
-        draw_symbol(seed, frame, run, pol, n + lo, cdf, n_lev, li, lq);
-        data[((size_t)(run * npol + pol) * 2 + 0) * N + n] = __float2half(amp[li]);
-        data[((size_t)(run * npol + pol) * 2 + 1) * N + n] = __float2half(amp[lq]);
+        int lv[4];
+        draw_symbol_pair(seed, frame, run, pol, (uint32_t)((n + lo) & ~1), cdf, n_lev, lv);
+        const int e = (n + lo) & 1;
+        data[((size_t)(run * npol + pol) * 2 + 0) * N + n] = __float2half(amp[lv[2 * e]]);
+        data[((size_t)(run * npol + pol) * 2 + 1) * N + n] = __float2half(amp[lv[2 * e + 1]]);
     }
 }
 
@@ -105,7 +167,7 @@ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(
 
 // stage 2: spectrum of both polarisations times H(f) and the CD phase (shared_funcs.py:40-53), in place
 __global__ __launch_bounds__(256) void gen_disperse_kernel(int Ls, double fs_over_Ls, double tau_cd, double tau_pmd, float2 e0, float2 e1,
-                                                           const float *__restrict__ theta, float2 *__restrict__ spec)
+                                                           float scale, const float *__restrict__ theta, float2 *__restrict__ spec)
 {
     const int run = blockIdx.y;
     float st, ct;
@@ -117,7 +179,7 @@ __global__ __launch_bounds__(256) void gen_disperse_kernel(int Ls, double fs_ove
         float sc, cc, sd, cd;
         sincosf((float)(2.0 * pf * pf * tau_cd), &sc, &cc);
         sincosf((float)(pf * tau_pmd), &sd, &cd);
-        const float2 ecd = make_float2(cc, sc), d = make_float2(cd, sd), di = make_float2(cd, -sd);
+        const float2 ecd = make_float2(scale * cc, scale * sc), d = make_float2(cd, sd), di = make_float2(cd, -sd);
         // R = [[c e0, s e0], [-s e1, c e1]],  RT = [[c e0, -s e0], [s e1, c e1]]  (the reference's "R_T", :47-48)
         const float2 ce0 = make_float2(ct * e0.x, ct * e0.y), se0 = make_float2(st * e0.x, st * e0.y);
         const float2 ce1 = make_float2(ct * e1.x, ct * e1.y), se1 = make_float2(st * e1.x, st * e1.y);
@@ -132,81 +194,112 @@ __global__ __launch_bounds__(256) void gen_disperse_kernel(int Ls, double fs_ove
     }
 }
 
-// stage 3a: mean |sig|^2 per run over both polarisations and all Ls samples (:83)
-__global__ __launch_bounds__(256) void gen_power_kernel(int Ls, int npol, const float2 *__restrict__ sig, float *__restrict__ power)
+// stage 3a: mean |sig|^2 per run over all polarisations and the first Ls samples of every (Lrow long) row (:83)
+__global__ __launch_bounds__(256) void gen_power_kernel(int Ls, int Lrow, int npol, const float2 *__restrict__ sig, float *__restrict__ power)
 {
     __shared__ float red[64];
     const int run = blockIdx.x;
-    const float2 *s = sig + (size_t)run * npol * Ls;
     float acc = 0.f;
-    for (int i = threadIdx.x; i < npol * Ls; i += 256) acc += s[i].x * s[i].x + s[i].y * s[i].y;
+    for (int p = 0; p < npol; p++) {
+        const float2 *s = sig + ((size_t)run * npol + p) * Lrow;
+        for (int i = threadIdx.x; i < Ls; i += 256) acc += s[i].x * s[i].x + s[i].y * s[i].y;
+    }
     block_reduce3<256>(acc, 0.f, 0.f, red);
     if (threadIdx.x == 0) power[run] = red[0] / (float)(npol * Ls);
 }
 
-// stage 3b: AWGN + planar split: rx[r][p][0/1][s] = Re/Im(sig + sigma_n (n1 + j n2)), s < sps*N   (:84-88)
-__global__ __launch_bounds__(256) void gen_finish_kernel(int Ls, int Lout, int sps, const float *__restrict__ snr_db, const float *__restrict__ power,
+// stage 3b: AWGN + planar split: rx[r][p][0/1][s] = Re/Im(sig + sigma_n (n1 + j n2)), s < Lout = sps*N (even)   (:84-88)
+// one Philox call -> two Box-Muller pairs -> the noise of two consecutive samples
+__global__ __launch_bounds__(256) void gen_finish_kernel(int Lrow, int Lout, int sps, const float *__restrict__ snr_db, const float *__restrict__ power,
                                                          uint64_t seed, uint32_t frame, int npol, const float2 *__restrict__ sig,
                                                          float *__restrict__ rx, float *__restrict__ sigma_out)
 {
     const int run = blockIdx.z, pol = blockIdx.y;
     const float sigma = sqrtf(power[run] * (float)sps * 0.5f / exp10f(snr_db[run] * 0.1f));
     if (sigma_out && pol == 0 && blockIdx.x == 0 && threadIdx.x == 0) sigma_out[run] = sigma;
-    const float2 *s = sig + ((size_t)run * npol + pol) * Ls;
+    const float2 *s = sig + ((size_t)run * npol + pol) * Lrow;
     float *rI = rx + ((size_t)(run * npol + pol) * 2 + 0) * Lout, *rQ = rI + Lout;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Lout; i += gridDim.x * blockDim.x) {
-        const Philox4 r = philox4x32_10((uint32_t)i, run, frame, (uint32_t)(STREAM_NOISE * 2 + pol), (uint32_t)seed, (uint32_t)(seed >> 32));
-        float sn, cs;                                           // Box-Muller: two independent N(0,1)
-        const float rad = sqrtf(-2.0f * __logf(u01(r.x)));
-        __sincosf(6.283185307179586f * u01(r.y), &sn, &cs);
-        rI[i] = s[i].x + sigma * rad * cs;
-        rQ[i] = s[i].y + sigma * rad * sn;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; 2 * j < Lout; j += gridDim.x * blockDim.x) {
+        const Philox4 r = philox4x32_10((uint32_t)j, run, frame, (uint32_t)(STREAM_NOISE * 2 + pol), (uint32_t)seed, (uint32_t)(seed >> 32));
+        float sn0, cs0, sn1, cs1;                               // Box-Muller: two independent N(0,1) per pair of uniforms
+        const float rad0 = sigma * sqrtf(-2.0f * __logf(u01(r.x))), rad1 = sigma * sqrtf(-2.0f * __logf(u01(r.z)));
+        __sincosf(6.283185307179586f * u01(r.y), &sn0, &cs0);
+        __sincosf(6.283185307179586f * u01(r.w), &sn1, &cs1);
+        const int i = 2 * j;
+        rI[i] = s[i].x + rad0 * cs0;
+        rQ[i] = s[i].y + rad0 * sn0;
+        if (i + 1 < Lout) {
+            rI[i + 1] = s[i + 1].x + rad1 * cs1;
+            rQ[i + 1] = s[i + 1].y + rad1 * sn1;
+        }
     }
+}
+
+// launches of stage 1 / stage 3 shared by the DP and the AWGN entry points
+static void launch_tx(int R, int npol, int N, int N_conv, int sps, int n_lev, int Lg, int Ls, int Lrow, int ref_offset, const float *amp,
+                      const float *cdf, const float2 *g, uint64_t seed, uint32_t frame, float2 *sig, __half *data, hipStream_t st)
+{
+    if (sps == 2) {
+        hipLaunchKernelGGL(gen_tx_kernel, dim3((Lrow + TX_TILE - 1) / TX_TILE, npol, R), dim3(TX_NT), 0, st, N_conv, n_lev, Lg, Ls, Lrow, amp, cdf,
+                           g, seed, frame, npol, sig, N, ref_offset, data);
+        return;
+    }
+    hipLaunchKernelGGL(gen_tx_generic_kernel, dim3((Lrow + 255) / 256 > 64 ? 64 : (Lrow + 255) / 256, npol, R), dim3(256), 0, st, N_conv, sps, n_lev,
+                       Lg, Ls, Lrow, amp, cdf, g, seed, frame, npol, sig);
+    if (data)
+        hipLaunchKernelGGL(gen_ref_kernel, dim3((N + 255) / 256 > 64 ? 64 : (N + 255) / 256, npol, R), dim3(256), 0, st, N, ref_offset, n_lev, amp,
+                           cdf, seed, frame, npol, data);
+}
+
+static void launch_finish(int R, int npol, int N, int sps, int Ls, int Lrow, const float *snr_db, uint64_t seed, uint32_t frame,
+                          const float2 *sig, float *power_ws, float *rx, float *sigma_out, hipStream_t st)
+{
+    const int Lout = sps * N, nj = (Lout + 1) / 2;
+    hipLaunchKernelGGL(gen_power_kernel, dim3(R), dim3(256), 0, st, Ls, Lrow, npol, sig, power_ws);
+    hipLaunchKernelGGL(gen_finish_kernel, dim3((nj + 255) / 256 > 64 ? 64 : (nj + 255) / 256, npol, R), dim3(256), 0, st, Lrow, Lout, sps, snr_db,
+                       power_ws, seed, frame, npol, sig, rx, sigma_out);
 }
 
 }  // namespace vaeq
 
-extern "C" int vaeq_gen_dp_tx(int32_t R, int32_t N, int32_t N_conv, int32_t sps, int32_t n_lev, int32_t Lg, int32_t Ls, int32_t ref_offset,
-                              const float *amp, const float *cdf, const float *g_complex, uint64_t seed, uint32_t frame,
+static bool tx_shape_ok(int R, int N, int N_conv, int sps, int n_lev, int Lg, int Ls, int Lrow, int ref_offset)
+{
+    if (R < 0 || N <= 0 || sps <= 0 || Lg <= 0 || Lg > vaeq::TX_MAXG || !(n_lev == 2 || n_lev == 4 || n_lev == 8) || ref_offset < 0) return false;
+    return Ls == sps * (N_conv - 1) + 1 - Lg + 1 && ref_offset + N <= N_conv && Ls >= sps * N && Lrow >= Ls;   // np.convolve 'valid' length
+}
+
+extern "C" int vaeq_gen_dp_tx(int32_t R, int32_t N, int32_t N_conv, int32_t sps, int32_t n_lev, int32_t Lg, int32_t Ls, int32_t Lrow,
+                              int32_t ref_offset, const float *amp, const float *cdf, const float *g_complex, uint64_t seed, uint32_t frame,
                               float *sig_complex, void *data_f16, void *stream)
 {
     if (!amp || !cdf || !g_complex || !sig_complex) return VAEQ_ERR_NULL;
-    if (R < 0 || N <= 0 || sps <= 0 || Lg <= 0 || Lg > vaeq::TX_MAXG || !(n_lev == 2 || n_lev == 4 || n_lev == 8) || ref_offset < 0)
-        return VAEQ_ERR_SHAPE;
-    if (Ls != sps * (N_conv - 1) + 1 - Lg + 1 || ref_offset + N > N_conv || Ls < sps * N) return VAEQ_ERR_SHAPE;   // np.convolve 'valid' length
+    if (!tx_shape_ok(R, N, N_conv, sps, n_lev, Lg, Ls, Lrow, ref_offset)) return VAEQ_ERR_SHAPE;
     if (R == 0) return VAEQ_OK;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(vaeq::gen_tx_kernel, dim3((Ls + vaeq::TX_TILE - 1) / vaeq::TX_TILE, 2, R), dim3(vaeq::TX_NT), 0, st, N_conv, sps, n_lev, Lg,
-                       Ls, amp, cdf, reinterpret_cast<const float2 *>(g_complex), seed, frame, 2, reinterpret_cast<float2 *>(sig_complex));
-    if (data_f16)
-        hipLaunchKernelGGL(vaeq::gen_ref_kernel, dim3((N + 255) / 256 > 64 ? 64 : (N + 255) / 256, 2, R), dim3(256), 0, st, N, ref_offset, n_lev,
-                           amp, cdf, seed, frame, 2, reinterpret_cast<__half *>(data_f16));
+    vaeq::launch_tx(R, 2, N, N_conv, sps, n_lev, Lg, Ls, Lrow, ref_offset, amp, cdf, reinterpret_cast<const float2 *>(g_complex), seed, frame,
+                    reinterpret_cast<float2 *>(sig_complex), reinterpret_cast<__half *>(data_f16), reinterpret_cast<hipStream_t>(stream));
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
 
 extern "C" int vaeq_gen_dp_disperse(int32_t R, int32_t Ls, double fs, double tau_cd, double tau_pmd, float e0_re, float e0_im, float e1_re,
-                                    float e1_im, const float *theta, float *spec_complex, void *stream)
+                                    float e1_im, float scale, const float *theta, float *spec_complex, void *stream)
 {
     if (!theta || !spec_complex) return VAEQ_ERR_NULL;
     if (R < 0 || Ls <= 0) return VAEQ_ERR_SHAPE;
     if (R == 0) return VAEQ_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(vaeq::gen_disperse_kernel, dim3((Ls + 255) / 256, R), dim3(256), 0, st, Ls, fs / (double)Ls, tau_cd, tau_pmd,
-                       make_float2(e0_re, e0_im), make_float2(e1_re, e1_im), theta, reinterpret_cast<float2 *>(spec_complex));
+                       make_float2(e0_re, e0_im), make_float2(e1_re, e1_im), scale, theta, reinterpret_cast<float2 *>(spec_complex));
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
 
-extern "C" int vaeq_gen_dp_finish(int32_t R, int32_t N, int32_t sps, int32_t Ls, const float *snr_db, uint64_t seed, uint32_t frame,
+extern "C" int vaeq_gen_dp_finish(int32_t R, int32_t N, int32_t sps, int32_t Ls, int32_t Lrow, const float *snr_db, uint64_t seed, uint32_t frame,
                                   const float *sig_complex, float *power_ws, float *rx, float *sigma_out, void *stream)
 {
     if (!snr_db || !sig_complex || !power_ws || !rx) return VAEQ_ERR_NULL;
-    if (R < 0 || N <= 0 || sps <= 0 || Ls < sps * N) return VAEQ_ERR_SHAPE;
+    if (R < 0 || N <= 0 || sps <= 0 || Ls < sps * N || Lrow < Ls) return VAEQ_ERR_SHAPE;
     if (R == 0) return VAEQ_OK;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int Lout = sps * N;
-    hipLaunchKernelGGL(vaeq::gen_power_kernel, dim3(R), dim3(256), 0, st, Ls, 2, reinterpret_cast<const float2 *>(sig_complex), power_ws);
-    hipLaunchKernelGGL(vaeq::gen_finish_kernel, dim3((Lout + 255) / 256 > 64 ? 64 : (Lout + 255) / 256, 2, R), dim3(256), 0, st, Ls, Lout, sps,
-                       snr_db, power_ws, seed, frame, 2, reinterpret_cast<const float2 *>(sig_complex), rx, sigma_out);
+    vaeq::launch_finish(R, 2, N, sps, Ls, Lrow, snr_db, seed, frame, reinterpret_cast<const float2 *>(sig_complex), power_ws, rx, sigma_out,
+                        reinterpret_cast<hipStream_t>(stream));
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
 
@@ -219,20 +312,12 @@ extern "C" int vaeq_gen_awgn(int32_t R, int32_t N, int32_t N_conv, int32_t sps, 
                              float *sig_ws, float *power_ws, float *rx, void *data_f16, float *sigma_out, void *stream)
 {
     if (!amp || !cdf || !g_complex || !snr_db || !sig_ws || !power_ws || !rx) return VAEQ_ERR_NULL;
-    if (R < 0 || N <= 0 || sps <= 0 || Lg <= 0 || Lg > vaeq::TX_MAXG || !(n_lev == 2 || n_lev == 4 || n_lev == 8) || ref_offset < 0)
-        return VAEQ_ERR_SHAPE;
-    if (Ls != sps * (N_conv - 1) + 1 - Lg + 1 || ref_offset + N > N_conv || Ls < sps * N) return VAEQ_ERR_SHAPE;
+    if (!tx_shape_ok(R, N, N_conv, sps, n_lev, Lg, Ls, Ls, ref_offset)) return VAEQ_ERR_SHAPE;
     if (R == 0) return VAEQ_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int Lout = sps * N;
     float2 *sig = reinterpret_cast<float2 *>(sig_ws);
-    hipLaunchKernelGGL(vaeq::gen_tx_kernel, dim3((Ls + vaeq::TX_TILE - 1) / vaeq::TX_TILE, 1, R), dim3(vaeq::TX_NT), 0, st, N_conv, sps, n_lev, Lg,
-                       Ls, amp, cdf, reinterpret_cast<const float2 *>(g_complex), seed, frame, 1, sig);
-    if (data_f16)
-        hipLaunchKernelGGL(vaeq::gen_ref_kernel, dim3((N + 255) / 256 > 64 ? 64 : (N + 255) / 256, 1, R), dim3(256), 0, st, N, ref_offset, n_lev,
-                           amp, cdf, seed, frame, 1, reinterpret_cast<__half *>(data_f16));
-    hipLaunchKernelGGL(vaeq::gen_power_kernel, dim3(R), dim3(256), 0, st, Ls, 1, sig, power_ws);
-    hipLaunchKernelGGL(vaeq::gen_finish_kernel, dim3((Lout + 255) / 256 > 64 ? 64 : (Lout + 255) / 256, 1, R), dim3(256), 0, st, Ls, Lout, sps,
-                       snr_db, power_ws, seed, frame, 1, sig, rx, sigma_out);
+    vaeq::launch_tx(R, 1, N, N_conv, sps, n_lev, Lg, Ls, Ls, ref_offset, amp, cdf, reinterpret_cast<const float2 *>(g_complex), seed, frame, sig,
+                    reinterpret_cast<__half *>(data_f16), st);
+    vaeq::launch_finish(R, 1, N, sps, Ls, Ls, snr_db, seed, frame, sig, power_ws, rx, sigma_out, st);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
