@@ -83,6 +83,11 @@ typedef struct vaeq_dp_args {
     float *y_out;        /* nullable [R][n_frames][2][2][steps*keep_len]        out_const */
     float *loss;         /* nullable [R][n_frames][steps]                        ELBO per minibatch */
     float *var_est;      /* nullable [R][n_frames][2][steps]                     C/(N-Mh) per minibatch */
+    float *eq_out;       /* nullable [R][n_frames][2][steps*keep_len]   E_q[x_I] per polarisation: all find_shift reads of q
+                            (shared_funcs.py:296-297) */
+    int8_t *dec_out;     /* nullable [R][n_frames][2][2][steps*keep_len] argmax_i q_i per axis: all SER_IQflip reads of q (:201).
+                            With eq_out + dec_out the per-frame epilogue needs no q: q_out may be NULL (32 of the 44 floats a
+                            DP symbol costs in HBM are the materialised q) */
     float *dbg_gW;       /* nullable [R][2][4][M]     gradient of the LAST step (parity tests) */
     float *dbg_gh;       /* nullable [R][2][2][2][M] */
     int32_t threads;     /* kernel choice: 0 = automatic (wave-per-run fast path when the shape allows, else generic/256);
@@ -193,6 +198,11 @@ int vaeq_dp_epilogue(int32_t R, int64_t N, int32_t n_lev, int32_t batch_len, con
                      const float *amp, const float *var, const float *nu_sc, float *ser, int32_t *shift, int32_t *rflag,
                      void *workspace, void *stream);
 int64_t vaeq_dp_epilogue_ws_bytes(int32_t R, int64_t N);
+/* Same epilogue fed by the training kernel's compact outputs instead of q: eq[R][2][N] (vaeq_dp_args.eq_out) and dec[R][2][2][N]
+ * (dec_out) of ONE frame; results are bit-identical to vaeq_dp_epilogue on the q of the same call. */
+int vaeq_dp_epilogue_compact(int32_t R, int64_t N, int32_t n_lev, int32_t batch_len, const float *eq, const int8_t *dec, const float *y,
+                             const void *tx_f16, const float *amp, const float *var, const float *nu_sc, float *ser, int32_t *shift,
+                             int32_t *r_flag, void *stream);
 
 /* ------------------------------------------------------------------------
  * Seeded on-device DP channel simulator (input producer): optical_DP_channel/shared_funcs.py:65-90 in three stages with

@@ -234,3 +234,46 @@ def test_wave_kernel_refused_for_unsupported_shape():
     eng = DPEngine(1, int(g["M_est"]), g["amp_levels"], g["P"], g["var"], float(g["nu_sc"]), DEV, 2, threads=1)
     with pytest.raises(nat.VaeqError):
         eng.train(torch.from_numpy(g["rx"][None]).to(DEV), int(g["B"]), 1, 1e-3)
+
+
+# ------------------------------------------------------------------ compact epilogue inputs (eq_out / dec_out)
+@pytest.mark.parametrize("threads", [1, 256])
+@pytest.mark.parametrize("flex", [False, True])
+def test_compact_outputs_equal_what_the_epilogue_derives_from_q(threads, flex):
+    """eq_out = E_q[x_I] and dec_out = argmax(q) written by the training kernel are bit-identical to the values the epilogue computes
+    from the materialised q of the same call, so vaeq_dp_epilogue_compact returns exactly vaeq_dp_epilogue's SER / shifts -- with
+    or without q being written at all."""
+    from vae_equalizer_amd import channel as ch, shared_funcs as sfun
+    from vae_equalizer_amd.engine import DPEngine, dp_epilogue, dp_epilogue_compact
+    R, B, M, sps, N = 5, 100, 25, 2, 3000
+    t = sfun.qam_tables("64-QAM", 0.0270955)
+    h_ch = sfun.upsampled_channel("h0", sps)
+    var = t["pow_mean"] / 10 ** 2.3 / 2
+    rx, data = ch.generate_batch_hip(R, N, t["amps"], t["P"], 23.0, h_ch, 90e9, sps, -26e-24, 0.1e-12 * np.sqrt(1000),
+                                     np.array([0.0314, 0.0314], np.complex64), np.linspace(0.1, 1.2, R), DEV, 5, 0)
+    if flex:
+        stride, klen, k0 = 10, 10, (B - 10) // 2
+        steps = (N - B) // stride
+        data = data[:, :, :, B // 2:steps * stride + B // 2]
+    else:
+        stride, klen, k0, steps = B, B, 0, N // B
+    outs = []
+    for want_q in (True, False):
+        eng = DPEngine(R, M, t["amps"], t["P"], [var, var], t["nu_sc"], DEV, sps, threads)
+        outs.append(eng.train(rx, B, steps, 2.5e-3, stride=stride, keep_off=k0, keep_len=klen, want_q=want_q, want_compact=True))
+    torch.cuda.synchronize()
+    a, b = outs
+    assert b["q"] is None and torch.equal(a["eq"], b["eq"]) and torch.equal(a["dec"], b["dec"]) and torch.equal(a["y"], b["y"])
+    q = a["q"][:, 0]
+    n = q.shape[2] // 2
+    amp = torch.tensor(t["amps"], dtype=torch.float32, device=DEV)
+    assert torch.equal(a["dec"][:, 0].long(), torch.stack([q[:, 0, :n].argmax(1), q[:, 0, n:].argmax(1), q[:, 1, :n].argmax(1),
+                                                           q[:, 1, n:].argmax(1)], 1).reshape(R, 2, 2, -1))
+    assert relerr(a["eq"][:, 0].cpu().numpy(), torch.einsum("i,rpin->rpn", amp, q[:, :, :n]).cpu().numpy()) < 1e-6
+    nu = torch.full((R,), float(t["nu_sc"]), device=DEV)
+    varr = torch.full((R, 2), var, device=DEV)
+    bl = None if flex else B
+    ref = dp_epilogue(q, a["y"][:, 0], data, amp, nu, varr, bl)
+    got = dp_epilogue_compact(b["eq"][:, 0], b["dec"][:, 0], b["y"][:, 0], data, amp, nu, varr, bl)
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), k

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 from vae_equalizer_amd import channel as ch, epilogue as epi, shared_funcs as sfun
-from vae_equalizer_amd.engine import DPEngine, dp_epilogue
+from vae_equalizer_amd.engine import DPEngine, dp_epilogue, dp_epilogue_compact
 
 dev = "cuda:0"
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
@@ -21,9 +21,13 @@ for it in range(3):
     t0 = sync()
     rx, data = ch.generate_batch_hip(R, 10000, t["amps"], t["P"], 23.0, h_ch, 90e9, 2, C["tau_cd"], C["tau_pmd"], C["phiIQ"], 0.3, dev, 1, it)
     t1 = sync()
-    out = eng.train(rx, 100, 100, 2.5e-3)
+    compact = len(sys.argv) > 2 and sys.argv[2] == "compact"
+    out = eng.train(rx, 100, 100, 2.5e-3, want_q=not compact, want_compact=compact)
     t2 = sync()
-    res = dp_epilogue(out["q"][:, 0], out["y"][:, 0], data, amp, nu, varr, 100)
+    if compact:
+        res = dp_epilogue_compact(out["eq"][:, 0], out["dec"][:, 0], out["y"][:, 0], data, amp, nu, varr, 100)
+    else:
+        res = dp_epilogue(out["q"][:, 0], out["y"][:, 0], data, amp, nu, varr, 100)
     ser = res["SER"].cpu()
     t3 = sync()
     print(f"R={R} frame {it}: generate {1e3*(t1-t0):8.1f} ms | train {1e3*(t2-t1):8.1f} ms | epilogue {1e3*(t3-t2):8.1f} ms", flush=True)

@@ -49,6 +49,7 @@ class DPArgs(C.Structure):
         ("step", C.c_void_p), ("amp", C.c_void_p), ("P", C.c_void_p), ("var", C.c_void_p), ("nu_sc", C.c_void_p),
         ("lr_W", C.c_void_p), ("lr_h", C.c_void_p),
         ("q_out", C.c_void_p), ("y_out", C.c_void_p), ("loss", C.c_void_p), ("var_est", C.c_void_p),
+        ("eq_out", C.c_void_p), ("dec_out", C.c_void_p),
         ("dbg_gW", C.c_void_p), ("dbg_gh", C.c_void_p),
         ("threads", C.c_int32), ("no_update", C.c_int32),
     ]
@@ -71,7 +72,7 @@ class AWGNArgs(C.Structure):
 
 
 # every symbol include/vaeq.h declares; tests check the library exports all of them
-EXPORTS = ["vaeq_dp_train", "vaeq_dp_lds_bytes", "vaeq_dp_resident_runs", "vaeq_soft_demap", "vaeq_dp_forward", "vaeq_dp_loss", "vaeq_dp_loss_bwd", "vaeq_dp_forward_bwd", "vaeq_dp_epilogue", "vaeq_dp_epilogue_ws_bytes", "vaeq_gen_dp_tx", "vaeq_gen_dp_disperse", "vaeq_gen_dp_finish", "vaeq_awgn_train",
+EXPORTS = ["vaeq_dp_train", "vaeq_dp_lds_bytes", "vaeq_dp_resident_runs", "vaeq_soft_demap", "vaeq_dp_forward", "vaeq_dp_loss", "vaeq_dp_loss_bwd", "vaeq_dp_forward_bwd", "vaeq_dp_epilogue", "vaeq_dp_epilogue_ws_bytes", "vaeq_dp_epilogue_compact", "vaeq_gen_dp_tx", "vaeq_gen_dp_disperse", "vaeq_gen_dp_finish", "vaeq_awgn_train",
            "vaeq_awgn_lds_bytes", "vaeq_awgn_forward", "vaeq_awgn_validate", "vaeq_gen_awgn", "vaeq_version", "vaeq_strerror"]
 
 
@@ -104,6 +105,8 @@ def lib():
         L.vaeq_dp_forward_bwd.argtypes = [C.c_int32] * 5 + [C.c_void_p] * 9
         L.vaeq_dp_epilogue.restype = C.c_int
         L.vaeq_dp_epilogue.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 11
+        L.vaeq_dp_epilogue_compact.restype = C.c_int
+        L.vaeq_dp_epilogue_compact.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 11
         L.vaeq_dp_epilogue_ws_bytes.restype = C.c_int64
         L.vaeq_dp_epilogue_ws_bytes.argtypes = [C.c_int32, C.c_int64]
         L.vaeq_gen_dp_tx.restype = C.c_int

@@ -126,6 +126,8 @@ __global__ __launch_bounds__(NT) void dp_train_kernel(const vaeq_dp_args a)
         const float *rxf = a.rx + ((size_t)run * a.n_frames + f) * 4 * (size_t)a.S;
         float *qf = a.q_out ? a.q_out + ((size_t)run * a.n_frames + f) * (4 * NLEV) * No : nullptr;
         float *yf = a.y_out ? a.y_out + ((size_t)run * a.n_frames + f) * 4 * No : nullptr;
+        float *ef = a.eq_out ? a.eq_out + ((size_t)run * a.n_frames + f) * 2 * No : nullptr;
+        int8_t *df = a.dec_out ? a.dec_out + ((size_t)run * a.n_frames + f) * 4 * No : nullptr;
         for (int s = 0; s < a.steps; s++) {
             // ============ P0: window -> LDS, zero halo of mh samples (Conv1d padding, :494)
             const size_t s0 = (size_t)s * a.stride_sym * sps;
@@ -188,6 +190,17 @@ __global__ __launch_bounds__(NT) void dp_train_kernel(const vaeq_dp_args a)
                     if (qf && kept) {
 #pragma unroll
                         for (int i = 0; i < NLEV; i++) qf[(size_t)(o * 2 * NLEV + c * NLEV + i) * No + col] = z[i];
+                    }
+                    if (kept) {                                 // compact stand-ins for q in the epilogue (same values it would derive)
+                        if (ef && c == 0) ef[(size_t)o * No + col] = m1;
+                        if (df) {
+                            float best = z[0];
+                            int bi = 0;
+#pragma unroll
+                            for (int i = 1; i < NLEV; i++)
+                                if (z[i] > best) { best = z[i]; bi = i; }
+                            df[(size_t)(o * 2 + c) * No + col] = (int8_t)bi;
+                        }
                     }
                     float m2 = 0.0f, m3 = 0.0f, kk = 0.0f;
 #pragma unroll

@@ -179,6 +179,8 @@ __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
     for (int f = 0; f < a.n_frames; f++) {
         float *qf = a.q_out ? a.q_out + ((size_t)run * a.n_frames + f) * (4 * NLEV) * No : nullptr;
         float *yf = a.y_out ? a.y_out + ((size_t)run * a.n_frames + f) * 4 * No : nullptr;
+        float *ef = a.eq_out ? a.eq_out + ((size_t)run * a.n_frames + f) * 2 * No : nullptr;
+        int8_t *df = a.dec_out ? a.dec_out + ((size_t)run * a.n_frames + f) * 4 * No : nullptr;
 #pragma unroll 1
         for (int s = 0; s < a.steps; s++) {
             // ============ P0: prefetched window -> LDS (polyphase scatter; halo stays zero)
@@ -265,6 +267,32 @@ __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
                     for (int i = 0; i < NLEV; i++) {
                         q[i] *= rs;
                         m1 += q[i] * amp[i];
+                    }
+                    // compact stand-ins for q in the epilogue: E_q[x_I] and the first maximum of q, exactly as it would derive them
+                    if (ef && c == 0) {
+                        float *r = ef + (size_t)o * No + col;
+                        if (pairst) {
+                            if (kept0) *reinterpret_cast<v2f *>(r) = m1;
+                        } else {
+                            if (kept0) r[0] = m1.x;
+                            if (kept1) r[1] = m1.y;
+                        }
+                    }
+                    if (df) {
+                        float v0 = q[0].x, v1 = q[0].y;
+                        int b0 = 0, b1 = 0;
+#pragma unroll
+                        for (int i = 1; i < NLEV; i++) {
+                            if (q[i].x > v0) { v0 = q[i].x; b0 = i; }
+                            if (q[i].y > v1) { v1 = q[i].y; b1 = i; }
+                        }
+                        int8_t *r = df + (size_t)(o * 2 + c) * No + col;
+                        if (pairst) {
+                            if (kept0) *reinterpret_cast<uint16_t *>(r) = (uint16_t)(b0 | (b1 << 8));
+                        } else {
+                            if (kept0) r[0] = (int8_t)b0;
+                            if (kept1) r[1] = (int8_t)b1;
+                        }
                     }
                     // log(q_i/P_i) = z_i ln2 - log(ssum) - log P_i: the softmax's own logits; the +1e-12 inside the reference's
                     // log and the q/(q+eps P) factor of its derivative change q*log(.) by < 1e-12, and the terms
@@ -649,6 +677,8 @@ bool dp_wave_supported(const vaeq_dp_args &a)
     if ((a.S & 3) || ((a.stride_sym * 2) & 3) || (reinterpret_cast<uintptr_t>(a.rx) & 15)) return false;   // 16-byte window loads
     if (a.q_out && (reinterpret_cast<uintptr_t>(a.q_out) & 7)) return false;
     if (a.y_out && (reinterpret_cast<uintptr_t>(a.y_out) & 7)) return false;
+    if (a.eq_out && (reinterpret_cast<uintptr_t>(a.eq_out) & 7)) return false;
+    if (a.dec_out && (reinterpret_cast<uintptr_t>(a.dec_out) & 1)) return false;
     if ((a.dbg_gW == nullptr) != (a.dbg_gh == nullptr)) return false;
     return true;
 }

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(EPI_NT) void dp_epilogue_kernel(int64_t N, int batc
 {
     __shared__ EpiShared sh;
     const int run = blockIdx.x, tid = threadIdx.x;
-    const float *qr = q + (size_t)run * 4 * NLEV * N, *yr = y + (size_t)run * 4 * N;
+    const float *qr = q ? q + (size_t)run * 4 * NLEV * N : nullptr, *yr = y + (size_t)run * 4 * N;
     const __half *tx = txg + (size_t)run * 4 * N;              // [a][c][n]
     float *E = wsE + (size_t)run * 2 * N;
     int8_t *D = wsD + (size_t)run * 4 * N;
@@ -147,7 +147,8 @@ __global__ __launch_bounds__(EPI_NT) void dp_epilogue_kernel(int64_t N, int batc
     }
 
     // ---- pass 1: E_q[x_I] per polarisation (shared_funcs.py:296-297) and hard decisions argmax(q) per axis (:201)
-    for (int64_t n = tid; n < N; n += EPI_NT) {
+    //      (q == nullptr: the training kernel already wrote both -- vaeq_dp_args.eq_out / dec_out)
+    for (int64_t n = tid; q && n < N; n += EPI_NT) {
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             float e = 0.f;
@@ -273,6 +274,27 @@ extern "C" int vaeq_dp_epilogue(int32_t R, int64_t N, int32_t n_lev, int32_t bat
     float *wsE = reinterpret_cast<float *>(workspace);
     int8_t *wsD = reinterpret_cast<int8_t *>(wsE + (size_t)R * 2 * N);
     const __half *tx = reinterpret_cast<const __half *>(tx_f16);
+    switch (n_lev) {
+    case 2: hipLaunchKernelGGL(vaeq::dp_epilogue_kernel<2>, dim3(R), dim3(vaeq::EPI_NT), 0, st, N, batch_len, q, y, tx, amp, var, nu_sc, ser, shift, rflag, wsE, wsD); break;
+    case 4: hipLaunchKernelGGL(vaeq::dp_epilogue_kernel<4>, dim3(R), dim3(vaeq::EPI_NT), 0, st, N, batch_len, q, y, tx, amp, var, nu_sc, ser, shift, rflag, wsE, wsD); break;
+    case 8: hipLaunchKernelGGL(vaeq::dp_epilogue_kernel<8>, dim3(R), dim3(vaeq::EPI_NT), 0, st, N, batch_len, q, y, tx, amp, var, nu_sc, ser, shift, rflag, wsE, wsD); break;
+    default: return VAEQ_ERR_SHAPE;
+    }
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}
+
+extern "C" int vaeq_dp_epilogue_compact(int32_t R, int64_t N, int32_t n_lev, int32_t batch_len, const float *eq, const int8_t *dec, const float *y,
+                                        const void *tx_f16, const float *amp, const float *var, const float *nu_sc, float *ser, int32_t *shift,
+                                        int32_t *rflag, void *stream)
+{
+    if (!eq || !dec || !y || !tx_f16 || !amp || !var || !nu_sc || !ser || !shift || !rflag) return VAEQ_ERR_NULL;
+    if (R < 0 || N < 2 * vaeq::EDGE + vaeq::N_SHIFT || N > 0x3fffffff || batch_len < 0 || (batch_len > 0 && N % batch_len)) return VAEQ_ERR_SHAPE;
+    if (R == 0) return VAEQ_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const __half *tx = reinterpret_cast<const __half *>(tx_f16);
+    float *wsE = const_cast<float *>(eq);
+    int8_t *wsD = const_cast<int8_t *>(dec);
+    const float *q = nullptr;
     switch (n_lev) {
     case 2: hipLaunchKernelGGL(vaeq::dp_epilogue_kernel<2>, dim3(R), dim3(vaeq::EPI_NT), 0, st, N, batch_len, q, y, tx, amp, var, nu_sc, ser, shift, rflag, wsE, wsD); break;
     case 4: hipLaunchKernelGGL(vaeq::dp_epilogue_kernel<4>, dim3(R), dim3(vaeq::EPI_NT), 0, st, N, batch_len, q, y, tx, amp, var, nu_sc, ser, shift, rflag, wsE, wsD); break;

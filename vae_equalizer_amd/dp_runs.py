@@ -13,7 +13,7 @@ import torch
 
 from . import channel as ch
 from . import shared_funcs as sfun
-from .engine import DPEngine, dp_epilogue
+from .engine import DPEngine, dp_epilogue, dp_epilogue_compact  # noqa: F401
 
 
 @dataclass
@@ -109,11 +109,14 @@ def run_dp_batch(runs, mod, sps, M_est, batch_len, N_frame_max, num_frames, flex
         theta = theta + theta_diff                                              # :51
         if flex:
             data = data[:, :, :, batch_len // 2:N_out + batch_len // 2]          # func_VAEflex...:51
-        out = eng.train(rx, batch_len, steps, cur_lr_W, lr0, stride=stride, keep_off=k0, keep_len=klen)
-        q, y = out["q"][:, 0], out["y"][:, 0]
+        # q itself is only materialised when the caller wants it back (keep_last): the epilogue reads E_q[x_I] and argmax(q), which
+        # the training kernel writes directly (5 instead of 32 floats per polarisation symbol through HBM)
+        need_q = keep_last and frame == num_frames - 1
+        out = eng.train(rx, batch_len, steps, cur_lr_W, lr0, stride=stride, keep_off=k0, keep_len=klen, want_q=need_q, want_compact=True)
+        q, y = (out["q"][:, 0] if need_q else None), out["y"][:, 0]
         ve = out["var_est"][:, 0]                                               # [R,2,steps]
         Var_est[:, :, frame] = ve.mean(dim=2).cpu()                             # :69
-        res = dp_epilogue(q, y, data, amp, nu_sc_t, var, None if flex else batch_len)     # HIP kernel (vaeq_dp_epilogue)
+        res = dp_epilogue_compact(out["eq"][:, 0], out["dec"][:, 0], y, data, amp, nu_sc_t, var, None if flex else batch_len)
         SER[:, :, frame] = res["SER"].cpu()
         if verbose:
             loss = out["loss"][:, 0, -1].cpu()

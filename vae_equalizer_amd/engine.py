@@ -62,11 +62,13 @@ class DPEngine:
             self.h.copy_(_f32(h, self.device).expand_as(self.h))
 
     def train(self, rx, B, steps, lr_W, lr_h=None, stride=None, keep_off=0, keep_len=None, want_q=True, want_y=True,
-              want_loss=True, debug_grads=False, no_update=False):
+              want_loss=True, debug_grads=False, no_update=False, want_compact=False):
         """Run ``steps`` minibatch steps per frame on rx[R, n_frames, 2, 2, S] (or [R, 2, 2, S]).
 
         VAE-LE: defaults (stride = keep_len = B).  VAEflex: stride = keep_len = flex_step, keep_off = (B-flex_step)//2.
         Returns dict of device tensors: q [R,F,2,2n,steps*keep_len], y [R,F,2,2,...], loss [R,F,steps], var_est [R,F,2,steps].
+        want_compact adds eq [R,F,2,No] (E_q[x_I] per polarisation) and dec [R,F,2,2,No] int8 (argmax of q per axis): everything the
+        per-frame epilogue reads of q, so a sweep can run with want_q=False (dp_epilogue_compact).
         """
         if rx.dim() == 4:
             rx = rx.unsqueeze(1)
@@ -87,6 +89,8 @@ class DPEngine:
             "var_est": e(R, F, 2, steps) if want_loss else None,
             "gW": e(R, 2, 4, self.M) if debug_grads else None,
             "gh": e(R, 2, 2, 2, self.M) if debug_grads else None,
+            "eq": e(R, F, 2, No) if want_compact else None,
+            "dec": torch.empty(R, F, 2, 2, No, dtype=torch.int8, device=dev) if want_compact else None,
         }
         a = nat.DPArgs(R=R, n_frames=F, steps=steps, B=B, sps=self.sps, M=self.M, n_lev=self.n_lev, stride_sym=stride,
                        keep_off=keep_off, keep_len=keep_len, S=S, rx=nat.ptr(rx), W=nat.ptr(self.W), h=nat.ptr(self.h),
@@ -94,6 +98,7 @@ class DPEngine:
                        step=nat.ptr(self.step, torch.int32), amp=nat.ptr(self.amp), P=nat.ptr(self.P), var=nat.ptr(self.var),
                        nu_sc=nat.ptr(self.nu_sc), lr_W=nat.ptr(lrW), lr_h=nat.ptr(lrH), q_out=nat.ptr(out["q"]),
                        y_out=nat.ptr(out["y"]), loss=nat.ptr(out["loss"]), var_est=nat.ptr(out["var_est"]),
+                       eq_out=nat.ptr(out["eq"]), dec_out=nat.ptr(out["dec"], torch.int8),
                        dbg_gW=nat.ptr(out["gW"]), dbg_gh=nat.ptr(out["gh"]), threads=self.threads, no_update=int(no_update))
         with torch.cuda.device(dev):
             nat.check(nat.lib().vaeq_dp_train(C.byref(a), nat.current_stream(dev)), "vaeq_dp_train")
@@ -259,4 +264,24 @@ def dp_epilogue(q, y, data, amp_levels, nu_sc, var, batch_len=None):
                                              nat.ptr(amp), nat.ptr(var), nat.ptr(nu), nat.ptr(ser), nat.ptr(shift, torch.int32),
                                              nat.ptr(rflag, torch.int32), nat.ptr(ws, torch.uint8), nat.current_stream(dev)),
                   "vaeq_dp_epilogue")
+    return dict(SER=ser, shift_q=shift[:, 0].long(), r_q=rflag[:, 0].long(), shift_c=shift[:, 1].long(), r_c=rflag[:, 1].long())
+
+
+def dp_epilogue_compact(eq, dec, y, data, amp_levels, nu_sc, var, batch_len=None):
+    """dp_epilogue fed by the training kernel's compact outputs of one frame (vaeq_dp_epilogue_compact): eq[R,2,N] f32,
+    dec[R,2,2,N] int8, y[R,2,2,N], data[R,2,2,N] fp16 -> the same dict; bit-identical to dp_epilogue on that call's q."""
+    dev, R, N = y.device, y.shape[0], y.shape[-1]
+    amp = _f32(amp_levels, dev).reshape(-1)
+    var = _f32(var, dev).expand(R, 2).contiguous()
+    nu = _f32(nu_sc, dev).expand(R).contiguous()
+    eq, dec, y = eq.contiguous(), dec.contiguous(), y.contiguous()
+    data = data.to(torch.float16).contiguous()
+    ser = torch.empty(R, 4, dtype=torch.float32, device=dev)
+    shift = torch.empty(R, 2, 2, dtype=torch.int32, device=dev)
+    rflag = torch.empty(R, 2, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().vaeq_dp_epilogue_compact(R, N, amp.numel(), int(batch_len or 0), nat.ptr(eq), nat.ptr(dec, torch.int8), nat.ptr(y),
+                                                     nat.ptr(data, torch.float16), nat.ptr(amp), nat.ptr(var), nat.ptr(nu), nat.ptr(ser),
+                                                     nat.ptr(shift, torch.int32), nat.ptr(rflag, torch.int32), nat.current_stream(dev)),
+                  "vaeq_dp_epilogue_compact")
     return dict(SER=ser, shift_q=shift[:, 0].long(), r_q=rflag[:, 0].long(), shift_c=shift[:, 1].long(), r_c=rflag[:, 1].long())
