@@ -226,6 +226,14 @@ int vaeq_gen_dp_disperse(int32_t R, int32_t Ls, double fs, double tau_cd, double
 int vaeq_gen_dp_finish(int32_t R, int32_t N, int32_t sps, int32_t Ls, int32_t Lrow, const float *snr_db, uint64_t seed, uint32_t frame,
                        const float *sig_complex, float *power_ws, float *rx, float *sigma_out, void *stream);
 
+/* The three stages and both transforms of one DP frame in ONE call (hipFFT in place on sig_ws[R][2][Lrow] complex64, plans cached
+ * per (Lrow, R)); same arguments as the stage entry points, e_k = exp(-j phiIQ[k]), fs = symb_rate * sps. */
+int vaeq_gen_dp_frame(int32_t R, int32_t N, int32_t N_conv, int32_t sps, int32_t n_lev, int32_t Lg, int32_t Ls, int32_t Lrow,
+                      int32_t ref_offset, const float *amp, const float *cdf, const float *g_complex, const float *snr_db,
+                      const float *theta, double fs, double tau_cd, double tau_pmd, float e0_re, float e0_im, float e1_re, float e1_im,
+                      uint64_t seed, uint32_t frame, float *sig_ws, float *power_ws, float *rx, void *data_f16, float *sigma_out,
+                      void *stream);
+
 /* Single-polarisation AWGN / ISI channel of AWGN_channel/func_VAELE_MQAM_shaping.py:39-61 (generate_data) for R runs, same three
  * stages without the dispersion step: g[Lg] = rrc * h_channel; sig_ws [R][Ls] complex64 and power_ws [R] are scratch;
  * rx[R][2][sps*N] (:57), data_f16 (nullable) [R][2][N] = symbols ref_offset .. ref_offset+N-1 (:59), sigma_out[R] nullable. */

@@ -31,7 +31,7 @@ def build(force=False, verbose=False):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(_ROOT, "include"),
-           "-I", csrc, *srcs, "-o", LIB_PATH]
+           "-I", csrc, *srcs, "-lhipfft", "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -72,7 +72,7 @@ class AWGNArgs(C.Structure):
 
 
 # every symbol include/vaeq.h declares; tests check the library exports all of them
-EXPORTS = ["vaeq_dp_train", "vaeq_dp_lds_bytes", "vaeq_dp_resident_runs", "vaeq_soft_demap", "vaeq_dp_forward", "vaeq_dp_loss", "vaeq_dp_loss_bwd", "vaeq_dp_forward_bwd", "vaeq_dp_epilogue", "vaeq_dp_epilogue_ws_bytes", "vaeq_dp_epilogue_compact", "vaeq_gen_dp_tx", "vaeq_gen_dp_disperse", "vaeq_gen_dp_finish", "vaeq_awgn_train",
+EXPORTS = ["vaeq_dp_train", "vaeq_dp_lds_bytes", "vaeq_dp_resident_runs", "vaeq_soft_demap", "vaeq_dp_forward", "vaeq_dp_loss", "vaeq_dp_loss_bwd", "vaeq_dp_forward_bwd", "vaeq_dp_epilogue", "vaeq_dp_epilogue_ws_bytes", "vaeq_dp_epilogue_compact", "vaeq_gen_dp_tx", "vaeq_gen_dp_disperse", "vaeq_gen_dp_finish", "vaeq_gen_dp_frame", "vaeq_awgn_train",
            "vaeq_awgn_lds_bytes", "vaeq_awgn_forward", "vaeq_awgn_validate", "vaeq_gen_awgn", "vaeq_version", "vaeq_strerror"]
 
 
@@ -122,6 +122,9 @@ def lib():
             L.vaeq_awgn_lds_bytes.argtypes = [C.c_int32] * 4
             L.vaeq_awgn_forward.restype = C.c_int
             L.vaeq_awgn_forward.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 8
+        L.vaeq_gen_dp_frame.restype = C.c_int
+        L.vaeq_gen_dp_frame.argtypes = ([C.c_int32] * 9 + [C.c_void_p] * 5 + [C.c_double] * 3 + [C.c_float] * 4 + [C.c_uint64, C.c_uint32]
+                                        + [C.c_void_p] * 6)
         L.vaeq_awgn_validate.restype = C.c_int
         L.vaeq_awgn_validate.argtypes = [C.c_int32, C.c_int64] + [C.c_int32] * 4 + [C.c_void_p] * 10
         L.vaeq_gen_awgn.restype = C.c_int

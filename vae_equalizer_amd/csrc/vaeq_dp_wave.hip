@@ -97,7 +97,9 @@ __device__ __forceinline__ void pair_fir(cacc (&acc)[2][2], const float2 *xp, in
     }
 }
 
-template <int M, int NLEV, int BT, bool PAIR>
+// OUT: 0 = every output nullable at run time; 1 = no compact outputs (eq_out / dec_out ignored); 2 = compact outputs, q not written.
+// The specialisations only drop dead code: fewer live scalars, fewer SGPR spills in the step loop.
+template <int M, int NLEV, int BT, bool PAIR, int OUT>
 __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
 {
     constexpr int mh = M / 2, Mh = 2 * mh, MP = M + 1;
@@ -177,10 +179,10 @@ __global__ __launch_bounds__(64, 2) void dp_wave_kernel(const vaeq_dp_args a)
     };
     fetch(0, 0);
     for (int f = 0; f < a.n_frames; f++) {
-        float *qf = a.q_out ? a.q_out + ((size_t)run * a.n_frames + f) * (4 * NLEV) * No : nullptr;
+        float *qf = (OUT != 2 && a.q_out) ? a.q_out + ((size_t)run * a.n_frames + f) * (4 * NLEV) * No : nullptr;
         float *yf = a.y_out ? a.y_out + ((size_t)run * a.n_frames + f) * 4 * No : nullptr;
-        float *ef = a.eq_out ? a.eq_out + ((size_t)run * a.n_frames + f) * 2 * No : nullptr;
-        int8_t *df = a.dec_out ? a.dec_out + ((size_t)run * a.n_frames + f) * 4 * No : nullptr;
+        float *ef = (OUT != 1 && a.eq_out) ? a.eq_out + ((size_t)run * a.n_frames + f) * 2 * No : nullptr;
+        int8_t *df = (OUT != 1 && a.dec_out) ? a.dec_out + ((size_t)run * a.n_frames + f) * 4 * No : nullptr;
 #pragma unroll 1
         for (int s = 0; s < a.steps; s++) {
             // ============ P0: prefetched window -> LDS (polyphase scatter; halo stays zero)
@@ -650,7 +652,12 @@ template <int M, int NLEV, int BT>
 static int launch_wave(const vaeq_dp_args &a, hipStream_t st)
 {
     const size_t lds = (size_t)wave_layout(a.B, M).total;
-    auto k = (((a.keep_len | a.keep_off) & 1) == 0) ? dp_wave_kernel<M, NLEV, BT, true> : dp_wave_kernel<M, NLEV, BT, false>;
+    const bool pair = ((a.keep_len | a.keep_off) & 1) == 0;
+    void (*k)(const vaeq_dp_args) = pair ? dp_wave_kernel<M, NLEV, BT, true, 0> : dp_wave_kernel<M, NLEV, BT, false, 0>;
+    if (BT) {                                                  // the tuned shape also gets the output-mode specialisations
+        if (!a.eq_out && !a.dec_out) k = pair ? dp_wave_kernel<M, NLEV, BT, true, BT ? 1 : 0> : dp_wave_kernel<M, NLEV, BT, false, BT ? 1 : 0>;
+        else if (!a.q_out) k = pair ? dp_wave_kernel<M, NLEV, BT, true, BT ? 2 : 0> : dp_wave_kernel<M, NLEV, BT, false, BT ? 2 : 0>;
+    }
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VAEQ_ERR_LDS;
@@ -690,7 +697,7 @@ static int64_t wave_resident(int B)
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return VAEQ_ERR_DEVICE;
     const size_t lds = (size_t)wave_layout(B, M).total;
-    auto k = dp_wave_kernel<M, NLEV, BT, true>;
+    auto k = dp_wave_kernel<M, NLEV, BT, true, 0>;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64, lds) != hipSuccess) return VAEQ_ERR_DEVICE;
     return (int64_t)nb * prop.multiProcessorCount;
 }

@@ -14,7 +14,12 @@
 // seeds nothing); the numpy restatement in channel.py is the bit-faithful one.
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
+#include <hipfft/hipfft.h>
 #include <stdint.h>
+
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "vaeq.h"
 #include "vaeq_common.h"
@@ -319,5 +324,53 @@ extern "C" int vaeq_gen_awgn(int32_t R, int32_t N, int32_t N_conv, int32_t sps, 
     vaeq::launch_tx(R, 1, N, N_conv, sps, n_lev, Lg, Ls, Ls, ref_offset, amp, cdf, reinterpret_cast<const float2 *>(g_complex), seed, frame, sig,
                     reinterpret_cast<__half *>(data_f16), st);
     vaeq::launch_finish(R, 1, N, sps, Ls, Ls, snr_db, seed, frame, sig, power_ws, rx, sigma_out, st);
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}
+
+// ---- whole DP frame in one call: stage 1 -> hipFFT (in place) -> stage 2 -> inverse hipFFT (in place, 1/Lrow folded into stage 2)
+//      -> stage 3.  Plans are cached per (row length, batch).
+namespace vaeq {
+static std::mutex g_plan_mu;
+static std::map<std::pair<int, int>, hipfftHandle> g_plans;
+
+static int get_plan(int Lrow, int batch, hipfftHandle *out)
+{
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_plans.find({Lrow, batch});
+    if (it == g_plans.end()) {
+        hipfftHandle h;
+        int n[1] = {Lrow};
+        if (hipfftPlanMany(&h, 1, n, nullptr, 1, Lrow, nullptr, 1, Lrow, HIPFFT_C2C, batch) != HIPFFT_SUCCESS) return VAEQ_ERR_DEVICE;
+        it = g_plans.emplace(std::make_pair(Lrow, batch), h).first;
+    }
+    *out = it->second;
+    return VAEQ_OK;
+}
+}  // namespace vaeq
+
+extern "C" int vaeq_gen_dp_frame(int32_t R, int32_t N, int32_t N_conv, int32_t sps, int32_t n_lev, int32_t Lg, int32_t Ls, int32_t Lrow,
+                                 int32_t ref_offset, const float *amp, const float *cdf, const float *g_complex, const float *snr_db,
+                                 const float *theta, double fs, double tau_cd, double tau_pmd, float e0_re, float e0_im, float e1_re,
+                                 float e1_im, uint64_t seed, uint32_t frame, float *sig_ws, float *power_ws, float *rx, void *data_f16,
+                                 float *sigma_out, void *stream)
+{
+    if (!amp || !cdf || !g_complex || !snr_db || !theta || !sig_ws || !power_ws || !rx) return VAEQ_ERR_NULL;
+    if (!tx_shape_ok(R, N, N_conv, sps, n_lev, Lg, Ls, Lrow, ref_offset)) return VAEQ_ERR_SHAPE;
+    if (R == 0) return VAEQ_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float2 *sig = reinterpret_cast<float2 *>(sig_ws);
+    hipfftHandle plan;
+    const int rc = vaeq::get_plan(Lrow, 2 * R, &plan);
+    if (rc != VAEQ_OK) return rc;
+    if (hipfftSetStream(plan, st) != HIPFFT_SUCCESS) return VAEQ_ERR_DEVICE;
+    vaeq::launch_tx(R, 2, N, N_conv, sps, n_lev, Lg, Ls, Lrow, ref_offset, amp, cdf, reinterpret_cast<const float2 *>(g_complex), seed, frame, sig,
+                    reinterpret_cast<__half *>(data_f16), st);
+    if (hipfftExecC2C(plan, reinterpret_cast<hipfftComplex *>(sig), reinterpret_cast<hipfftComplex *>(sig), HIPFFT_FORWARD) != HIPFFT_SUCCESS)
+        return VAEQ_ERR_LAUNCH;
+    hipLaunchKernelGGL(vaeq::gen_disperse_kernel, dim3((Lrow + 255) / 256, R), dim3(256), 0, st, Lrow, fs / (double)Lrow, tau_cd, tau_pmd,
+                       make_float2(e0_re, e0_im), make_float2(e1_re, e1_im), 1.0f / (float)Lrow, theta, sig);
+    if (hipfftExecC2C(plan, reinterpret_cast<hipfftComplex *>(sig), reinterpret_cast<hipfftComplex *>(sig), HIPFFT_BACKWARD) != HIPFFT_SUCCESS)
+        return VAEQ_ERR_LAUNCH;
+    vaeq::launch_finish(R, 2, N, sps, Ls, Lrow, snr_db, seed, frame, sig, power_ws, rx, sigma_out, st);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
