@@ -30,7 +30,7 @@ extern "C" {
 #define VAEQ_VERSION 100
 
 enum {
-    VAEQ_OK = 0,
+    VAEQ_OK = 0,             /* also for an empty batch (R == 0): nothing is read, pointers may be NULL */
     VAEQ_ERR_NULL = -1,      /* a required pointer is NULL */
     VAEQ_ERR_SHAPE = -2,     /* inconsistent or unsupported sizes (even M, n_lev not in {2,4,8}, window past S ...) */
     VAEQ_ERR_LDS = -3,       /* the per-run working set does not fit the 160 KiB LDS of a CU */

@@ -1,0 +1,115 @@
+"""Edge cases of the C ABI on the GPU: empty batches, NULL / inconsistent arguments, the largest supported tap count, long
+minibatches, sps != 2 -- each compute case against the CPU oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+OK, ERR_NULL, ERR_SHAPE, ERR_LDS = 0, -1, -2, -3
+
+
+def _amp(n):
+    a = np.arange(-(n - 1), n, 2).astype(np.float32)
+    return a / np.sqrt(2 * np.mean(a ** 2))
+
+
+def test_empty_batches_are_a_no_op():
+    """R = 0 is legal everywhere (a rank may own no sweep point): VAEQ_OK, nothing launched, nothing touched."""
+    from vae_equalizer_amd import _native as nat
+    from vae_equalizer_amd.engine import AWGNEngine, DPEngine, dp_epilogue_compact
+    L = nat.lib()
+    eng = DPEngine(0, 25, _amp(8), np.zeros((0, 8), np.float32), np.zeros((0, 2), np.float32), np.zeros(0, np.float32), DEV)
+    out = eng.train(torch.zeros(0, 1, 2, 2, 400, device=DEV), 100, 2, 1e-3, want_compact=True)
+    assert out["q"].shape == (0, 1, 2, 16, 200) and out["loss"].shape == (0, 1, 2)
+    res = dp_epilogue_compact(out["eq"][:, 0], out["dec"][:, 0], out["y"][:, 0], torch.zeros(0, 2, 2, 200, dtype=torch.float16, device=DEV),
+                              _amp(8), 0.0, 0.01, 100)
+    assert res["SER"].shape == (0, 4)
+    aeng = AWGNEngine(0, 25, _amp(8), np.zeros((0, 8), np.float32), [], [], DEV)
+    assert aeng.train(torch.zeros(0, 2, 700, device=DEV), 350, 1, 1e-3)["loss"].shape == (0, 1)
+    ser, sh, _ = aeng.validate(torch.zeros(0, 2, 2000, device=DEV), torch.zeros(0, 2, 1000, dtype=torch.float16, device=DEV))
+    assert ser.shape == (0,) and sh.shape == (0,)
+    z = C.c_void_p(torch.zeros(8, device=DEV).data_ptr())
+    assert L.vaeq_gen_awgn(0, 100, 141, 2, 8, 40, 242, 12, z, z, z, z, C.c_uint64(1), C.c_uint32(0), z, z, z, None, None, None) == OK
+
+
+def test_null_and_inconsistent_arguments_are_refused():
+    from vae_equalizer_amd import _native as nat
+    L = nat.lib()
+    t = torch.zeros(4096, device=DEV)
+    p = C.c_void_p(t.data_ptr())
+    i32 = C.c_void_p(torch.zeros(4, dtype=torch.int32, device=DEV).data_ptr())
+    base = dict(R=1, n_frames=1, steps=1, B=100, sps=2, M=25, n_lev=8, stride_sym=100, keep_off=0, keep_len=100, S=400, rx=p, W=p, h=p,
+                adam_mW=p, adam_vW=p, adam_mh=p, adam_vh=p, step=i32, amp=p, P=p, var=p, nu_sc=p, lr_W=p, lr_h=p, threads=0, no_update=1)
+    call = lambda **kw: L.vaeq_dp_train(C.byref(nat.DPArgs(**{**base, **kw})), None)
+    assert call(rx=None) == ERR_NULL and call(W=None) == ERR_NULL and call(step=None) == ERR_NULL
+    assert call(M=24) == ERR_SHAPE                                  # even tap count
+    assert call(n_lev=3) == ERR_SHAPE and call(n_lev=16) == ERR_SHAPE
+    assert call(S=199) == ERR_SHAPE                                 # window past the row
+    assert call(B=24) == ERR_SHAPE                                  # B <= 2 * (M // 2): empty ELBO
+    assert call(keep_off=50, keep_len=60) == ERR_SHAPE              # kept slice past the minibatch
+    assert call(threads=7) == ERR_SHAPE
+    assert call(B=20000, S=80000, stride_sym=20000, keep_len=20000) == ERR_LDS
+    assert L.vaeq_dp_train(None, None) == ERR_NULL
+    assert L.vaeq_strerror(ERR_LDS).decode() and L.vaeq_strerror(-99).decode()
+    assert L.vaeq_dp_epilogue_compact(1, 1000, 8, 100, None, p, p, p, p, p, p, p, i32, i32, None) == ERR_NULL
+    assert L.vaeq_dp_epilogue_compact(1, 30, 8, 0, p, p, p, p, p, p, p, p, i32, i32, None) == ERR_SHAPE        # shorter than the trims
+    assert L.vaeq_dp_epilogue_compact(1, 1000, 8, 300, p, p, p, p, p, p, p, p, i32, i32, None) == ERR_SHAPE    # N % batch_len
+    assert L.vaeq_awgn_validate(1, 1000, 2, 24, 8, 21, p, p, p, p, p, p, p, p, i32, None) == ERR_SHAPE
+    assert L.vaeq_awgn_validate(1, 1000, 2, 25, 8, 64, p, p, p, p, p, p, p, p, i32, None) == ERR_SHAPE         # n_shift > 32
+    assert L.vaeq_gen_awgn(1, 100, 141, 2, 8, 40, 999, 12, p, p, p, p, C.c_uint64(1), C.c_uint32(0), p, p, p, None, None, None) == ERR_SHAPE
+    assert L.vaeq_gen_dp_frame(1, 100, 141, 2, 8, 200, 242, 256, 12, p, p, p, p, p, 1.8e11, 0.0, 0.0, 1.0, 0.0, 1.0, 0.0, C.c_uint64(1),
+                               C.c_uint32(0), p, p, p, None, None, None) == ERR_SHAPE                              # Lg > 96 taps
+
+
+@pytest.mark.parametrize("M,B,sps,n", [(63, 150, 2, 8), (31, 600, 2, 4), (9, 41, 3, 2), (5, 33, 1, 8)])
+def test_dp_extreme_shapes_against_oracle(M, B, sps, n):
+    """Largest tap count (M = 63), a 600-symbol minibatch (42 KB of LDS), sps = 3 and sps = 1: the generic kernel, 3 free steps."""
+    from vae_equalizer_amd.engine import DPEngine
+    rng = np.random.default_rng(M * B)
+    R, steps = 2, 3
+    amp = _amp(n)
+    P = np.full((R, n), 1 / n, np.float32)
+    var = np.full((R, 2), 0.01, np.float32)
+    rx = (0.5 * rng.standard_normal((R, 2, 2, steps * B * sps))).astype(np.float32)
+    W0 = (0.03 * rng.standard_normal((R, 2, 4, M))).astype(np.float32)
+    W0[:, 0, 0, M // 2] += 1; W0[:, 1, 1, M // 2] += 1
+    h0 = (0.03 * rng.standard_normal((R, 2, 2, 2, M))).astype(np.float32)
+    h0[:, 0, 0, 0, M // 2] += 1; h0[:, 1, 1, 0, M // 2] += 1
+    eng = DPEngine(R, M, amp, P, var, 0.01, DEV, sps)
+    eng.set_state(W0, h0)
+    r = eng.train(torch.from_numpy(rx).to(DEV), B, steps, 1e-3)
+    torch.cuda.synchronize()
+    for i in range(R):
+        st = oracle.DPState(M, np.float32, W0[i], h0[i])
+        o = oracle.dp_train(st, rx[i], steps, B, amp, P[i], var[i], 0.01, 1e-3, 1e-3, sps)
+        assert np.max(np.abs(r["loss"][i, 0].cpu().numpy() - o["loss"]) / np.abs(o["loss"])) < 2e-5
+        assert relerr(r["y"][i, 0].cpu().numpy(), o["out"]) < 1e-5
+        assert np.max(np.abs(r["q"][i, 0].cpu().numpy() - o["q"])) < 1e-4
+        assert np.max(np.abs(eng.W[i].cpu().numpy() - st.W)) < 2e-5 and np.max(np.abs(eng.h[i].cpu().numpy() - st.h)) < 2e-5
+
+
+@pytest.mark.parametrize("M,B,sps,n", [(63, 200, 2, 8), (25, 1000, 2, 4), (9, 41, 3, 2)])
+def test_awgn_extreme_shapes_against_oracle(M, B, sps, n):
+    from vae_equalizer_amd.engine import AWGNEngine
+    rng = np.random.default_rng(M + B)
+    steps = 3
+    amp = _amp(n)
+    P = np.full(n, 1 / n, np.float32)
+    amp_mean, var = float(np.mean(np.abs(amp))), 0.02
+    rx = (0.5 * rng.standard_normal((2, steps * B * sps))).astype(np.float32)
+    W0 = (0.03 * rng.standard_normal((1, 2, M))).astype(np.float32); W0[0, 0, M // 2] += 1
+    h0 = (0.03 * rng.standard_normal((2, M))).astype(np.float32); h0[0, M // 2] += 1
+    eng = AWGNEngine(1, M, amp, P, amp_mean, var, DEV, sps)
+    eng.set_state(W0, h0)
+    r = eng.train(torch.from_numpy(rx[None]).to(DEV), B, steps, 1e-3)
+    torch.cuda.synchronize()
+    st = oracle.AWGNState(M, np.float32, W0, h0)
+    loss = oracle.awgn_train(st, rx, steps, B, amp, P, amp_mean, var, 1e-3, sps)
+    assert np.max(np.abs(r["loss"][0].cpu().numpy() - loss) / np.abs(loss)) < 2e-5
+    assert np.max(np.abs(eng.W[0].cpu().numpy() - st.W[0])) < 2e-5 and np.max(np.abs(eng.h[0].cpu().numpy() - st.h)) < 2e-5

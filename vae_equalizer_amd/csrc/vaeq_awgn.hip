@@ -571,6 +571,7 @@ extern "C" int vaeq_awgn_train(const vaeq_awgn_args *pa, void *stream)
 {
     if (!pa) return VAEQ_ERR_NULL;
     const vaeq_awgn_args &a = *pa;
+    if (a.R == 0) return VAEQ_OK;                              // an empty batch owns no memory: its pointers may be NULL
     if (!a.rx || !a.W || !a.h || !a.adam_mW || !a.adam_vW || !a.adam_xW || !a.adam_mh || !a.adam_vh || !a.adam_xh || !a.step ||
         !a.amp || !a.P || !a.amp_mean || !a.var || !a.lr)
         return VAEQ_ERR_NULL;
@@ -595,6 +596,7 @@ extern "C" int vaeq_awgn_train(const vaeq_awgn_args *pa, void *stream)
 extern "C" int vaeq_awgn_forward(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, const float *x, const float *W,
                                  const float *amp, const float *amp_mean, const float *var, float *q, float *y, void *stream)
 {
+    if (R == 0 || N == 0) return VAEQ_OK;                      // an empty batch owns no memory: its pointers may be NULL
     if (!x || !W || !amp || !amp_mean || !var || !y) return VAEQ_ERR_NULL;
     if (R < 0 || N < 0 || sps <= 0 || M <= 0 || (M & 1) == 0 || M > 63) return VAEQ_ERR_SHAPE;
     if (R == 0 || N == 0) return VAEQ_OK;
@@ -612,10 +614,10 @@ extern "C" int vaeq_awgn_validate(int32_t R, int64_t N, int32_t sps, int32_t M, 
                                   const float *amp, const float *amp_mean, const float *var, const void *data_f16, float *y_ws, float *ser,
                                   int32_t *shift, void *stream)
 {
+    if (R == 0) return VAEQ_OK;                                // an empty batch owns no memory: its pointers may be NULL
     if (!x || !W || !amp || !amp_mean || !var || !data_f16 || !y_ws || !ser) return VAEQ_ERR_NULL;
     if (R < 0 || sps <= 0 || M <= 0 || (M & 1) == 0 || M > 63 || n_shift <= 0 || n_shift > vaeq::VAL_MAXSHIFT) return VAEQ_ERR_SHAPE;
     if (N < 64 || N > 65536) return VAEQ_ERR_SHAPE;           // decisions live in LDS (N bytes); 22 + n_shift symbols are trimmed
-    if (R == 0) return VAEQ_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const __half *d = reinterpret_cast<const __half *>(data_f16);
     switch (n_lev) {

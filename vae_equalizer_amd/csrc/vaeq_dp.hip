@@ -427,6 +427,7 @@ extern "C" int vaeq_dp_train(const vaeq_dp_args *pa, void *stream)
 {
     if (!pa) return VAEQ_ERR_NULL;
     const vaeq_dp_args &a = *pa;
+    if (a.R == 0) return VAEQ_OK;                              // an empty batch owns no memory: its pointers may be NULL
     if (!a.rx || !a.W || !a.h || !a.adam_mW || !a.adam_vW || !a.adam_mh || !a.adam_vh || !a.step || !a.amp || !a.P ||
         !a.var || !a.nu_sc || !a.lr_W || !a.lr_h)
         return VAEQ_ERR_NULL;

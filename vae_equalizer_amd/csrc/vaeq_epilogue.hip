@@ -267,9 +267,9 @@ extern "C" int vaeq_dp_epilogue(int32_t R, int64_t N, int32_t n_lev, int32_t bat
                                 const float *amp, const float *var, const float *nu_sc, float *ser, int32_t *shift, int32_t *rflag,
                                 void *workspace, void *stream)
 {
+    if (R == 0) return VAEQ_OK;                                // an empty batch owns no memory: its pointers may be NULL
     if (!q || !y || !tx_f16 || !amp || !var || !nu_sc || !ser || !shift || !rflag || !workspace) return VAEQ_ERR_NULL;
     if (R < 0 || N < 2 * vaeq::EDGE + vaeq::N_SHIFT || N > 0x3fffffff || batch_len < 0 || (batch_len > 0 && N % batch_len)) return VAEQ_ERR_SHAPE;
-    if (R == 0) return VAEQ_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float *wsE = reinterpret_cast<float *>(workspace);
     int8_t *wsD = reinterpret_cast<int8_t *>(wsE + (size_t)R * 2 * N);
@@ -287,9 +287,9 @@ extern "C" int vaeq_dp_epilogue_compact(int32_t R, int64_t N, int32_t n_lev, int
                                         const void *tx_f16, const float *amp, const float *var, const float *nu_sc, float *ser, int32_t *shift,
                                         int32_t *rflag, void *stream)
 {
+    if (R == 0) return VAEQ_OK;                                // an empty batch owns no memory: its pointers may be NULL
     if (!eq || !dec || !y || !tx_f16 || !amp || !var || !nu_sc || !ser || !shift || !rflag) return VAEQ_ERR_NULL;
     if (R < 0 || N < 2 * vaeq::EDGE + vaeq::N_SHIFT || N > 0x3fffffff || batch_len < 0 || (batch_len > 0 && N % batch_len)) return VAEQ_ERR_SHAPE;
-    if (R == 0) return VAEQ_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const __half *tx = reinterpret_cast<const __half *>(tx_f16);
     float *wsE = const_cast<float *>(eq);

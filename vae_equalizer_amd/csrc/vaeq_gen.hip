@@ -277,9 +277,9 @@ extern "C" int vaeq_gen_dp_tx(int32_t R, int32_t N, int32_t N_conv, int32_t sps,
                               int32_t ref_offset, const float *amp, const float *cdf, const float *g_complex, uint64_t seed, uint32_t frame,
                               float *sig_complex, void *data_f16, void *stream)
 {
+    if (R == 0) return VAEQ_OK;                                // an empty batch owns no memory: its pointers may be NULL
     if (!amp || !cdf || !g_complex || !sig_complex) return VAEQ_ERR_NULL;
     if (!tx_shape_ok(R, N, N_conv, sps, n_lev, Lg, Ls, Lrow, ref_offset)) return VAEQ_ERR_SHAPE;
-    if (R == 0) return VAEQ_OK;
     vaeq::launch_tx(R, 2, N, N_conv, sps, n_lev, Lg, Ls, Lrow, ref_offset, amp, cdf, reinterpret_cast<const float2 *>(g_complex), seed, frame,
                     reinterpret_cast<float2 *>(sig_complex), reinterpret_cast<__half *>(data_f16), reinterpret_cast<hipStream_t>(stream));
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
@@ -288,9 +288,9 @@ extern "C" int vaeq_gen_dp_tx(int32_t R, int32_t N, int32_t N_conv, int32_t sps,
 extern "C" int vaeq_gen_dp_disperse(int32_t R, int32_t Ls, double fs, double tau_cd, double tau_pmd, float e0_re, float e0_im, float e1_re,
                                     float e1_im, float scale, const float *theta, float *spec_complex, void *stream)
 {
+    if (R == 0) return VAEQ_OK;                                // an empty batch owns no memory: its pointers may be NULL
     if (!theta || !spec_complex) return VAEQ_ERR_NULL;
     if (R < 0 || Ls <= 0) return VAEQ_ERR_SHAPE;
-    if (R == 0) return VAEQ_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(vaeq::gen_disperse_kernel, dim3((Ls + 255) / 256, R), dim3(256), 0, st, Ls, fs / (double)Ls, tau_cd, tau_pmd,
                        make_float2(e0_re, e0_im), make_float2(e1_re, e1_im), scale, theta, reinterpret_cast<float2 *>(spec_complex));
@@ -300,9 +300,9 @@ extern "C" int vaeq_gen_dp_disperse(int32_t R, int32_t Ls, double fs, double tau
 extern "C" int vaeq_gen_dp_finish(int32_t R, int32_t N, int32_t sps, int32_t Ls, int32_t Lrow, const float *snr_db, uint64_t seed, uint32_t frame,
                                   const float *sig_complex, float *power_ws, float *rx, float *sigma_out, void *stream)
 {
+    if (R == 0) return VAEQ_OK;                                // an empty batch owns no memory: its pointers may be NULL
     if (!snr_db || !sig_complex || !power_ws || !rx) return VAEQ_ERR_NULL;
     if (R < 0 || N <= 0 || sps <= 0 || Ls < sps * N || Lrow < Ls) return VAEQ_ERR_SHAPE;
-    if (R == 0) return VAEQ_OK;
     vaeq::launch_finish(R, 2, N, sps, Ls, Lrow, snr_db, seed, frame, reinterpret_cast<const float2 *>(sig_complex), power_ws, rx, sigma_out,
                         reinterpret_cast<hipStream_t>(stream));
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
@@ -316,9 +316,9 @@ extern "C" int vaeq_gen_awgn(int32_t R, int32_t N, int32_t N_conv, int32_t sps, 
                              const float *amp, const float *cdf, const float *g_complex, const float *snr_db, uint64_t seed, uint32_t frame,
                              float *sig_ws, float *power_ws, float *rx, void *data_f16, float *sigma_out, void *stream)
 {
+    if (R == 0) return VAEQ_OK;                                // an empty batch owns no memory: its pointers may be NULL
     if (!amp || !cdf || !g_complex || !snr_db || !sig_ws || !power_ws || !rx) return VAEQ_ERR_NULL;
     if (!tx_shape_ok(R, N, N_conv, sps, n_lev, Lg, Ls, Ls, ref_offset)) return VAEQ_ERR_SHAPE;
-    if (R == 0) return VAEQ_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float2 *sig = reinterpret_cast<float2 *>(sig_ws);
     vaeq::launch_tx(R, 1, N, N_conv, sps, n_lev, Lg, Ls, Ls, ref_offset, amp, cdf, reinterpret_cast<const float2 *>(g_complex), seed, frame, sig,
@@ -354,9 +354,9 @@ extern "C" int vaeq_gen_dp_frame(int32_t R, int32_t N, int32_t N_conv, int32_t s
                                  float e1_im, uint64_t seed, uint32_t frame, float *sig_ws, float *power_ws, float *rx, void *data_f16,
                                  float *sigma_out, void *stream)
 {
+    if (R == 0) return VAEQ_OK;                                // an empty batch owns no memory: its pointers may be NULL
     if (!amp || !cdf || !g_complex || !snr_db || !theta || !sig_ws || !power_ws || !rx) return VAEQ_ERR_NULL;
     if (!tx_shape_ok(R, N, N_conv, sps, n_lev, Lg, Ls, Lrow, ref_offset)) return VAEQ_ERR_SHAPE;
-    if (R == 0) return VAEQ_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float2 *sig = reinterpret_cast<float2 *>(sig_ws);
     hipfftHandle plan;

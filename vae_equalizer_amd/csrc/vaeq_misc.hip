@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void dp_loss_kernel(int B, int sps, int M, con
 extern "C" int vaeq_soft_demap(int32_t R, int64_t N, int32_t n_lev, const float *y, const float *amp, const float *var,
                                const float *nu_sc, float *q, void *stream)
 {
+    if (R == 0 || N == 0) return VAEQ_OK;                      // an empty batch owns no memory: its pointers may be NULL
     if (!y || !amp || !var || !nu_sc || !q) return VAEQ_ERR_NULL;
     if (R < 0 || N < 0) return VAEQ_ERR_SHAPE;
     if (R == 0 || N == 0) return VAEQ_OK;
@@ -172,6 +173,7 @@ extern "C" int vaeq_soft_demap(int32_t R, int64_t N, int32_t n_lev, const float 
 extern "C" int vaeq_dp_forward(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, const float *x, const float *W,
                                const float *amp, const float *var, const float *nu_sc, float *q, float *y, void *stream)
 {
+    if (R == 0 || N == 0) return VAEQ_OK;                      // an empty batch owns no memory: its pointers may be NULL
     if (!x || !W || !amp || !var || !nu_sc || !y) return VAEQ_ERR_NULL;
     if (R < 0 || N < 0 || sps <= 0 || M <= 0 || (M & 1) == 0 || M > 63) return VAEQ_ERR_SHAPE;
     if (R == 0 || N == 0) return VAEQ_OK;
@@ -189,9 +191,9 @@ extern "C" int vaeq_dp_forward(int32_t R, int64_t N, int32_t sps, int32_t M, int
 extern "C" int vaeq_dp_loss(int32_t R, int32_t B, int32_t sps, int32_t M, int32_t n_lev, const float *q, const float *x,
                             const float *h, const float *amp, const float *P, float *loss, float *var_est, void *stream)
 {
+    if (R == 0) return VAEQ_OK;                                // an empty batch owns no memory: its pointers may be NULL
     if (!q || !x || !h || !amp || !P || !loss || !var_est) return VAEQ_ERR_NULL;
     if (R < 0 || B <= 0 || sps <= 0 || M <= 0 || (M & 1) == 0 || M > 63 || B * sps - 2 * (M / 2) <= 0 || B <= 2 * (M / 2)) return VAEQ_ERR_SHAPE;
-    if (R == 0) return VAEQ_OK;
     const size_t lds = sizeof(float) * (size_t)(8 * B + 8 * M + 2 * M + 64);
     if (lds > 160 * 1024) return VAEQ_ERR_LDS;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -401,9 +403,9 @@ __global__ __launch_bounds__(256) void dp_forward_bwd_kernel(int N, int sps, int
 extern "C" int vaeq_dp_loss_bwd(int32_t R, int32_t B, int32_t sps, int32_t M, int32_t n_lev, const float *q, const float *x, const float *h,
                                 const float *amp, const float *P, const float *g_up, float *gq, float *gh, void *stream)
 {
+    if (R == 0) return VAEQ_OK;                                // an empty batch owns no memory: its pointers may be NULL
     if (!q || !x || !h || !amp || !P || !g_up || !gq || !gh) return VAEQ_ERR_NULL;
     if (R < 0 || B <= 0 || sps <= 0 || M <= 0 || (M & 1) == 0 || M > 63 || B * sps - 2 * (M / 2) <= 0 || B <= 2 * (M / 2)) return VAEQ_ERR_SHAPE;
-    if (R == 0) return VAEQ_OK;
     const size_t lds = sizeof(float) * (size_t)(8 * B + 4 * (B * sps - 2 * (M / 2)) + 10 * M + 64);
     if (lds > 160 * 1024) return VAEQ_ERR_LDS;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -428,9 +430,9 @@ extern "C" int vaeq_dp_loss_bwd(int32_t R, int32_t B, int32_t sps, int32_t M, in
 extern "C" int vaeq_dp_forward_bwd(int32_t R, int32_t N, int32_t sps, int32_t M, int32_t n_lev, const float *x, const float *q, const float *y,
                                    const float *gq, const float *gy, const float *amp, const float *var, float *gW, void *stream)
 {
+    if (R == 0) return VAEQ_OK;                                // an empty batch owns no memory: its pointers may be NULL
     if (!x || !q || !y || !gq || !amp || !var || !gW) return VAEQ_ERR_NULL;
     if (R < 0 || N <= 0 || sps <= 0 || M <= 0 || (M & 1) == 0 || M > 63) return VAEQ_ERR_SHAPE;
-    if (R == 0) return VAEQ_OK;
     const size_t lds = sizeof(float) * (size_t)4 * N;
     if (lds > 160 * 1024) return VAEQ_ERR_LDS;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
