@@ -234,6 +234,37 @@ int vaeq_gen_dp_frame(int32_t R, int32_t N, int32_t N_conv, int32_t sps, int32_t
                       uint64_t seed, uint32_t frame, float *sig_ws, float *power_ws, float *rx, void *data_f16, float *sigma_out,
                       void *stream);
 
+/* ------------------------------------------------------------------------
+ * the AWGN VAE-NN equalizer (AWGN_channel/func_VAENN_MQAM.py).  Net (:170-188) = Conv1d(2, C, k1, pad k1/2) -> ELU ->
+ * Conv1d(C, C, k2, pad k2/2, stride sps) -> per-axis softmax, C = 2 n_lev; loss_function (:63-95); Adam(amsgrad=True) on all
+ * parameters (:248-253).  One run's parameters are ONE flat vector in the order of net.parameters() followed by h_est:
+ *   theta = [fc1.weight C*2*k1 | fc1.bias C | fc2.weight C*C*k2 | fc2.bias C | h_est 2*M],  vaeq_nn_param_count() floats;
+ * the Adam vectors (m, v, max v) and dbg_g use the same layout.  (Net_BN, the BatchNorm variant, is not implemented.)
+ * vaeq_nn_train replaces the minibatch loop (:274-285) for R runs: step s uses symbols [s*B, (s+1)*B) of rx[R][2][S]. */
+typedef struct vaeq_nn_args {
+    int32_t R, steps, B, sps, M, n_lev, k1, k2;
+    int64_t S;
+    const float *rx;     /* [R][2][S] */
+    float *theta;        /* [R][NP] in/out */
+    float *adam_m;       /* [R][NP] in/out */
+    float *adam_v;       /* [R][NP] in/out */
+    float *adam_x;       /* [R][NP] in/out: max_exp_avg_sq */
+    int32_t *step;       /* [R] in/out */
+    const float *amp;    /* [n_lev] */
+    const float *lr;     /* [R] */
+    float *loss;         /* nullable [R][steps] */
+    float *q_out;        /* nullable [R][2*n_lev][steps*B] */
+    float *dbg_g;        /* nullable [R][NP]: gradient of the LAST step */
+    int32_t no_update;   /* 1: skip the Adam update */
+} vaeq_nn_args;
+
+int vaeq_nn_train(const vaeq_nn_args *args, void *stream);
+int64_t vaeq_nn_param_count(int32_t M, int32_t n_lev, int32_t k1, int32_t k2);
+int64_t vaeq_nn_lds_bytes(int32_t B, int32_t sps, int32_t M, int32_t n_lev, int32_t k1, int32_t k2);
+/* Net.forward in eval mode on N symbols per run (:293-295): x[R][2][N*sps], theta[R][NP] -> q[R][2*n_lev][N]. */
+int vaeq_nn_forward(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, int32_t k1, int32_t k2, const float *x,
+                    const float *theta, float *q, void *stream);
+
 /* Single-polarisation AWGN / ISI channel of AWGN_channel/func_VAELE_MQAM_shaping.py:39-61 (generate_data) for R runs, same three
  * stages without the dispersion step: g[Lg] = rrc * h_channel; sig_ws [R][Ls] complex64 and power_ws [R] are scratch;
  * rx[R][2][sps*N] (:57), data_f16 (nullable) [R][2][N] = symbols ref_offset .. ref_offset+N-1 (:59), sigma_out[R] nullable. */

@@ -223,3 +223,79 @@ def awgn_train(state, rx, n_steps, B, amp, P, amp_mean, var, lr, sps=2, dtype=np
       _p(state.mh), _p(state.vh), _p(state.vmaxh), C.byref(state.step), _p(amp), _p(P), ct(amp_mean), ct(var),
       C.c_double(lr), _p(loss))
     return loss
+
+
+# ------------------------------------------------------------------ AWGN VAE-NN (row f3)
+def nn_param_count(n, k1, k2, M):
+    C_ = 2 * n
+    return C_ * 2 * k1 + C_ + C_ * C_ * k2 + C_ + 2 * M
+
+
+def nn_pack(w1, b1, w2, b2, h, dtype=np.float32):
+    """Flat parameter vector [fc1.weight | fc1.bias | fc2.weight | fc2.bias | h_est] (func_VAENN_MQAM.py:170-176, 244-246)."""
+    return np.concatenate([np.asarray(a, dtype=dtype).reshape(-1) for a in (w1, b1, w2, b2, h)])
+
+
+def nn_unpack(theta, n, k1, k2, M):
+    C_ = 2 * n
+    o = np.cumsum([0, C_ * 2 * k1, C_, C_ * C_ * k2, C_, 2 * M])
+    return (theta[o[0]:o[1]].reshape(C_, 2, k1), theta[o[1]:o[2]], theta[o[2]:o[3]].reshape(C_, C_, k2), theta[o[3]:o[4]],
+            theta[o[4]:o[5]].reshape(2, M))
+
+
+def nn_forward(x, theta, n, k1, k2, sps=2, dtype=np.float32):
+    """Net.forward (func_VAENN_MQAM.py:178-188) -> q[2n, B]."""
+    sfx, ct, npt = _sfx(dtype)
+    x, theta = _arr(x, npt), _arr(theta, npt)
+    L = x.shape[-1]
+    B = L // sps
+    z1, a2, q = np.empty((2 * n, L), npt), np.empty((2 * n, B), npt), np.empty((2 * n, B), npt)
+    f = getattr(lib(), "vaeq_oracle_nn_forward" + sfx)
+    f.restype = None
+    f(B, sps, n, k1, k2, _p(x), _p(theta), _p(z1), _p(a2), _p(q))
+    return q
+
+
+def nn_loss(q, x, h, amp, dtype=np.float32):
+    """loss_function (func_VAENN_MQAM.py:63-95)."""
+    sfx, ct, npt = _sfx(dtype)
+    q, x, h, amp = (_arr(a, npt) for a in (q, x, h, amp))
+    B, L, M, n = q.shape[-1], x.shape[-1], h.shape[-1], amp.shape[0]
+    f = getattr(lib(), "vaeq_oracle_nn_loss" + sfx)
+    f.restype = ct
+    return npt(f(B, L // B, M, n, _p(q), _p(x), _p(h), _p(amp)))
+
+
+def nn_step_grads(x, theta, amp, k1, k2, M, sps=2, dtype=np.float32):
+    sfx, ct, npt = _sfx(dtype)
+    x, theta, amp = _arr(x, npt), _arr(theta, npt), _arr(amp, npt)
+    L, n = x.shape[-1], amp.shape[0]
+    B = L // sps
+    assert theta.size == nn_param_count(n, k1, k2, M)
+    q, g = np.empty((2 * n, B), npt), np.empty(theta.size, npt)
+    f = getattr(lib(), "vaeq_oracle_nn_step_grads" + sfx)
+    f.restype = ct
+    loss = f(B, sps, M, n, k1, k2, _p(x), _p(theta), _p(amp), _p(q), _p(g))
+    return dict(q=q, loss=npt(loss), g=g)
+
+
+class NNState:
+    """Caller-owned state of one VAE-NN run: flat parameters + AMSGrad moments + step count."""
+
+    def __init__(self, theta, dtype=np.float32):
+        self.theta = np.array(theta, dtype=dtype).reshape(-1)
+        self.m, self.v, self.vmax = (np.zeros_like(self.theta) for _ in range(3))
+        self.step = C.c_int(0)
+
+
+def nn_train(state, rx, n_steps, B, amp, k1, k2, M, lr, sps=2, dtype=np.float32):
+    sfx, ct, npt = _sfx(dtype)
+    rx, amp = _arr(rx, npt), _arr(amp, npt)
+    S, n = rx.shape[-1], amp.shape[0]
+    assert n_steps * B * sps <= S and state.theta.size == nn_param_count(n, k1, k2, M)
+    loss = np.empty(n_steps, npt)
+    f = getattr(lib(), "vaeq_oracle_nn_train" + sfx)
+    f.restype = None
+    f(n_steps, B, sps, M, n, k1, k2, S, _p(rx), _p(state.theta), _p(state.m), _p(state.v), _p(state.vmax), C.byref(state.step), _p(amp),
+      C.c_double(lr), _p(loss))
+    return loss

@@ -533,6 +533,159 @@ void FN(vaeq_oracle_awgn_train)(int n_steps, int B, int sps, int M, int n, int S
     free(mb);
 }
 
+/* ============================================================== row f3: AWGN VAE-NN (AWGN_channel/func_VAENN_MQAM.py)
+ * Net (NN:170-188): fc1 = Conv1d(2, C, k1, pad k1/2), ELU, fc2 = Conv1d(C, C, k2, pad k2/2, stride sps), C = 2 n;
+ * residual x_res = mean of the sps samples of a symbol added to every logit of its axis; per-axis softmax.
+ * Parameters as one flat vector  theta = [w1[C][2][k1] | b1[C] | w2[C][C][k2] | b2[C] | h[2][M]]. */
+#define NN_NP(C_, k1_, k2_, M_) ((C_) * 2 * (k1_) + (C_) + (C_) * (C_) * (k2_) + (C_) + 2 * (M_))
+
+/* forward: x[2][L] -> z1[C][L] (ELU output), a2[C][B] (fc2 output, before the residual), q[C][B] */
+void FN(vaeq_oracle_nn_forward)(int B, int sps, int n, int k1, int k2, const REAL *x, const REAL *theta, REAL *z1, REAL *a2, REAL *q)
+{
+    const int C = 2 * n, L = B * sps, p1 = k1 / 2, p2 = k2 / 2;
+    const REAL *w1 = theta, *b1 = w1 + C * 2 * k1, *w2 = b1 + C, *b2 = w2 + C * C * k2;
+    for (int c = 0; c < C; c++)
+        for (int s = 0; s < L; s++) {
+            REAL a = b1[c];
+            for (int i = 0; i < 2; i++)
+                for (int k = 0; k < k1; k++) {
+                    const int sx = s + k - p1;
+                    if (sx >= 0 && sx < L) a += w1[(c * 2 + i) * k1 + k] * x[i * L + sx];
+                }
+            z1[c * L + s] = a > 0 ? a : FN(r_exp)(a) - 1;        /* F.elu, alpha = 1 (NN:177) */
+        }
+    for (int c = 0; c < C; c++)
+        for (int nn = 0; nn < B; nn++) {
+            REAL a = b2[c];
+            for (int cc = 0; cc < C; cc++)
+                for (int k = 0; k < k2; k++) {
+                    const int sx = nn * sps + k - p2;
+                    if (sx >= 0 && sx < L) a += w2[(c * C + cc) * k2 + k] * z1[cc * L + sx];
+                }
+            a2[c * B + nn] = a;
+        }
+    for (int ax = 0; ax < 2; ax++)
+        for (int nn = 0; nn < B; nn++) {
+            REAL xres = 0;                                       /* NN:181-183 */
+            for (int i = 0; i < sps; i++) xres += x[ax * L + nn * sps + i] / (REAL)sps;
+            REAL lg[MAXLEV], mx = -1e30, sum = 0;
+            for (int i = 0; i < n; i++) { lg[i] = a2[(ax * n + i) * B + nn] + xres; if (lg[i] > mx) mx = lg[i]; }
+            for (int i = 0; i < n; i++) { lg[i] = FN(r_exp)(lg[i] - mx); sum += lg[i]; }
+            for (int i = 0; i < n; i++) q[(ax * n + i) * B + nn] = lg[i] / sum;   /* nn.Softmax(dim=1), NN:184-186 */
+        }
+}
+
+/* loss_function (NN:63-95): the AWGN VAE-LE ELBO without the prior (entropy instead of KL): awgn_loss_core with P = 1 */
+REAL FN(vaeq_oracle_nn_loss)(int B, int sps, int M, int n, const REAL *q, const REAL *x, const REAL *h, const REAL *amp)
+{
+    REAL ones[MAXLEV];
+    for (int i = 0; i < MAXLEV; i++) ones[i] = 1;
+    return FN(vaeq_oracle_awgn_loss)(B, sps, M, n, q, x, h, amp, ones);
+}
+
+/* forward + loss + backward the way autograd walks it (NN:279-285): g = dL/dtheta (flat), q out */
+REAL FN(vaeq_oracle_nn_step_grads)(int B, int sps, int M, int n, int k1, int k2, const REAL *x, const REAL *theta, const REAL *amp,
+                                   REAL *q, REAL *g)
+{
+    const int C = 2 * n, L = B * sps, mh = M / 2, Mh = 2 * mh, nm = L - Mh, p1 = k1 / 2, p2 = k2 / 2;
+    const REAL *w1 = theta, *w2 = theta + C * 2 * k1 + C, *h = theta + NN_NP(C, k1, k2, M) - 2 * M;
+    REAL *gw1 = g, *gb1 = gw1 + C * 2 * k1, *gw2 = gb1 + C, *gb2 = gw2 + C * C * k2, *gh = gb2 + C;
+    (void)w1;
+    REAL *buf = (REAL *)malloc(sizeof(REAL) * ((size_t)2 * C * L + 2 * C * B + 8 * L + 2 * nm));
+    REAL *z1 = buf, *gz = z1 + C * L, *a2 = gz + C * L, *ga2 = a2 + C * B;
+    REAL *Eq = ga2 + C * B, *Eq2 = Eq + 2 * L, *gEq = Eq2 + 2 * L, *gEq2 = gEq + 2 * L, *Dre = gEq2 + 2 * L, *Dim = Dre + nm;
+    REAL ones[MAXLEV], Cc;
+    for (int i = 0; i < MAXLEV; i++) ones[i] = 1;
+    FN(vaeq_oracle_nn_forward)(B, sps, n, k1, k2, x, theta, z1, a2, q);
+    const REAL loss = FN(awgn_loss_core)(B, sps, M, n, q, x, h, amp, ones, Eq, Eq2, Dre, Dim, &Cc);
+    const REAL gC = (REAL)nm / Cc;
+    for (int i = 0; i < 2 * L; i++) { gEq[i] = 0; gEq2[i] = 0; }
+    for (int j = 0; j <= Mh; j++) {                              /* same graph as the VAE-LE loss (NN:85-88) */
+        const REAL hr = h[j], hi = h[M + j], hh = hr * hr + hi * hi;
+        REAL ghr = 0, ghi = 0, vs = 0;
+        for (int t = 0; t < nm; t++) {
+            const int s = t + Mh - j;
+            const REAL dDr = -2 * (x[mh + t] - Dre[t]) * gC, dDi = -2 * (x[L + mh + t] - Dim[t]) * gC;
+            ghr += dDr * Eq[s] + dDi * Eq[L + s];
+            ghi += -dDr * Eq[L + s] + dDi * Eq[s];
+            gEq[s] += dDr * hr + dDi * hi;
+            gEq[L + s] += -dDr * hi + dDi * hr;
+            gEq2[s] += gC * hh;
+            gEq2[L + s] += gC * hh;
+            gEq[s] += gC * hh * (-2 * Eq[s]);
+            gEq[L + s] += gC * hh * (-2 * Eq[L + s]);
+            vs += (Eq2[s] - Eq[s] * Eq[s]) + (Eq2[L + s] - Eq[L + s] * Eq[L + s]);
+        }
+        gh[j] = ghr + gC * 2 * hr * vs;
+        gh[M + j] = ghi + gC * 2 * hi * vs;
+    }
+    for (int ax = 0; ax < 2; ax++)                               /* dL/dq, softmax backward -> dL/da2 */
+        for (int nn = 0; nn < B; nn++) {
+            const REAL gmu = gEq[ax * L + nn * sps], grho = gEq2[ax * L + nn * sps];
+            const int inr = (nn >= mh && nn < B - mh);
+            REAL gq[MAXLEV], dot = 0;
+            for (int i = 0; i < n; i++) {
+                const REAL qq = q[(ax * n + i) * B + nn];
+                gq[i] = amp[i] * gmu + (amp[i] * amp[i]) * grho;
+                if (inr) gq[i] += FN(r_log)(qq + (REAL)1e-12) + qq / (qq + (REAL)1e-12);   /* d(q log(q+eps))/dq, NN:90 */
+                dot += qq * gq[i];
+            }
+            for (int i = 0; i < n; i++) ga2[(ax * n + i) * B + nn] = q[(ax * n + i) * B + nn] * (gq[i] - dot);
+        }
+    for (int i = 0; i < C * L; i++) gz[i] = 0;
+    for (int c = 0; c < C; c++) {                                /* fc2 backward */
+        REAL sb = 0;
+        for (int nn = 0; nn < B; nn++) sb += ga2[c * B + nn];
+        gb2[c] = sb;
+        for (int cc = 0; cc < C; cc++)
+            for (int k = 0; k < k2; k++) {
+                REAL sw = 0;
+                const REAL w = w2[(c * C + cc) * k2 + k];
+                for (int nn = 0; nn < B; nn++) {
+                    const int sx = nn * sps + k - p2;
+                    if (sx < 0 || sx >= L) continue;
+                    sw += ga2[c * B + nn] * z1[cc * L + sx];
+                    gz[cc * L + sx] += w * ga2[c * B + nn];
+                }
+                gw2[(c * C + cc) * k2 + k] = sw;
+            }
+    }
+    for (int i = 0; i < C * L; i++) gz[i] *= z1[i] > 0 ? 1 : z1[i] + 1;   /* ELU': 1 or exp(a) = z1 + 1 */
+    for (int c = 0; c < C; c++) {                                /* fc1 backward */
+        REAL sb = 0;
+        for (int s = 0; s < L; s++) sb += gz[c * L + s];
+        gb1[c] = sb;
+        for (int i = 0; i < 2; i++)
+            for (int k = 0; k < k1; k++) {
+                REAL sw = 0;
+                for (int s = 0; s < L; s++) {
+                    const int sx = s + k - p1;
+                    if (sx >= 0 && sx < L) sw += gz[c * L + s] * x[i * L + sx];
+                }
+                gw1[(c * 2 + i) * k1 + k] = sw;
+            }
+    }
+    free(buf);
+    return loss;
+}
+
+/* minibatch loop with Adam(amsgrad=True) on every parameter (NN:248-253, 274-285) */
+void FN(vaeq_oracle_nn_train)(int n_steps, int B, int sps, int M, int n, int k1, int k2, int S, const REAL *rx, REAL *theta, REAL *am,
+                              REAL *av, REAL *avmax, int *step, const REAL *amp, double lr, REAL *loss)
+{
+    const int C = 2 * n, L = B * sps, np_ = NN_NP(C, k1, k2, M);
+    REAL *mb = (REAL *)malloc(sizeof(REAL) * ((size_t)2 * L + C * B + np_));
+    REAL *q = mb + 2 * L, *g = q + C * B;
+    for (int s = 0; s < n_steps; s++) {
+        for (int r = 0; r < 2; r++) memcpy(mb + r * L, rx + (size_t)r * S + (size_t)s * L, sizeof(REAL) * L);   /* NN:276 */
+        loss[s] = FN(vaeq_oracle_nn_step_grads)(B, sps, M, n, k1, k2, mb, theta, amp, q, g);
+        *step += 1;
+        FN(vaeq_oracle_adam)(np_, theta, g, am, av, avmax, *step, lr, 1);
+    }
+    free(mb);
+}
+#undef NN_NP
+
 #undef FN
 #undef CAT
 #undef CAT_

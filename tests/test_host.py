@@ -34,7 +34,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 def test_struct_mirrors_match_header_field_order():
     from vae_equalizer_amd import _native as nat
     header = open(os.path.join(ROOT, "include", "vaeq.h")).read()
-    for name, cls in (("vaeq_dp_args", nat.DPArgs), ("vaeq_awgn_args", nat.AWGNArgs)):
+    for name, cls in (("vaeq_dp_args", nat.DPArgs), ("vaeq_awgn_args", nat.AWGNArgs), ("vaeq_nn_args", nat.NNArgs)):
         body = header[header.index(f"typedef struct {name} {{"):header.index(f"}} {name};")]
         fields = []
         for line in body.splitlines()[1:]:

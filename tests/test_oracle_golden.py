@@ -185,3 +185,46 @@ def test_epilogue_polswap_and_shift(swap, delays):
     assert r["r_q"] == swap and r["r_c"] == swap
     assert tuple(r["shift_q"]) == delays and tuple(r["shift_c"]) == delays
     assert r["SER"].max() == 0.0
+
+
+# ------------------------------------------------------------------ row f3: AWGN VAE-NN (G8)
+G8 = ["G8_vaenn_64qam", "G8_vaenn_16qam_small", "G8_vaenn_4qam_k5"]
+
+
+@pytest.mark.parametrize("name", G8)
+def test_vaenn_forward_loss_grads(name):
+    """Net.forward, loss_function and autograd's gradients of every parameter (fc1/fc2 weights and biases, h_est) at the
+    Xavier-initialised start, teacher-forced on the captured minibatch."""
+    g = load_golden(name)
+    B, sps, k1, k2, M = int(g["B"]), int(g["sps"]), int(g["k1"]), int(g["k2"]), int(g["M_est"])
+    n = len(g["amp_levels"])
+    x = g["rx"][:, :B * sps]
+    for dt, tq, tl, tg in ((np.float32, 2e-6, 2e-6, 2e-4), (np.float64, 2e-6, 2e-6, 2e-4)):
+        q = oracle.nn_forward(x, g["theta0"], n, k1, k2, sps, dt)
+        assert np.max(np.abs(q - g["q0"])) < tq
+        h0 = oracle.nn_unpack(g["theta0"], n, k1, k2, M)[4]
+        assert abs(oracle.nn_loss(g["q0"], x, h0, g["amp_levels"], dt) - g["loss"][0]) / abs(g["loss"][0]) < tl
+        r = oracle.nn_step_grads(x, g["theta0"], g["amp_levels"], k1, k2, M, sps, dt)
+        assert abs(r["loss"] - g["loss"][0]) / abs(g["loss"][0]) < tl
+        gw1, gb1, gw2, gb2, gh = oracle.nn_unpack(r["g"], n, k1, k2, M)
+        rw1, rb1, rw2, rb2, rh = oracle.nn_unpack(g["g0"], n, k1, k2, M)
+        for a, b in ((gw1, rw1), (gb1, rb1), (gw2, rw2), (gb2, rb2), (gh, rh)):
+            assert relerr(a, b) < tg
+
+
+@pytest.mark.parametrize("name", G8)
+def test_vaenn_free_run(name):
+    """n_steps of the minibatch loop with Adam(amsgrad) on all 1650 parameters (64-QAM case): losses, parameters, moments."""
+    g = load_golden(name)
+    B, sps, k1, k2, M, ns = int(g["B"]), int(g["sps"]), int(g["k1"]), int(g["k2"]), int(g["M_est"]), int(g["n_steps"])
+    st = oracle.NNState(g["theta0"], np.float32)
+    loss = oracle.nn_train(st, g["rx"], ns, B, g["amp_levels"], k1, k2, M, float(g["lr"]), sps, np.float32)
+    assert np.max(np.abs(loss[:3] - g["loss"][:3]) / np.abs(g["loss"][:3])) < 1e-5
+    assert np.max(np.abs(loss - g["loss"]) / np.abs(g["loss"])) < 2e-3          # Adam amplifies rounding on near-zero gradients
+    assert np.max(np.abs(st.theta - g[f"theta{ns}"])) < (5e-5 if ns <= 3 else 2 * ns * float(g["lr"]))
+    st3 = oracle.NNState(g["theta0"], np.float32)
+    oracle.nn_train(st3, g["rx"], 1, B, g["amp_levels"], k1, k2, M, float(g["lr"]), sps, np.float32)
+    # one step: every parameter moves by ~lr in the direction of its gradient's sign; entries with a rounding-level gradient may flip
+    ok = np.abs(g["g0"]) > 1e-4 * np.abs(g["g0"]).max()
+    assert np.max(np.abs(st3.theta - g["theta1"])[ok]) < 2e-6
+    assert np.max(np.abs(st3.theta - g["theta1"])) < 2.01 * float(g["lr"])

@@ -31,7 +31,7 @@ def _worker(rank, world, port, n_runs, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_runs", [(2, 7), (2, 8), (3, 4)])
+@pytest.mark.parametrize("world,n_runs", [(2, 7), (2, 8), (3, 4), (3, 2)])   # (3, 2): one rank owns no run
 def test_shard_and_gather(world, n_runs):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -447,6 +447,78 @@ def capture_G7(sfun, awgn, full=False):
     save("G7_full_runs" if full else "G7_runs", **res)
 
 
+# --------------------------------------------------------------------------
+# G8: AWGN VAE-NN (row f3): Net + loss_function + Adam(amsgrad) of AWGN_channel/func_VAENN_MQAM.py
+# --------------------------------------------------------------------------
+def _nn_case(mod, SNR, M_est, k1, k2, B, seed, n_steps, lr=4e-3, channel="h1"):
+    import func_VAENN_MQAM as nnref  # reference module
+
+    sps = 2
+    torch.manual_seed(seed)
+    ir = {"h1": [0.0545 + 0.05j, 0.2823 - 0.11971j, -0.7676 + 0.2788j, -0.0641 - 0.0576j, 0.0466 - 0.02275j],
+          "h2": [0.0545 + 0.0165j, -1.3449 - 0.4523j, 1.0067 + 1.1524j, 0.3476 + 0.3153j]}[channel]
+    ir = np.array(ir).astype(np.complex64)
+    h_channel = np.zeros(sps * (len(ir) - 1) + 1, dtype=np.complex64)
+    h_channel[0::sps] = ir
+    h_channel /= np.linalg.norm(h_channel)
+    nlev = {"4-QAM": 2, "16-QAM": 4, "64-QAM": 8}[mod]
+    ask = np.arange(-(nlev - 1), nlev, 2).astype(np.float64)
+    constellation = (ask[:, None] + 1j * ask[None, :]).reshape(-1)
+    constellation = constellation / np.sqrt(np.mean(np.abs(constellation) ** 2))        # NN:233
+    amp_levels = torch.tensor(constellation.real[::nlev], dtype=torch.float32)          # NN:235-237
+    with SeededRng(seed):
+        rx, data = nnref.generate_data(B * n_steps, len(ir), constellation, SNR, h_channel, sps, "cpu")
+    net = nnref.Net(k1, k2, nlev, sps)
+    h_est = np.zeros([2, M_est])
+    h_est[0, M_est // 2] = 1
+    h_est = torch.tensor(h_est, requires_grad=True, dtype=torch.float32)
+    opt = torch.optim.Adam(net.parameters(), lr=lr, amsgrad=True)
+    opt.add_param_group({"params": h_est})
+    params = [net.fc1.weight, net.fc1.bias, net.fc2.weight, net.fc2.bias, h_est]
+    flat = lambda ts: np.concatenate([t2n(t).reshape(-1) for t in ts])
+    res = dict(rx=t2n(rx), data=t2n(data), theta0=flat(params), amp_levels=t2n(amp_levels), lr=np.float64(lr), B=np.int64(B),
+               M_est=np.int64(M_est), k1=np.int64(k1), k2=np.int64(k2), sps=np.int64(sps), n_steps=np.int64(n_steps), mod=np.array(mod),
+               SNR=np.float64(SNR))
+    losses = np.zeros(n_steps, dtype=np.float32)
+    mb = torch.empty(1, 2, B * sps)
+    for s in range(n_steps):
+        mb[0] = rx[:, s * B * sps:(s + 1) * B * sps]
+        opt.zero_grad()
+        q = net(mb)
+        loss = nnref.loss_function(q.squeeze(), mb.squeeze(), h_est, "cpu", amp_levels)
+        loss.backward()
+        losses[s] = loss.item()
+        if s < 3:
+            res[f"q{s}"], res[f"g{s}"] = t2n(q[0]), flat([p_.grad for p_ in params])
+        opt.step()
+        if s < 3 or s + 1 == n_steps:
+            res[f"theta{s + 1}"] = flat(params)
+    res["loss"] = losses
+    res["m"] = flat([opt.state[p_]["exp_avg"] for p_ in params])
+    res["v"] = flat([opt.state[p_]["exp_avg_sq"] for p_ in params])
+    res["vmax"] = flat([opt.state[p_]["max_exp_avg_sq"] for p_ in params])
+    return res
+
+
+def capture_G8(sfun, awgn):
+    import contextlib
+    import io
+    import func_VAENN_MQAM as nnref  # reference module
+
+    # the sweep script's shape (Eval_run_vaenn.py: 64-QAM, k1 = 25, k2 = 3, M = 25, batch_len 300, lr 4e-3, SNR 24)
+    save("G8_vaenn_64qam", **_nn_case("64-QAM", 24, 25, 25, 3, 300, seed=81, n_steps=10))
+    save("G8_vaenn_16qam_small", **_nn_case("16-QAM", 20, 9, 11, 3, 60, seed=82, n_steps=3, lr=2e-3))
+    save("G8_vaenn_4qam_k5", **_nn_case("4-QAM", 12, 13, 7, 5, 41, seed=83, n_steps=3, channel="h2"))
+    # processing() itself: 16-QAM, 40 epochs x 4 minibatches of 300, validation on 5000 symbols every 2nd epoch
+    t0 = time.time()
+    torch.manual_seed(84)
+    with SeededRng(84), contextlib.redirect_stdout(io.StringIO()):
+        SER = nnref.processing("16-QAM", 2, 20, 25, 25, 3, 4e-3, 300, 5000, 1200, 40, 2, "h1", "Net")
+    print(f"   G8 run: {time.time() - t0:.0f}s  SER {np.round(t2n(SER), 4).tolist()}")
+    save("G8_vaenn_run", SER=t2n(SER), seed=np.int64(84), seconds=np.float64(time.time() - t0),
+         args=np.array(["16-QAM", 2, 20, 25, 25, 3, 4e-3, 300, 5000, 1200, 40, 2, "h1", "Net"], dtype=object))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -455,7 +527,7 @@ def main():
     torch.set_num_threads(1)
     os.makedirs(OUT, exist_ok=True)
     sfun, awgn = _import_reference()
-    todo = [s for s in args.only.split(",") if s] or ["G0", "G1", "G2", "G3", "G4", "G5", "G6", "G7"]
+    todo = [s for s in args.only.split(",") if s] or ["G0", "G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8"]
     for g in todo:
         print(f"[{g}]")
         if g == "G7":

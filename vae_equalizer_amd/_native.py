@@ -13,7 +13,7 @@ import torch
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("VAEQ_LIB") or os.path.join(_PKG, "libvaeq_hip.so")   # VAEQ_LIB: A/B builds of the kernels (tools/build_variant.sh)
-SOURCES = ["vaeq_dp.hip", "vaeq_dp_wave.hip", "vaeq_awgn.hip", "vaeq_awgn_wave.hip", "vaeq_misc.hip", "vaeq_epilogue.hip", "vaeq_gen.hip"]
+SOURCES = ["vaeq_dp.hip", "vaeq_dp_wave.hip", "vaeq_awgn.hip", "vaeq_awgn_wave.hip", "vaeq_misc.hip", "vaeq_nn.hip", "vaeq_epilogue.hip", "vaeq_gen.hip"]
 HEADERS = ["vaeq_common.h", "vaeq_wave.h"]
 _LIB = None
 
@@ -71,9 +71,20 @@ class AWGNArgs(C.Structure):
     ]
 
 
+class NNArgs(C.Structure):
+    """Mirror of ``struct vaeq_nn_args`` (include/vaeq.h)."""
+    _fields_ = [
+        ("R", C.c_int32), ("steps", C.c_int32), ("B", C.c_int32), ("sps", C.c_int32), ("M", C.c_int32), ("n_lev", C.c_int32),
+        ("k1", C.c_int32), ("k2", C.c_int32), ("S", C.c_int64),
+        ("rx", C.c_void_p), ("theta", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("adam_x", C.c_void_p),
+        ("step", C.c_void_p), ("amp", C.c_void_p), ("lr", C.c_void_p), ("loss", C.c_void_p), ("q_out", C.c_void_p), ("dbg_g", C.c_void_p),
+        ("no_update", C.c_int32),
+    ]
+
+
 # every symbol include/vaeq.h declares; tests check the library exports all of them
 EXPORTS = ["vaeq_dp_train", "vaeq_dp_lds_bytes", "vaeq_dp_resident_runs", "vaeq_soft_demap", "vaeq_dp_forward", "vaeq_dp_loss", "vaeq_dp_loss_bwd", "vaeq_dp_forward_bwd", "vaeq_dp_epilogue", "vaeq_dp_epilogue_ws_bytes", "vaeq_dp_epilogue_compact", "vaeq_gen_dp_tx", "vaeq_gen_dp_disperse", "vaeq_gen_dp_finish", "vaeq_gen_dp_frame", "vaeq_awgn_train",
-           "vaeq_awgn_lds_bytes", "vaeq_awgn_forward", "vaeq_awgn_validate", "vaeq_gen_awgn", "vaeq_version", "vaeq_strerror"]
+           "vaeq_awgn_lds_bytes", "vaeq_awgn_forward", "vaeq_awgn_validate", "vaeq_gen_awgn", "vaeq_nn_train", "vaeq_nn_param_count", "vaeq_nn_lds_bytes", "vaeq_nn_forward", "vaeq_version", "vaeq_strerror"]
 
 
 def lib():
@@ -122,6 +133,14 @@ def lib():
             L.vaeq_awgn_lds_bytes.argtypes = [C.c_int32] * 4
             L.vaeq_awgn_forward.restype = C.c_int
             L.vaeq_awgn_forward.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 8
+        L.vaeq_nn_train.restype = C.c_int
+        L.vaeq_nn_train.argtypes = [C.POINTER(NNArgs), C.c_void_p]
+        L.vaeq_nn_param_count.restype = C.c_int64
+        L.vaeq_nn_param_count.argtypes = [C.c_int32] * 4
+        L.vaeq_nn_lds_bytes.restype = C.c_int64
+        L.vaeq_nn_lds_bytes.argtypes = [C.c_int32] * 6
+        L.vaeq_nn_forward.restype = C.c_int
+        L.vaeq_nn_forward.argtypes = [C.c_int32, C.c_int64] + [C.c_int32] * 5 + [C.c_void_p] * 4
         L.vaeq_gen_dp_frame.restype = C.c_int
         L.vaeq_gen_dp_frame.argtypes = ([C.c_int32] * 9 + [C.c_void_p] * 5 + [C.c_double] * 3 + [C.c_float] * 4 + [C.c_uint64, C.c_uint32]
                                         + [C.c_void_p] * 6)

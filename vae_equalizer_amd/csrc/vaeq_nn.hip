@@ -1,0 +1,452 @@
+// vaeq_nn.hip -- SURVEY row f3: the AWGN VAE-NN equalizer (AWGN_channel/func_VAENN_MQAM.py), training loop and validation pass.
+//
+//   Net.forward (:170-188)   fc1 = Conv1d(2, C, k1, pad k1/2) -> ELU -> fc2 = Conv1d(C, C, k2, pad k2/2, stride sps), C = 2 n_lev;
+//                            per-axis softmax over the n_lev logits.  The residual x_res (:181-186) adds the SAME number to every
+//                            logit of an axis, which a softmax cancels exactly -- it is not computed here.
+//   loss_function (:63-95)   the VAE-LE ELBO of the AWGN channel with the entropy of q in place of the KL to a prior:
+//                            loss = nm log C + sum q log(q + 1e-12),  C = sum|x - D|^2 + sum_j |h_j|^2 VS[j]
+//   Adam(amsgrad=True) (:248-253) on every parameter, one learning rate.
+// Parameters of a run are ONE flat vector theta = [fc1.weight C*2*k1 | fc1.bias C | fc2.weight C*C*k2 | fc2.bias C | h_est 2*M]
+// (the order of net.parameters() followed by h_est); gradients and the three Adam vectors use the same layout.
+//
+// One workgroup per run, everything in LDS (105 KB for 64-QAM / k1 = 25 / B = 300): x window, ELU output z1 (C x L, reused in
+// place for dL/dz1), logits -> q -> dL/dlogits in place, the loss intermediates of vaeq_awgn.hip, theta, gradient, Adam state.
+// Backward = the closed form of the ELBO (vaeq_dp.hip) down to dL/dq, then softmax / conv / ELU / conv backward by the chain rule.
+// fc1 and its weight gradient (the two 480 kMAC loops) are register-blocked 4-wide along the sample axis with a sliding window.
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vaeq.h"
+#include "vaeq_common.h"
+
+namespace vaeq {
+
+struct NNLayout {
+    int C, L, p1, p2, Lx, Lz, mh, Mh, nm, NP, NW1, oW1, oB1, oW2, oB2, oH;
+    int xs, z1, a2, mu, vr, es, VS, th, gr, am, av, ax, part, red, total;
+};
+
+__host__ __device__ inline int npad4(int x) { return (x + 3) & ~3; }
+
+__host__ __device__ inline NNLayout nn_layout(int B, int sps, int M, int n, int k1, int k2)
+{
+    NNLayout l;
+    l.C = 2 * n; l.L = B * sps; l.p1 = k1 / 2; l.p2 = k2 / 2;
+    l.Lx = npad4(l.L + 2 * l.p1 + 8);                  // zero halo + room for the 4-wide windows of the last quad
+    l.Lz = npad4(l.L + 2 * l.p2 + 4);
+    l.mh = M / 2; l.Mh = 2 * l.mh; l.nm = l.L - l.Mh;
+    l.NW1 = l.C * 2 * k1;
+    l.oW1 = 0; l.oB1 = l.NW1; l.oW2 = l.oB1 + l.C; l.oB2 = l.oW2 + l.C * l.C * k2; l.oH = l.oB2 + l.C; l.NP = l.oH + 2 * M;
+    int o = 0;
+    auto take = [&](int cnt) { int r = o; o += npad4(cnt); return r; };
+    l.xs = take(2 * l.Lx);
+    l.z1 = take(l.C * l.Lz);
+    l.a2 = take(l.C * B);
+    l.mu = take(2 * B); l.vr = take(2 * B);
+    l.es = take(2 * l.nm);
+    l.VS = take(M);
+    l.th = take(l.NP); l.gr = take(l.NP); l.am = take(l.NP); l.av = take(l.NP); l.ax = take(l.NP);
+    l.part = take(2 * (l.NW1 + l.C));
+    l.red = take(64);
+    l.total = o;
+    return l;
+}
+
+// ---- forward on one LDS-resident window: xs (zero-haloed input) -> z1 (ELU output, zero-haloed) -> a2 (logits)
+template <int NT, int NLEV>
+__device__ __forceinline__ void nn_fc1_elu(const NNLayout &l, int k1, const float *xs, const float *th, float *z1, int Lvalid, int zlo, int zhi)
+{
+    // z1p[c][p2 + s] for s in [0, Lvalid); entries whose absolute position (zlo + s) lies outside [0, zhi) are fc2's zero padding
+    constexpr int C = 2 * NLEV;
+    const int tid = threadIdx.x, nquad = (Lvalid + 3) / 4;
+    for (int it = tid; it < C * nquad; it += NT) {
+        const int c = it / nquad, s0 = (it - c * nquad) * 4;
+        const float b = th[l.oB1 + c];
+        float a0 = b, a1 = b, a2_ = b, a3 = b;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const float *w = th + l.oW1 + (c * 2 + i) * k1, *xp = xs + i * l.Lx + s0;
+            float x0 = xp[0], x1 = xp[1], x2 = xp[2];
+            for (int k = 0; k < k1; k++) {             // out[s] = sum_k w[k] x[s + k - p1]: the haloed index of x[s + k - p1] is s + k
+                const float x3 = xp[k + 3], wk = w[k];
+                a0 = fmaf(wk, x0, a0); a1 = fmaf(wk, x1, a1); a2_ = fmaf(wk, x2, a2_); a3 = fmaf(wk, x3, a3);
+                x0 = x1; x1 = x2; x2 = x3;
+            }
+        }
+        const float av[4] = {a0, a1, a2_, a3};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int s = s0 + t;
+            if (s < Lvalid) {
+                const int pos = zlo + s;
+                const float z = av[t] > 0.f ? av[t] : __expf(av[t]) - 1.0f;              // F.elu, alpha = 1 (:177)
+                z1[c * l.Lz + l.p2 + s] = (pos >= 0 && pos < zhi) ? z : 0.f;
+            }
+        }
+    }
+}
+
+template <int NT, int NLEV>
+__device__ __forceinline__ void nn_fc2(const NNLayout &l, int sps, int k2, int Bt, int astride, const float *z1, const float *th, float *a2, int zoff)
+{
+    constexpr int C = 2 * NLEV;
+    for (int it = threadIdx.x; it < C * Bt; it += NT) {
+        const int c = it / Bt, n = it - c * Bt;
+        float acc = th[l.oB2 + c];
+        for (int cc = 0; cc < C; cc++) {
+            const float *w = th + l.oW2 + (c * C + cc) * k2, *zp = z1 + cc * l.Lz + zoff + n * sps;   // z1[n sps + k - p2] -> haloed n sps + k
+            for (int k = 0; k < k2; k++) acc = fmaf(w[k], zp[k], acc);
+        }
+        a2[c * astride + n] = acc;
+    }
+}
+
+template <int NT, int NLEV>
+__global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
+{
+    extern __shared__ float4 smem4[];
+    float *sm = reinterpret_cast<float *>(smem4);
+    constexpr int C = 2 * NLEV;
+    const int tid = threadIdx.x, run = blockIdx.x;
+    const int B = a.B, sps = a.sps, M = a.M, k1 = a.k1, k2 = a.k2;
+    const NNLayout l = nn_layout(B, sps, M, NLEV, k1, k2);
+    const int L = l.L, p1 = l.p1, p2 = l.p2, Lx = l.Lx, Lz = l.Lz, mh = l.mh, Mh = l.Mh, nm = l.nm, NP = l.NP;
+    float *xs = sm + l.xs, *z1 = sm + l.z1, *a2 = sm + l.a2, *mu = sm + l.mu, *vr = sm + l.vr, *es = sm + l.es, *VS = sm + l.VS;
+    float *th = sm + l.th, *gr = sm + l.gr, *am = sm + l.am, *av = sm + l.av, *ax = sm + l.ax, *part = sm + l.part, *red = sm + l.red;
+    const float *hs = th + l.oH;                               // h_est[2][M]: re row, im row
+
+    float amp[NLEV];
+#pragma unroll
+    for (int i = 0; i < NLEV; i++) amp[i] = a.amp[i];
+    const double lr = (double)a.lr[run];
+    for (int i = tid; i < NP; i += NT) {
+        const size_t g = (size_t)run * NP + i;
+        th[i] = a.theta[g]; am[i] = a.adam_m[g]; av[i] = a.adam_v[g]; ax[i] = a.adam_x[g];
+    }
+    for (int i = tid; i < 2 * Lx; i += NT) xs[i] = 0.f;        // halos stay zero
+    for (int i = tid; i < C * Lz; i += NT) z1[i] = 0.f;
+    int step = a.step[run];
+    double b1t = pow(0.9, (double)step), b2t = pow(0.999, (double)step);
+    __syncthreads();
+
+    const size_t No = (size_t)a.steps * B;
+    const float *rxr = a.rx + (size_t)run * 2 * (size_t)a.S;
+    float *qf = a.q_out ? a.q_out + (size_t)run * C * No : nullptr;
+
+    for (int s = 0; s < a.steps; s++) {
+        // ---- P0: minibatch -> LDS (:276)
+        for (int i = tid; i < 2 * L; i += NT) {
+            const int row = i / L, c = i - row * L;
+            xs[row * Lx + p1 + c] = rxr[(size_t)row * a.S + (size_t)s * L + c];
+        }
+        __syncthreads();
+        // ---- P1/P2: fc1 + ELU, fc2
+        nn_fc1_elu<NT, NLEV>(l, k1, xs, th, z1, L, 0, L);
+        __syncthreads();
+        nn_fc2<NT, NLEV>(l, sps, k2, B, B, z1, th, a2, 0);
+        __syncthreads();
+        // ---- P3: per-axis softmax -> q (in place), moments, entropy term; item = (axis, n)
+        float klsum = 0.f;
+        for (int it = tid; it < 2 * B; it += NT) {
+            const int axq = it / B, n = it - axq * B;
+            float z[NLEV], zmax = -3.0e38f;
+#pragma unroll
+            for (int i = 0; i < NLEV; i++) { z[i] = a2[(axq * NLEV + i) * B + n]; zmax = fmaxf(zmax, z[i]); }
+            float ssum = 0.f;
+#pragma unroll
+            for (int i = 0; i < NLEV; i++) { z[i] = __expf(z[i] - zmax); ssum += z[i]; }
+            const float rs = 1.0f / ssum;
+            float e1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NLEV; i++) { z[i] *= rs; e1 = fmaf(amp[i], z[i], e1); }
+            float e2 = 0.f;
+            const bool inr = (n >= mh) && (n < B - mh);        // entropy slice (:90)
+#pragma unroll
+            for (int i = 0; i < NLEV; i++) {
+                const float d = amp[i] - e1;
+                e2 = fmaf(z[i] * d, d, e2);
+                if (inr) klsum = fmaf(z[i], __logf(z[i] + 1e-12f), klsum);
+                a2[(axq * NLEV + i) * B + n] = z[i];
+                if (qf) qf[(size_t)(axq * NLEV + i) * No + (size_t)s * B + n] = z[i];
+            }
+            mu[it] = e1; vr[it] = e2;
+        }
+        __syncthreads();
+        // ---- P4: residual e = x - D (item t), VS (item j), C
+        float se = 0.f;
+        for (int t = tid; t < nm; t += NT) {
+            float dr = 0.f, di = 0.f;
+            for (int j = (t + Mh) % sps; j <= Mh; j += sps) {
+                const int np = (t + Mh - j) / sps;
+                const float a_ = mu[np], b_ = mu[B + np], c_ = hs[j], d_ = hs[M + j];
+                dr = fmaf(c_, a_, dr); dr = fmaf(-d_, b_, dr);
+                di = fmaf(c_, b_, di); di = fmaf(d_, a_, di);
+            }
+            const float er = xs[p1 + mh + t] - dr, ei = xs[Lx + p1 + mh + t] - di;
+            es[t] = er; es[nm + t] = ei;
+            se += er * er + ei * ei;
+        }
+        for (int j = tid; j < M; j += NT) {
+            const int lo = (Mh - j + sps - 1) / sps, hi_ = (nm - 1 + Mh - j) / sps;
+            float acc = 0.f;
+            for (int np = lo; np <= hi_; np++) acc += vr[np] + vr[B + np];
+            VS[j] = acc;
+        }
+        block_reduce3<NT>(se, klsum, 0.f, red);
+        float Cc = red[0];
+        for (int j = 0; j < M; j++) Cc = fmaf(hs[j] * hs[j] + hs[M + j] * hs[M + j], VS[j], Cc);
+        const float gC = (float)nm / Cc;
+        if (tid == 0 && a.loss) a.loss[(size_t)run * a.steps + s] = (float)nm * logf(Cc) + red[1];
+        // ---- P5: dL/dh (item j)
+        for (int j = tid; j < M; j += NT) {
+            const int lo = (Mh - j + sps - 1) / sps, hi_ = (nm - 1 + Mh - j) / sps;
+            float ar = 0.f, ai = 0.f;
+            for (int np = lo; np <= hi_; np++) {
+                const int t = np * sps - Mh + j;
+                const float a_ = es[t], b_ = es[nm + t], c_ = mu[np], d_ = mu[B + np];
+                ar = fmaf(a_, c_, ar); ar = fmaf(b_, d_, ar);
+                ai = fmaf(b_, c_, ai); ai = fmaf(-a_, d_, ai);
+            }
+            gr[l.oH + j] = gC * (-2.0f * ar + 2.0f * hs[j] * VS[j]);
+            gr[l.oH + M + j] = gC * (-2.0f * ai + 2.0f * hs[M + j] * VS[j]);
+        }
+        // ---- P6: dL/dmu, dL/drho -> dL/dq -> softmax backward -> dL/dlogits in place of q; item = n (both axes)
+        for (int n = tid; n < B; n += NT) {
+            const int sx = n * sps;
+            const int jlo = max(0, Mh - sx), jhi = min(Mh, nm - 1 + Mh - sx);
+            const float *er = es + (sx - Mh), *ei = er + nm;
+            float pr = 0.f, pi = 0.f, ph = 0.f;
+            for (int j = jlo; j <= jhi; j++) {
+                const float a_ = er[j], b_ = ei[j], c_ = hs[j], d_ = hs[M + j];
+                pr = fmaf(a_, c_, pr); pr = fmaf(b_, d_, pr);
+                pi = fmaf(b_, c_, pi); pi = fmaf(-a_, d_, pi);
+                ph = fmaf(c_, c_, ph); ph = fmaf(d_, d_, ph);
+            }
+            const float gv = gC * ph;
+            const bool inr = (n >= mh) && (n < B - mh);
+#pragma unroll
+            for (int axq = 0; axq < 2; axq++) {
+                const float gmu = -2.0f * gC * (axq ? pi : pr) - 2.0f * mu[axq * B + n] * gv;   // incl. the -mu^2 part of the variance
+                float q[NLEV], gq[NLEV], dot = 0.f;
+#pragma unroll
+                for (int i = 0; i < NLEV; i++) {
+                    q[i] = a2[(axq * NLEV + i) * B + n];
+                    gq[i] = amp[i] * gmu + amp[i] * amp[i] * gv;
+                    if (inr) gq[i] += __logf(q[i] + 1e-12f) + q[i] / (q[i] + 1e-12f);
+                    dot = fmaf(q[i], gq[i], dot);
+                }
+#pragma unroll
+                for (int i = 0; i < NLEV; i++) a2[(axq * NLEV + i) * B + n] = q[i] * (gq[i] - dot);
+            }
+        }
+        __syncthreads();
+        // ---- P7a: fc2 weight / bias gradients; item = (c, cc, k) or (c)
+        for (int it = tid; it < C * C * k2 + C; it += NT) {
+            float acc = 0.f;
+            if (it < C * C * k2) {
+                const int c = it / (C * k2), rem = it - c * (C * k2), cc = rem / k2, k = rem - cc * k2;
+                const float *g = a2 + c * B, *zp = z1 + cc * Lz + k;
+                for (int n = 0; n < B; n++) acc = fmaf(g[n], zp[n * sps], acc);
+                gr[l.oW2 + it] = acc;
+            } else {
+                const float *g = a2 + (it - C * C * k2) * B;
+                for (int n = 0; n < B; n++) acc += g[n];
+                gr[l.oB2 + it - C * C * k2] = acc;
+            }
+        }
+        __syncthreads();
+        // ---- P7b: dL/dz1 through fc2, times ELU' -> dL/da1 in place of z1; item = (cc, s)
+        for (int it = tid; it < C * L; it += NT) {
+            const int cc = it / L, sx = it - cc * L;
+            float acc = 0.f;
+            for (int k = 0; k < k2; k++) {
+                const int t = sx + p2 - k;
+                if (t < 0 || t % sps) continue;
+                const int n = t / sps;
+                if (n >= B) continue;
+                for (int c = 0; c < C; c++) acc = fmaf(th[l.oW2 + (c * C + cc) * k2 + k], a2[c * B + n], acc);
+            }
+            const float z = z1[cc * Lz + p2 + sx];
+            z1[cc * Lz + p2 + sx] = acc * (z > 0.f ? 1.0f : z + 1.0f);                    // ELU' = 1 or exp(a1) = z1 + 1
+        }
+        __syncthreads();
+        // ---- P8: fc1 weight / bias gradients, 4 taps per item, two halves of the sample range; item = (c, i, k-quad, half) or (c, half)
+        {
+            const int nkq = (k1 + 3) / 4, nW = C * 2 * nkq * 2, Lh = (L + 1) / 2;
+            for (int it = tid; it < nW + 2 * C; it += NT) {
+                if (it < nW) {
+                    const int half = it & 1, r = it >> 1, kq = r % nkq, ci = r / nkq;   // ci = c * 2 + i
+                    const int c = ci >> 1, i = ci & 1, k0 = kq * 4, s0 = half * Lh, s1 = min(L, s0 + Lh);
+                    const float *g = z1 + c * Lz + p2, *xp = xs + i * Lx + k0;
+                    float a0 = 0.f, a1 = 0.f, a2_ = 0.f, a3 = 0.f;
+                    float x0 = xp[s0], x1 = xp[s0 + 1], x2 = xp[s0 + 2];
+                    for (int sx = s0; sx < s1; sx++) {          // gw1[c][i][k] = sum_s gz[c][s] x[i][s + k - p1] -> haloed index s + k
+                        const float x3 = xp[sx + 3], gz = g[sx];
+                        a0 = fmaf(gz, x0, a0); a1 = fmaf(gz, x1, a1); a2_ = fmaf(gz, x2, a2_); a3 = fmaf(gz, x3, a3);
+                        x0 = x1; x1 = x2; x2 = x3;
+                    }
+                    const float av4[4] = {a0, a1, a2_, a3};
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                        if (k0 + t < k1) part[half * (l.NW1 + C) + ci * k1 + k0 + t] = av4[t];
+                } else {
+                    const int r = it - nW, half = r & 1, c = r >> 1, s0 = half * Lh, s1 = min(L, s0 + Lh);
+                    const float *g = z1 + c * Lz + p2;
+                    float acc = 0.f;
+                    for (int sx = s0; sx < s1; sx++) acc += g[sx];
+                    part[half * (l.NW1 + C) + l.NW1 + c] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < l.NW1 + C; i += NT) gr[i] = part[i] + part[l.NW1 + C + i];   // oW1 = 0, oB1 = NW1: contiguous
+        __syncthreads();
+        // ---- P9: Adam(amsgrad) on every parameter (:285)
+        step += 1;
+        b1t *= 0.9;
+        b2t *= 0.999;
+        if (!a.no_update) {
+            const float bc2s = (float)sqrt(1.0 - b2t), ss = (float)(lr / (1.0 - b1t));
+            for (int i = tid; i < NP; i += NT) adam_update_amsgrad(th[i], am[i], av[i], ax[i], gr[i], ss, bc2s);
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < NP; i += NT) {
+        const size_t g = (size_t)run * NP + i;
+        if (!a.no_update) { a.theta[g] = th[i]; a.adam_m[g] = am[i]; a.adam_v[g] = av[i]; a.adam_x[g] = ax[i]; }
+        if (a.dbg_g) a.dbg_g[g] = gr[i];
+    }
+    if (tid == 0 && !a.no_update) a.step[run] = step;
+}
+
+// ---- eval-mode forward over N symbols in tiles (validation, :293-301): q[R][C][N]
+constexpr int NN_TILE = 256;                           // symbols per tile
+
+template <int NT, int NLEV>
+__device__ __forceinline__ void nn_forward_tile(const NNLayout &l, int sps, int k1, int k2, int64_t Ltot, const float *x0, const float *x1,
+                                                int n0, int Bt, float *xs, float *z1, float *a2, const float *th)
+{
+    // tile symbols n0 .. n0+Bt-1: z1 needed at absolute positions [n0 sps - p2, (n0+Bt-1) sps + k2 - p2), x p1 beyond that on both sides
+    const int tid = threadIdx.x, p1 = l.p1, p2 = l.p2;
+    const int zlo = n0 * sps - p2, Lz_need = (Bt - 1) * sps + k2, xlo = zlo - p1, Lx_need = Lz_need + 2 * p1;
+    for (int i = tid; i < 2 * (Lx_need + 4); i += NT) {
+        const int row = i / (Lx_need + 4), c = i - row * (Lx_need + 4);
+        const int64_t sx = (int64_t)xlo + c;
+        xs[row * l.Lx + c] = (c < Lx_need && sx >= 0 && sx < Ltot) ? (row ? x1[sx] : x0[sx]) : 0.f;
+    }
+    __syncthreads();
+    // fc1 writes z1p[c][p2 + s] for s in [0, Lz_need) with absolute position zlo + s: shift the base so that p2 + s -> s
+    nn_fc1_elu<NT, NLEV>(l, k1, xs, th, z1 - p2, Lz_need, zlo, (int)Ltot);
+    __syncthreads();
+    nn_fc2<NT, NLEV>(l, sps, k2, Bt, NN_TILE, z1, th, a2, 0);   // haloed index of z1[n sps + k - p2] relative to zlo is n sps + k
+    __syncthreads();
+}
+
+template <int NT, int NLEV>
+__global__ __launch_bounds__(NT) void nn_forward_kernel(int N, int sps, int M, int k1, int k2, const float *__restrict__ x,
+                                                        const float *__restrict__ theta, float *__restrict__ q)
+{
+    extern __shared__ float4 smem4[];
+    float *sm = reinterpret_cast<float *>(smem4);
+    constexpr int C = 2 * NLEV;
+    const int tid = threadIdx.x, run = blockIdx.x;
+    const NNLayout l = nn_layout(NN_TILE, sps, M, NLEV, k1, k2);
+    float *xs = sm + l.xs, *z1 = sm + l.z1, *a2 = sm + l.a2, *th = sm + l.th;
+    for (int i = tid; i < l.NP; i += NT) th[i] = theta[(size_t)run * l.NP + i];
+    __syncthreads();
+    const int64_t Ltot = (int64_t)N * sps;
+    const float *x0 = x + (size_t)run * 2 * Ltot, *x1 = x0 + Ltot;
+    for (int n0 = 0; n0 < N; n0 += NN_TILE) {
+        const int Bt = min(NN_TILE, N - n0);
+        nn_forward_tile<NT, NLEV>(l, sps, k1, k2, Ltot, x0, x1, n0, Bt, xs, z1, a2, th);
+        for (int it = tid; it < 2 * Bt; it += NT) {
+            const int axq = it / Bt, n = it - axq * Bt;
+            float z[NLEV], zmax = -3.0e38f, ssum = 0.f;
+#pragma unroll
+            for (int i = 0; i < NLEV; i++) { z[i] = a2[(axq * NLEV + i) * NN_TILE + n]; zmax = fmaxf(zmax, z[i]); }
+#pragma unroll
+            for (int i = 0; i < NLEV; i++) { z[i] = __expf(z[i] - zmax); ssum += z[i]; }
+#pragma unroll
+            for (int i = 0; i < NLEV; i++) q[((size_t)run * C + axq * NLEV + i) * N + n0 + n] = z[i] / ssum;
+        }
+        __syncthreads();
+    }
+}
+
+template <int NLEV>
+static int launch_nn_train(const vaeq_nn_args &a, size_t lds, hipStream_t st)
+{
+    auto k = nn_train_kernel<512, NLEV>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return VAEQ_ERR_LDS;
+    hipLaunchKernelGGL(k, dim3(a.R), dim3(512), lds, st, a);
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}
+
+template <int NLEV>
+static int launch_nn_forward(int R, int N, int sps, int M, int k1, int k2, const float *x, const float *theta, float *q, hipStream_t st)
+{
+    const size_t lds = (size_t)nn_layout(NN_TILE, sps, M, NLEV, k1, k2).total * 4;
+    auto k = nn_forward_kernel<512, NLEV>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return VAEQ_ERR_LDS;
+    hipLaunchKernelGGL(k, dim3(R), dim3(512), lds, st, N, sps, M, k1, k2, x, theta, q);
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}
+
+static bool nn_shape_ok(int B, int sps, int M, int n_lev, int k1, int k2)
+{
+    if (B <= 0 || sps <= 0 || sps > 8 || M <= 0 || (M & 1) == 0 || M > 63 || !(n_lev == 2 || n_lev == 4 || n_lev == 8)) return false;
+    if (k1 <= 0 || (k1 & 1) == 0 || k1 > 63 || k2 <= 0 || (k2 & 1) == 0 || k2 > 9) return false;
+    return (int64_t)B * sps - 2 * (M / 2) > 0 && B > 2 * (M / 2);
+}
+
+}  // namespace vaeq
+
+extern "C" int64_t vaeq_nn_param_count(int32_t M, int32_t n_lev, int32_t k1, int32_t k2)
+{
+    if (!vaeq::nn_shape_ok(2 * (M / 2) + 1, 1, M, n_lev, k1, k2)) return VAEQ_ERR_SHAPE;
+    return vaeq::nn_layout(64, 1, M, n_lev, k1, k2).NP;
+}
+
+extern "C" int64_t vaeq_nn_lds_bytes(int32_t B, int32_t sps, int32_t M, int32_t n_lev, int32_t k1, int32_t k2)
+{
+    if (!vaeq::nn_shape_ok(B, sps, M, n_lev, k1, k2)) return VAEQ_ERR_SHAPE;
+    return (int64_t)vaeq::nn_layout(B, sps, M, n_lev, k1, k2).total * 4;
+}
+
+extern "C" int vaeq_nn_train(const vaeq_nn_args *pa, void *stream)
+{
+    if (!pa) return VAEQ_ERR_NULL;
+    const vaeq_nn_args &a = *pa;
+    if (a.R == 0) return VAEQ_OK;                              // an empty batch owns no memory: its pointers may be NULL
+    if (!a.rx || !a.theta || !a.adam_m || !a.adam_v || !a.adam_x || !a.step || !a.amp || !a.lr) return VAEQ_ERR_NULL;
+    const int64_t lds = vaeq_nn_lds_bytes(a.B, a.sps, a.M, a.n_lev, a.k1, a.k2);
+    if (lds < 0) return (int)lds;
+    if (lds > 160 * 1024) return VAEQ_ERR_LDS;
+    if (a.R < 0 || a.steps <= 0 || (int64_t)a.steps * a.B * a.sps > a.S) return VAEQ_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (a.n_lev) {
+    case 2: return vaeq::launch_nn_train<2>(a, (size_t)lds, st);
+    case 4: return vaeq::launch_nn_train<4>(a, (size_t)lds, st);
+    case 8: return vaeq::launch_nn_train<8>(a, (size_t)lds, st);
+    }
+    return VAEQ_ERR_SHAPE;
+}
+
+extern "C" int vaeq_nn_forward(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, int32_t k1, int32_t k2, const float *x,
+                               const float *theta, float *q, void *stream)
+{
+    if (R == 0 || N == 0) return VAEQ_OK;
+    if (!x || !theta || !q) return VAEQ_ERR_NULL;
+    if (R < 0 || N < 0 || N > 0x3fffffff || !vaeq::nn_shape_ok(vaeq::NN_TILE, sps, M, n_lev, k1, k2)) return VAEQ_ERR_SHAPE;
+    if ((int64_t)vaeq::nn_layout(vaeq::NN_TILE, sps, M, n_lev, k1, k2).total * 4 > 160 * 1024) return VAEQ_ERR_LDS;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (n_lev) {
+    case 2: return vaeq::launch_nn_forward<2>(R, (int)N, sps, M, k1, k2, x, theta, q, st);
+    case 4: return vaeq::launch_nn_forward<4>(R, (int)N, sps, M, k1, k2, x, theta, q, st);
+    case 8: return vaeq::launch_nn_forward<8>(R, (int)N, sps, M, k1, k2, x, theta, q, st);
+    }
+    return VAEQ_ERR_SHAPE;
+}

@@ -245,6 +245,76 @@ class AWGNEngine:
         return ser, shift, y
 
 
+class NNEngine:
+    """R independent AWGN VAE-NN runs (AWGN_channel/func_VAENN_MQAM.py): flat per-run parameter vectors
+    theta = [fc1.weight | fc1.bias | fc2.weight | fc2.bias | h_est] and their AMSGrad state on the device."""
+
+    def __init__(self, R, M_est, kernel_1, kernel_2, amp_levels, device="cuda:0", sps=2):
+        self.device = torch.device(device)
+        self.amp = _f32(amp_levels, self.device).reshape(-1).contiguous()
+        self.R, self.M, self.k1, self.k2, self.sps, self.n_lev = int(R), int(M_est), int(kernel_1), int(kernel_2), int(sps), self.amp.numel()
+        NP = int(nat.lib().vaeq_nn_param_count(self.M, self.n_lev, self.k1, self.k2))
+        if NP < 0:
+            raise ValueError(f"unsupported VAE-NN shape M={M_est} k1={kernel_1} k2={kernel_2} n_lev={self.n_lev}: "
+                             + nat.lib().vaeq_strerror(NP).decode())
+        self.NP = NP
+        z = lambda: torch.zeros(self.R, NP, dtype=torch.float32, device=self.device)
+        self.theta, self.m, self.v, self.vmax = z(), z(), z(), z()
+        self.step = torch.zeros(self.R, dtype=torch.int32, device=self.device)
+
+    def offsets(self):
+        C_ = 2 * self.n_lev
+        o = [0, C_ * 2 * self.k1]
+        o += [o[-1] + C_, o[-1] + C_ + C_ * C_ * self.k2]
+        o += [o[-1] + C_, o[-1] + C_ + 2 * self.M]
+        return o
+
+    def init_parameters(self, generator=None):
+        """nn.init.xavier_uniform_ on both conv weights, PyTorch's default uniform(+-1/sqrt(fan_in)) on the biases (:172-176), Dirac
+        h_est (:244-246), independently per run."""
+        C_, o = 2 * self.n_lev, self.offsets()
+        u = lambda n, bound: (torch.rand(self.R, n, generator=generator, device=self.device) * 2 - 1) * bound
+        self.theta[:, o[0]:o[1]] = u(o[1] - o[0], (6.0 / (2 * self.k1 + C_ * self.k1)) ** 0.5)           # fan_in 2 k1, fan_out C k1
+        self.theta[:, o[1]:o[2]] = u(C_, (2 * self.k1) ** -0.5)
+        self.theta[:, o[2]:o[3]] = u(o[3] - o[2], (6.0 / (2 * C_ * self.k2)) ** 0.5)
+        self.theta[:, o[3]:o[4]] = u(C_, (C_ * self.k2) ** -0.5)
+        self.theta[:, o[4]:] = 0
+        self.theta[:, o[4] + self.M // 2] = 1
+        for t in (self.m, self.v, self.vmax):
+            t.zero_()
+        self.step.zero_()
+
+    def train(self, rx, B, steps, lr, want_q=False, debug_grads=False, no_update=False):
+        """rx[R,2,S] -> dict(loss[R,steps], q[R,2n,steps*B]?, g[R,NP]?)."""
+        R, S = rx.shape[0], rx.shape[-1]
+        if R != self.R or rx.dim() != 3 or rx.shape[1] != 2:
+            raise ValueError(f"rx must be [R={self.R}, 2, S], got {tuple(rx.shape)}")
+        rx = rx.contiguous()
+        dev = self.device
+        lr_t = _f32(lr, dev).expand(R).contiguous()
+        out = {"loss": torch.empty(R, steps, dtype=torch.float32, device=dev),
+               "q": torch.empty(R, 2 * self.n_lev, steps * B, dtype=torch.float32, device=dev) if want_q else None,
+               "g": torch.empty(R, self.NP, dtype=torch.float32, device=dev) if debug_grads else None}
+        a = nat.NNArgs(R=R, steps=steps, B=B, sps=self.sps, M=self.M, n_lev=self.n_lev, k1=self.k1, k2=self.k2, S=S, rx=nat.ptr(rx),
+                       theta=nat.ptr(self.theta), adam_m=nat.ptr(self.m), adam_v=nat.ptr(self.v), adam_x=nat.ptr(self.vmax),
+                       step=nat.ptr(self.step, torch.int32), amp=nat.ptr(self.amp), lr=nat.ptr(lr_t), loss=nat.ptr(out["loss"]),
+                       q_out=nat.ptr(out["q"]), dbg_g=nat.ptr(out["g"]), no_update=int(no_update))
+        with torch.cuda.device(dev):
+            nat.check(nat.lib().vaeq_nn_train(C.byref(a), nat.current_stream(dev)), "vaeq_nn_train")
+        out["_keepalive"] = (lr_t, rx)
+        return out
+
+    def forward(self, x):
+        """Validation pass (:293-295): x[R,2,N*sps] -> q[R,2n,N]."""
+        R, N = x.shape[0], x.shape[-1] // self.sps
+        x = x.contiguous()
+        q = torch.empty(R, 2 * self.n_lev, N, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().vaeq_nn_forward(R, N, self.sps, self.M, self.n_lev, self.k1, self.k2, nat.ptr(x), nat.ptr(self.theta),
+                                                nat.ptr(q), nat.current_stream(self.device)), "vaeq_nn_forward")
+        return q
+
+
 def dp_epilogue(q, y, data, amp_levels, nu_sc, var, batch_len=None):
     """Per-frame epilogue on the device (vaeq_dp_epilogue): q[R,2,2n,N], y[R,2,2,N], data[R,2,2,N] fp16 ->
     dict(SER[R,4], shift_q[R,2], r_q[R], shift_c[R,2], r_c[R]).  batch_len None = VAEflex (no per-minibatch cut)."""
