@@ -265,12 +265,19 @@ int64_t vaeq_nn_lds_bytes(int32_t B, int32_t sps, int32_t M, int32_t n_lev, int3
 int vaeq_nn_forward(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, int32_t k1, int32_t k2, const float *x,
                     const float *theta, float *q, void *stream);
 
+/* The whole VAE-NN validation block (:287-301: eval forward, find_shift :147-166, SER_q :97-123) in one call, q not materialised:
+ * x[R][2][N*sps], theta[R][NP], data_f16[R][2][N] -> ser[R], shift[R] (nullable). */
+int vaeq_nn_validate(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, int32_t k1, int32_t k2, int32_t n_shift, const float *x,
+                     const float *theta, const float *amp, const void *data_f16, float *ser, int32_t *shift, void *stream);
+
 /* Single-polarisation AWGN / ISI channel of AWGN_channel/func_VAELE_MQAM_shaping.py:39-61 (generate_data) for R runs, same three
  * stages without the dispersion step: g[Lg] = rrc * h_channel; sig_ws [R][Ls] complex64 and power_ws [R] are scratch;
- * rx[R][2][sps*N] (:57), data_f16 (nullable) [R][2][N] = symbols ref_offset .. ref_offset+N-1 (:59), sigma_out[R] nullable. */
+ * rx[R][2][sps*N] (:57), data_f16 (nullable) [R][2][N] = symbols ref_offset .. ref_offset+N-1 (:59), sigma_out[R] nullable.
+ * sigma_fixed (nullable [R]): use this noise standard deviation instead of the power-derived one -- the VAE-NN script's model
+ * (func_VAENN_MQAM.py:52: sigma_n = sqrt(1/2) / 10^(SNR/20)); snr_db may then be NULL. */
 int vaeq_gen_awgn(int32_t R, int32_t N, int32_t N_conv, int32_t sps, int32_t n_lev, int32_t Lg, int32_t Ls, int32_t ref_offset,
                   const float *amp, const float *cdf, const float *g_complex, const float *snr_db, uint64_t seed, uint32_t frame,
-                  float *sig_ws, float *power_ws, float *rx, void *data_f16, float *sigma_out, void *stream);
+                  float *sig_ws, float *power_ws, float *rx, void *data_f16, float *sigma_out, const float *sigma_fixed, void *stream);
 
 /* Fused validation pass of one AWGN epoch (func_VAELE_MQAM_shaping.py:308-318): twoFIR.forward in eval mode on N symbols per run,
  * find_shift (:188-204, n_shift circular lags over the first 1000 symbols) and SER_q (:97-123, argmax decisions, minimum over the

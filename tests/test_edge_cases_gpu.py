@@ -35,7 +35,7 @@ def test_empty_batches_are_a_no_op():
     ser, sh, _ = aeng.validate(torch.zeros(0, 2, 2000, device=DEV), torch.zeros(0, 2, 1000, dtype=torch.float16, device=DEV))
     assert ser.shape == (0,) and sh.shape == (0,)
     z = C.c_void_p(torch.zeros(8, device=DEV).data_ptr())
-    assert L.vaeq_gen_awgn(0, 100, 141, 2, 8, 40, 242, 12, z, z, z, z, C.c_uint64(1), C.c_uint32(0), z, z, z, None, None, None) == OK
+    assert L.vaeq_gen_awgn(0, 100, 141, 2, 8, 40, 242, 12, z, z, z, z, C.c_uint64(1), C.c_uint32(0), z, z, z, None, None, None, None) == OK
 
 
 def test_null_and_inconsistent_arguments_are_refused():
@@ -62,7 +62,7 @@ def test_null_and_inconsistent_arguments_are_refused():
     assert L.vaeq_dp_epilogue_compact(1, 1000, 8, 300, p, p, p, p, p, p, p, p, i32, i32, None) == ERR_SHAPE    # N % batch_len
     assert L.vaeq_awgn_validate(1, 1000, 2, 24, 8, 21, p, p, p, p, p, p, p, p, i32, None) == ERR_SHAPE
     assert L.vaeq_awgn_validate(1, 1000, 2, 25, 8, 64, p, p, p, p, p, p, p, p, i32, None) == ERR_SHAPE         # n_shift > 32
-    assert L.vaeq_gen_awgn(1, 100, 141, 2, 8, 40, 999, 12, p, p, p, p, C.c_uint64(1), C.c_uint32(0), p, p, p, None, None, None) == ERR_SHAPE
+    assert L.vaeq_gen_awgn(1, 100, 141, 2, 8, 40, 999, 12, p, p, p, p, C.c_uint64(1), C.c_uint32(0), p, p, p, None, None, None, None) == ERR_SHAPE
     assert L.vaeq_gen_dp_frame(1, 100, 141, 2, 8, 200, 242, 256, 12, p, p, p, p, p, 1.8e11, 0.0, 0.0, 1.0, 0.0, 1.0, 0.0, C.c_uint64(1),
                                C.c_uint32(0), p, p, p, None, None, None) == ERR_SHAPE                              # Lg > 96 taps
 

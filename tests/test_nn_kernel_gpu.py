@@ -77,3 +77,40 @@ def test_nn_forward_tiles_match_oracle(name, N):
     q = eng.forward(torch.from_numpy(x[None]).to(DEV))
     qo = oracle.nn_forward(x, g["theta3"], len(g["amp_levels"]), int(g["k1"]), int(g["k2"]), sps, np.float64)
     assert np.max(np.abs(_np(q)[0] - qo)) < 5e-6
+
+
+@pytest.mark.parametrize("name,N", [("G8_vaenn_64qam", 3000), ("G8_vaenn_16qam_small", 180)])
+def test_nn_validate_matches_torch_mirror(name, N):
+    """forward + find_shift + SER_q fused (vaeq_nn_validate) == the torch restatement of the reference's three calls on the q of
+    vaeq_nn_forward; runs differ in the delay of the TX reference and in a quadrant rotation of the decisions."""
+    from vae_equalizer_amd.func_VAELE_MQAM_shaping import SER_q, find_shift
+    g = load_golden(name)
+    sps, n = int(g["sps"]), len(g["amp_levels"])
+    R = 4
+    eng = _engine(g, R)
+    eng.theta.copy_(torch.from_numpy(g[f"theta{int(g['n_steps'])}"])[None].expand(R, -1))
+    x = torch.from_numpy(g["rx"][:, :N * sps])[None].expand(R, -1, -1).contiguous().to(DEV)
+    rng = np.random.default_rng(3)
+    q = eng.forward(x)
+    # a TX reference the decisions agree with up to 2 % errors, delayed / rotated per run: data = levels of argmax(q) rolled by k
+    dec = torch.stack([q[0, :n].argmax(0), q[0, n:].argmax(0)]).cpu().numpy()
+    flip = rng.random(dec.shape) < 0.02
+    dec = np.where(flip, (dec + 1) % n, dec)
+    amps = g["amp_levels"]
+    datas = []
+    for r, (k, rot) in enumerate([(0, 0), (4, 1), (-7, 2), (9, 3)]):
+        d = np.roll(dec, -k, axis=1)                                          # q[:, 11+k+j] lines up with data[:, 11+j]
+        K = n - 1
+        d = [d, np.stack([K - d[0], K - d[1]]), np.stack([d[1], K - d[0]]), np.stack([K - d[1], d[0]])][rot]
+        datas.append(amps[d])
+    data = torch.from_numpy(np.stack(datas)).to(torch.float16).to(DEV)
+    ser, sh = eng.validate(x, data, 21)
+    torch.cuda.synchronize()
+    amp = torch.tensor(amps, dtype=torch.float32, device=DEV)
+    for i in range(R):
+        s_ref = int(find_shift(q[i], data[i], 21, amp, n))
+        assert int(sh[i]) == s_ref, (i, int(sh[i]), s_ref)
+        e_ref = float(SER_q(q[i][:, 11 + s_ref:-11], data[i][:, 11:-11 - s_ref], sps, n))
+        assert abs(float(ser[i]) - e_ref) <= 2.0 / N, (i, float(ser[i]), e_ref)
+    if N >= 1000:
+        assert [int(v) for v in sh] == [0, 4, -7, 9] and float(ser.max()) < 0.06

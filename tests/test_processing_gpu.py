@@ -244,3 +244,37 @@ def test_awgn_config2_device_pipeline_monte_carlo():
     assert np.all(conv >= 20) and np.median(conv) < 160, conv                 # ... neither instantly nor never (reference: 56)
     tail = SER[:, -50:].mean()                                                # 24 x 50 x 15000 symbols
     assert abs(tail - g["SER"][-50:].mean()) < 1.5e-4, (tail, g["SER"][-50:].mean())
+
+
+def test_vaenn_processing_vs_reference_trajectory():
+    """Row f3 through the drop-in call surface: func_VAENN_MQAM.processing with the frames and the initial network the reference saw
+    under seed 84 (16-QAM, SNR 20 dB, 120 epochs x 4 minibatches of 300, validation on 5000 symbols every 2nd epoch)."""
+    from vae_equalizer_amd.func_VAENN_MQAM import processing
+    g = load_golden("G8_vaenn_run")
+    SER = processing("16-QAM", 2, 20, 25, 25, 3, 4e-3, 300, 5000, 1200, 120, 2, "h1", "Net", seed=int(g["seed"]), theta0=g["theta0"],
+                     generator="numpy", verbose=False).numpy()
+    ref = g["SER"]
+    assert SER.shape == ref.shape == (60,)
+    assert np.max(np.abs(SER[:5] - ref[:5])) < 0.02                            # same frames, same start: 20 steps in
+    conv = lambda s: int(np.argmax(s < 0.02))
+    assert abs(conv(SER) - conv(ref)) <= 8, (conv(SER), conv(ref))             # reference: validation 25
+    assert abs(SER[-20:].mean() - ref[-20:].mean()) < 8e-4, (SER[-20:].mean(), ref[-20:].mean())
+    with pytest.raises(NotImplementedError):
+        processing("16-QAM", 2, 20, 25, 25, 3, 4e-3, 300, 5000, 1200, 2, 2, "h1", "Net_BN", verbose=False)
+
+
+def test_vaenn_device_pipeline_monte_carlo():
+    """vaeq_gen_awgn (fixed noise level) -> vaeq_nn_train -> vaeq_nn_validate for 16 independently initialised runs: all lock, and the
+    converged SER agrees with the reference's curve within Monte-Carlo error."""
+    from vae_equalizer_amd.func_VAENN_MQAM import run_vaenn_batch
+    g = load_golden("G8_vaenn_run")
+    runs = [dict(SNR=20, lr_optim=4e-3, seed=None) for _ in range(16)]
+    SER = run_vaenn_batch(runs, "16-QAM", 2, 25, 25, 3, 300, 5000, 1200, 120, 2, "h1", generator="hip", seed=5).numpy()
+    assert SER.shape == (16, 60)
+    tail = SER[:, -10:].mean(1)
+    locked = tail < 0.01
+    # how fast the blind CNN equalizer escapes its start depends on the random initialisation: most runs lock within the 120 epochs
+    # (the reference's own run: validation 25 of 60), the rest are still descending
+    assert locked.sum() >= 10, tail
+    assert (SER[~locked, -1] < SER[~locked, 0] - 0.05).all(), SER[~locked][:, [0, -1]]
+    assert abs(SER[locked, -20:].mean() - g["SER"][-20:].mean()) < 6e-4, (SER[locked, -20:].mean(), g["SER"][-20:].mean())

@@ -509,14 +509,20 @@ def capture_G8(sfun, awgn):
     save("G8_vaenn_64qam", **_nn_case("64-QAM", 24, 25, 25, 3, 300, seed=81, n_steps=10))
     save("G8_vaenn_16qam_small", **_nn_case("16-QAM", 20, 9, 11, 3, 60, seed=82, n_steps=3, lr=2e-3))
     save("G8_vaenn_4qam_k5", **_nn_case("4-QAM", 12, 13, 7, 5, 41, seed=83, n_steps=3, channel="h2"))
-    # processing() itself: 16-QAM, 40 epochs x 4 minibatches of 300, validation on 5000 symbols every 2nd epoch
+    # processing() itself: 16-QAM, 120 epochs x 4 minibatches of 300, validation on 5000 symbols every 2nd epoch; the initial
+    # parameters are what Net() draws right after torch.manual_seed(84), captured by constructing the same net first
+    torch.manual_seed(84)
+    net0 = nnref.Net(25, 3, 4, 2)
+    h0 = np.zeros([2, 25])
+    h0[0, 12] = 1
+    theta0 = np.concatenate([t2n(p_).reshape(-1) for p_ in (net0.fc1.weight, net0.fc1.bias, net0.fc2.weight, net0.fc2.bias)] + [h0.reshape(-1)])
     t0 = time.time()
     torch.manual_seed(84)
     with SeededRng(84), contextlib.redirect_stdout(io.StringIO()):
-        SER = nnref.processing("16-QAM", 2, 20, 25, 25, 3, 4e-3, 300, 5000, 1200, 40, 2, "h1", "Net")
+        SER = nnref.processing("16-QAM", 2, 20, 25, 25, 3, 4e-3, 300, 5000, 1200, 120, 2, "h1", "Net")
     print(f"   G8 run: {time.time() - t0:.0f}s  SER {np.round(t2n(SER), 4).tolist()}")
-    save("G8_vaenn_run", SER=t2n(SER), seed=np.int64(84), seconds=np.float64(time.time() - t0),
-         args=np.array(["16-QAM", 2, 20, 25, 25, 3, 4e-3, 300, 5000, 1200, 40, 2, "h1", "Net"], dtype=object))
+    save("G8_vaenn_run", SER=t2n(SER), theta0=theta0.astype(np.float32), seed=np.int64(84), seconds=np.float64(time.time() - t0),
+         args=np.array([str(v) for v in ("16-QAM", 2, 20, 25, 25, 3, 4e-3, 300, 5000, 1200, 120, 2, "h1", "Net")]))
 
 
 def main():

@@ -295,10 +295,11 @@ def awgn_frame_geometry(N, h_channel, sps):
     return dict(N_conv=N_conv, g=g, Lg=len(g), Ls=Ls, ref_offset=T + M_channel - 1)
 
 
-def generate_awgn_batch_hip(R, N, amps, P, SNR, h_channel, sps, device, seed, frame, return_sigma=False):
+def generate_awgn_batch_hip(R, N, amps, P, SNR, h_channel, sps, device, seed, frame, return_sigma=False, sigma_fixed=None):
     """The AWGN/ISI channel model for R runs on the device (vaeq_gen_awgn): deterministic in (seed, frame, run).
 
-    amps[n]; P[R,n] or [n]; SNR scalar or [R].  Returns (rx[R,2,sps*N] f32, data[R,2,N] f16[, sigma_n[R]])."""
+    amps[n]; P[R,n] or [n]; SNR scalar or [R]; sigma_fixed (scalar or [R]) replaces the power-derived noise level (the VAE-NN
+    script's generate_data).  Returns (rx[R,2,sps*N] f32, data[R,2,N] f16[, sigma_n[R]])."""
     import ctypes as C
 
     from . import _native as nat
@@ -320,6 +321,8 @@ def generate_awgn_batch_hip(R, N, amps, P, SNR, h_channel, sps, device, seed, fr
         nat.check(nat.lib().vaeq_gen_awgn(R, N, geo["N_conv"], sps, n, geo["Lg"], geo["Ls"], geo["ref_offset"], nat.ptr(amp_t), nat.ptr(cdf),
                                           nat.ptr(g_t), nat.ptr(snr), C.c_uint64(_mix_seed(seed, 0)), C.c_uint32(frame), nat.ptr(sig),
                                           nat.ptr(pw), nat.ptr(rx), nat.ptr(data, torch.float16), nat.ptr(sigma),
+                                          None if sigma_fixed is None else
+                                          nat.ptr(_dev_const(np.broadcast_to(np.asarray(sigma_fixed, np.float32), (R,)), torch.float32, dev)),
                                           nat.current_stream(dev)), "vaeq_gen_awgn")
     return (rx, data, sigma) if return_sigma else (rx, data)
 

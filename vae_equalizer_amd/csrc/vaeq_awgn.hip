@@ -18,6 +18,7 @@
 #include "vaeq.h"
 #include "vaeq_common.h"
 #include "vaeq_wave.h"
+#include "vaeq_validate.h"
 
 namespace vaeq {
 
@@ -331,7 +332,6 @@ __global__ __launch_bounds__(256) void awgn_forward_kernel(int64_t N, int sps, i
 //   find_shift (:188-204): E_q[x_I] of the first 1000 symbols against the TX I (else Q) row over n_shift circular lags
 //   SER_q (:97-123) on q[:, 11+sh : -11] vs data[:, 11 : -11-sh], minimum over the four quadrant rotations
 // MT > 0: tap count baked in, four symbols per thread from one register window (sps == 2).
-constexpr int VAL_NE = 1000, VAL_MAXSHIFT = 32;
 
 template <int NLEV, int MT>
 __global__ __launch_bounds__(256, 4) void awgn_validate_kernel(int N, int sps, int Mrt, int n_shift, const float *__restrict__ x,
@@ -468,51 +468,7 @@ __global__ __launch_bounds__(256, 4) void awgn_validate_kernel(int N, int sps, i
         }
     }
     __syncthreads();
-    const __half *tI = data + (size_t)run * 2 * N, *tQ = tI + N;
-    const int half_ = n_shift / 2;
-    for (int i = 0; i < n_shift; i++) {                  // corr[i] = <tx[:NE], roll(E, i - half)>,  roll(E, s)[n] = E[(n - s) mod NE]
-        float cI = 0.f, cQ = 0.f;
-        for (int n = tid; n < NE; n += 256) {
-            int m = n - (i - half_);
-            m = m < 0 ? m + NE : (m >= NE ? m - NE : m);
-            const float e = E[m];
-            cI = fmaf(__half2float(tI[n]), e, cI);
-            cQ = fmaf(__half2float(tQ[n]), e, cQ);
-        }
-        __syncthreads();
-        block_reduce3<256>(cI, cQ, 0.f, red);
-        if (tid == 0) { corr[0][i] = fabsf(red[0]); corr[1][i] = fabsf(red[1]); }
-    }
-    if (tid == 0) {
-        int aI = 0, aQ = 0;
-        for (int i = 1; i < n_shift; i++) {
-            if (corr[0][i] > corr[0][aI]) aI = i;
-            if (corr[1][i] > corr[1][aQ]) aQ = i;
-        }
-        int sh = half_ - aI;
-        if (!(corr[0][aI] >= (float)(0.02 * (double)N)) && corr[1][aQ] >= corr[0][aI]) sh = half_ - aQ;
-        sh_s = sh;
-        if (shift_out) shift_out[run] = sh;
-    }
-    __syncthreads();
-    const int sh = sh_s, len = N - 22 - sh, K = NLEV - 1;
-    const float scale = 0.5f * (float)K;
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-    for (int j = tid; j < len; j += 256) {
-        const int dd = decs[11 + sh + j], dI = dd & 15, dQ = dd >> 4;
-        const int aI = (int)rintf(__fadd_rn(__fmul_rn(scale, __half2float(tI[11 + j])), scale));
-        const int aQ = (int)rintf(__fadd_rn(__fmul_rn(scale, __half2float(tQ[11 + j])), scale));
-        c0 += (aI != dI) | (aQ != dQ);
-        c1 += (aI != K - dI) | (aQ != K - dQ);
-        c2 += (aI != K - dQ) | (aQ != dI);
-        c3 += (aI != dQ) | (aQ != K - dI);
-    }
-    __syncthreads();
-    block_reduce3<256>(c0, c1, c2, red);
-    const float r0 = red[0], r1 = red[1], r2 = red[2];
-    __syncthreads();
-    block_reduce3<256>(c3, 0.f, 0.f, red);
-    if (tid == 0) ser_out[run] = fminf(fminf(r0, r1), fminf(r2, red[0])) / (float)len;
+    validate_tail<256, NLEV>(N, n_shift, decs, E, NE, data + (size_t)run * 2 * N, red, corr, &sh_s, ser_out + run, shift_out ? shift_out + run : nullptr);
 }
 
 template <int NLEV>

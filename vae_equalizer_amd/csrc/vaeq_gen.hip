@@ -217,10 +217,11 @@ __global__ __launch_bounds__(256) void gen_power_kernel(int Ls, int Lrow, int np
 // one Philox call -> two Box-Muller pairs -> the noise of two consecutive samples
 __global__ __launch_bounds__(256) void gen_finish_kernel(int Lrow, int Lout, int sps, const float *__restrict__ snr_db, const float *__restrict__ power,
                                                          uint64_t seed, uint32_t frame, int npol, const float2 *__restrict__ sig,
-                                                         float *__restrict__ rx, float *__restrict__ sigma_out)
+                                                         float *__restrict__ rx, float *__restrict__ sigma_out,
+                                                         const float *__restrict__ sigma_fixed)
 {
     const int run = blockIdx.z, pol = blockIdx.y;
-    const float sigma = sqrtf(power[run] * (float)sps * 0.5f / exp10f(snr_db[run] * 0.1f));
+    const float sigma = sigma_fixed ? sigma_fixed[run] : sqrtf(power[run] * (float)sps * 0.5f / exp10f(snr_db[run] * 0.1f));
     if (sigma_out && pol == 0 && blockIdx.x == 0 && threadIdx.x == 0) sigma_out[run] = sigma;
     const float2 *s = sig + ((size_t)run * npol + pol) * Lrow;
     float *rI = rx + ((size_t)(run * npol + pol) * 2 + 0) * Lout, *rQ = rI + Lout;
@@ -257,12 +258,12 @@ static void launch_tx(int R, int npol, int N, int N_conv, int sps, int n_lev, in
 }
 
 static void launch_finish(int R, int npol, int N, int sps, int Ls, int Lrow, const float *snr_db, uint64_t seed, uint32_t frame,
-                          const float2 *sig, float *power_ws, float *rx, float *sigma_out, hipStream_t st)
+                          const float2 *sig, float *power_ws, float *rx, float *sigma_out, hipStream_t st, const float *sigma_fixed = nullptr)
 {
     const int Lout = sps * N, nj = (Lout + 1) / 2;
-    hipLaunchKernelGGL(gen_power_kernel, dim3(R), dim3(256), 0, st, Ls, Lrow, npol, sig, power_ws);
+    if (!sigma_fixed) hipLaunchKernelGGL(gen_power_kernel, dim3(R), dim3(256), 0, st, Ls, Lrow, npol, sig, power_ws);
     hipLaunchKernelGGL(gen_finish_kernel, dim3((nj + 255) / 256 > 64 ? 64 : (nj + 255) / 256, npol, R), dim3(256), 0, st, Lrow, Lout, sps, snr_db,
-                       power_ws, seed, frame, npol, sig, rx, sigma_out);
+                       power_ws, seed, frame, npol, sig, rx, sigma_out, sigma_fixed);
 }
 
 }  // namespace vaeq
@@ -314,16 +315,17 @@ extern "C" int vaeq_gen_dp_finish(int32_t R, int32_t N, int32_t sps, int32_t Ls,
 // TX reference data[R][2][N] (fp16, :59).  sig_ws: [R][Ls] complex64 scratch, power_ws: [R] floats.
 extern "C" int vaeq_gen_awgn(int32_t R, int32_t N, int32_t N_conv, int32_t sps, int32_t n_lev, int32_t Lg, int32_t Ls, int32_t ref_offset,
                              const float *amp, const float *cdf, const float *g_complex, const float *snr_db, uint64_t seed, uint32_t frame,
-                             float *sig_ws, float *power_ws, float *rx, void *data_f16, float *sigma_out, void *stream)
+                             float *sig_ws, float *power_ws, float *rx, void *data_f16, float *sigma_out, const float *sigma_fixed,
+                             void *stream)
 {
     if (R == 0) return VAEQ_OK;                                // an empty batch owns no memory: its pointers may be NULL
-    if (!amp || !cdf || !g_complex || !snr_db || !sig_ws || !power_ws || !rx) return VAEQ_ERR_NULL;
+    if (!amp || !cdf || !g_complex || (!snr_db && !sigma_fixed) || !sig_ws || !power_ws || !rx) return VAEQ_ERR_NULL;
     if (!tx_shape_ok(R, N, N_conv, sps, n_lev, Lg, Ls, Ls, ref_offset)) return VAEQ_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float2 *sig = reinterpret_cast<float2 *>(sig_ws);
     vaeq::launch_tx(R, 1, N, N_conv, sps, n_lev, Lg, Ls, Ls, ref_offset, amp, cdf, reinterpret_cast<const float2 *>(g_complex), seed, frame, sig,
                     reinterpret_cast<__half *>(data_f16), st);
-    vaeq::launch_finish(R, 1, N, sps, Ls, Ls, snr_db, seed, frame, sig, power_ws, rx, sigma_out, st);
+    vaeq::launch_finish(R, 1, N, sps, Ls, Ls, snr_db, seed, frame, sig, power_ws, rx, sigma_out, st, sigma_fixed);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
 

@@ -19,6 +19,7 @@
 
 #include "vaeq.h"
 #include "vaeq_common.h"
+#include "vaeq_validate.h"
 
 namespace vaeq {
 
@@ -374,6 +375,77 @@ __global__ __launch_bounds__(NT) void nn_forward_kernel(int N, int sps, int M, i
     }
 }
 
+
+// Fused validation pass (:287-301): tiled eval forward, hard decisions = argmax of the logits (first maximum, like argmax q),
+// E_q[x_I] of the first 1000 symbols, then the common shift search + SER; q never leaves the chip.
+template <int NT, int NLEV>
+__global__ __launch_bounds__(NT) void nn_validate_kernel(int N, int sps, int M, int k1, int k2, int n_shift, const float *__restrict__ x,
+                                                         const float *__restrict__ theta, const float *__restrict__ amp_g,
+                                                         const __half *__restrict__ data, float *__restrict__ ser_out, int *__restrict__ shift_out)
+{
+    extern __shared__ float4 smem4[];
+    float *sm = reinterpret_cast<float *>(smem4);
+    __shared__ float E[VAL_NE];
+    __shared__ float corr[2][VAL_MAXSHIFT];
+    __shared__ int sh_s;
+    const int tid = threadIdx.x, run = blockIdx.x;
+    const NNLayout l = nn_layout(NN_TILE, sps, M, NLEV, k1, k2);
+    float *xs = sm + l.xs, *z1 = sm + l.z1, *a2 = sm + l.a2, *th = sm + l.th, *red = sm + l.red;
+    unsigned char *decs = reinterpret_cast<unsigned char *>(sm + l.total);      // [N] after the forward working set
+    float amp[NLEV];
+#pragma unroll
+    for (int i = 0; i < NLEV; i++) amp[i] = amp_g[i];
+    for (int i = tid; i < l.NP; i += NT) th[i] = theta[(size_t)run * l.NP + i];
+    __syncthreads();
+    const int64_t Ltot = (int64_t)N * sps;
+    const float *x0 = x + (size_t)run * 2 * Ltot, *x1 = x0 + Ltot;
+    const int NE = N < VAL_NE ? N : VAL_NE;
+    for (int n0 = 0; n0 < N; n0 += NN_TILE) {
+        const int Bt = min(NN_TILE, N - n0);
+        nn_forward_tile<NT, NLEV>(l, sps, k1, k2, Ltot, x0, x1, n0, Bt, xs, z1, a2, th);
+        for (int n = tid; n < Bt; n += NT) {
+            int d[2];
+#pragma unroll
+            for (int axq = 0; axq < 2; axq++) {
+                float best = a2[(axq * NLEV) * NN_TILE + n];
+                int bi = 0;
+#pragma unroll
+                for (int i = 1; i < NLEV; i++) {
+                    const float v = a2[(axq * NLEV + i) * NN_TILE + n];
+                    if (v > best) { best = v; bi = i; }
+                }
+                d[axq] = bi;
+                if (axq == 0 && n0 + n < NE) {
+                    float ssum = 0.f, e1 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < NLEV; i++) {
+                        const float w = __expf(a2[i * NN_TILE + n] - best);
+                        ssum += w;
+                        e1 = fmaf(amp[i], w, e1);
+                    }
+                    E[n0 + n] = e1 / ssum;
+                }
+            }
+            decs[n0 + n] = (unsigned char)(d[0] | (d[1] << 4));
+        }
+        __syncthreads();
+    }
+    validate_tail<NT, NLEV>(N, n_shift, decs, E, NE, data + (size_t)run * 2 * N, red, corr, &sh_s, ser_out + run, shift_out ? shift_out + run : nullptr);
+}
+
+template <int NLEV>
+static int launch_nn_validate(int R, int N, int sps, int M, int k1, int k2, int n_shift, const float *x, const float *theta, const float *amp,
+                              const __half *data, float *ser, int *shift, hipStream_t st)
+{
+    const size_t lds = (size_t)nn_layout(NN_TILE, sps, M, NLEV, k1, k2).total * 4 + (((size_t)N + 15) & ~(size_t)15);
+    if (lds > 150 * 1024) return VAEQ_ERR_LDS;
+    auto k = nn_validate_kernel<512, NLEV>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return VAEQ_ERR_LDS;
+    hipLaunchKernelGGL(k, dim3(R), dim3(512), lds, st, N, sps, M, k1, k2, n_shift, x, theta, amp, data, ser, shift);
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}
+
 template <int NLEV>
 static int launch_nn_train(const vaeq_nn_args &a, size_t lds, hipStream_t st)
 {
@@ -447,6 +519,24 @@ extern "C" int vaeq_nn_forward(int32_t R, int64_t N, int32_t sps, int32_t M, int
     case 2: return vaeq::launch_nn_forward<2>(R, (int)N, sps, M, k1, k2, x, theta, q, st);
     case 4: return vaeq::launch_nn_forward<4>(R, (int)N, sps, M, k1, k2, x, theta, q, st);
     case 8: return vaeq::launch_nn_forward<8>(R, (int)N, sps, M, k1, k2, x, theta, q, st);
+    }
+    return VAEQ_ERR_SHAPE;
+}
+
+extern "C" int vaeq_nn_validate(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, int32_t k1, int32_t k2, int32_t n_shift,
+                                const float *x, const float *theta, const float *amp, const void *data_f16, float *ser, int32_t *shift,
+                                void *stream)
+{
+    if (R == 0) return VAEQ_OK;                                // an empty batch owns no memory: its pointers may be NULL
+    if (!x || !theta || !amp || !data_f16 || !ser) return VAEQ_ERR_NULL;
+    if (R < 0 || N < 64 || N > 65536 || n_shift <= 0 || n_shift > vaeq::VAL_MAXSHIFT || !vaeq::nn_shape_ok(vaeq::NN_TILE, sps, M, n_lev, k1, k2))
+        return VAEQ_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const __half *d = reinterpret_cast<const __half *>(data_f16);
+    switch (n_lev) {
+    case 2: return vaeq::launch_nn_validate<2>(R, (int)N, sps, M, k1, k2, n_shift, x, theta, amp, d, ser, shift, st);
+    case 4: return vaeq::launch_nn_validate<4>(R, (int)N, sps, M, k1, k2, n_shift, x, theta, amp, d, ser, shift, st);
+    case 8: return vaeq::launch_nn_validate<8>(R, (int)N, sps, M, k1, k2, n_shift, x, theta, amp, d, ser, shift, st);
     }
     return VAEQ_ERR_SHAPE;
 }

@@ -314,6 +314,21 @@ class NNEngine:
                                                 nat.ptr(q), nat.current_stream(self.device)), "vaeq_nn_forward")
         return q
 
+    def validate(self, x, data, n_shift=21):
+        """Fused validation pass (:287-301) -> (SER[R] f32, shift[R] i32): eval forward, find_shift and SER_q in one kernel
+        (vaeq_nn_validate); x[R,2,N*sps] f32, data[R,2,N] f16."""
+        R, N = x.shape[0], x.shape[-1] // self.sps
+        if tuple(data.shape) != (R, 2, N):
+            raise ValueError(f"data must be [R={R}, 2, N={N}], got {tuple(data.shape)}")
+        x, data = x.contiguous(), data.contiguous()
+        ser = torch.empty(R, dtype=torch.float32, device=self.device)
+        shift = torch.empty(R, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().vaeq_nn_validate(R, N, self.sps, self.M, self.n_lev, self.k1, self.k2, int(n_shift), nat.ptr(x),
+                                                 nat.ptr(self.theta), nat.ptr(self.amp), nat.ptr(data, torch.float16), nat.ptr(ser),
+                                                 nat.ptr(shift, torch.int32), nat.current_stream(self.device)), "vaeq_nn_validate")
+        return ser, shift
+
 
 def dp_epilogue(q, y, data, amp_levels, nu_sc, var, batch_len=None):
     """Per-frame epilogue on the device (vaeq_dp_epilogue): q[R,2,2n,N], y[R,2,2,N], data[R,2,2,N] fp16 ->
