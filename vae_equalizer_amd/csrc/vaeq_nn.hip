@@ -12,7 +12,9 @@
 // One workgroup per run, everything in LDS (105 KB for 64-QAM / k1 = 25 / B = 300): x window, ELU output z1 (C x L, reused in
 // place for dL/dz1), logits -> q -> dL/dlogits in place, the loss intermediates of vaeq_awgn.hip, theta, gradient, Adam state.
 // Backward = the closed form of the ELBO (vaeq_dp.hip) down to dL/dq, then softmax / conv / ELU / conv backward by the chain rule.
-// fc1 and its weight gradient (the two 480 kMAC loops) are register-blocked 4-wide along the sample axis with a sliding window.
+// Forward convolutions: item = (4 output channels, sample), consecutive lanes on consecutive samples, the 4 channels' weights of a
+// tap in one 16-byte broadcast read of a transposed weight copy.  Weight gradients: one wave per (input, tap) column, lanes stride
+// over the samples with all C channel sums in registers, then wave reductions -- every LDS access pattern is conflict free.
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -25,7 +27,7 @@ namespace vaeq {
 
 struct NNLayout {
     int C, L, p1, p2, Lx, Lz, mh, Mh, nm, NP, NW1, oW1, oB1, oW2, oB2, oH;
-    int xs, z1, a2, mu, vr, es, VS, th, gr, am, av, ax, part, red, total;
+    int xs, z1, a2, mu, vr, es, VS, th, gr, am, av, ax, w1t, w2t, red, total;
 };
 
 __host__ __device__ inline int npad4(int x) { return (x + 3) & ~3; }
@@ -48,58 +50,82 @@ __host__ __device__ inline NNLayout nn_layout(int B, int sps, int M, int n, int 
     l.es = take(2 * l.nm);
     l.VS = take(M);
     l.th = take(l.NP); l.gr = take(l.NP); l.am = take(l.NP); l.av = take(l.NP); l.ax = take(l.NP);
-    l.part = take(2 * (l.NW1 + l.C));
+    l.w1t = take(l.NW1);                               // fc1.weight as [i][k][c]: the 4 channels of a thread in one 16-byte read
+    l.w2t = take(l.C * l.C * k2);                      // fc2.weight as [cc][k][c]
     l.red = take(64);
     l.total = o;
     return l;
 }
 
-// ---- forward on one LDS-resident window: xs (zero-haloed input) -> z1 (ELU output, zero-haloed) -> a2 (logits)
+// ---- transposed weight copies (after every parameter update): w1t[(i k1 + k) C + c], w2t[(cc k2 + k) C + c]
 template <int NT, int NLEV>
-__device__ __forceinline__ void nn_fc1_elu(const NNLayout &l, int k1, const float *xs, const float *th, float *z1, int Lvalid, int zlo, int zhi)
+__device__ __forceinline__ void nn_transpose_weights(const NNLayout &l, int k1, int k2, const float *th, float *w1t, float *w2t)
+{
+    constexpr int C = 2 * NLEV;
+    for (int j = threadIdx.x; j < l.NW1; j += NT) {
+        const int c = j % C, ik = j / C, i = ik / k1, k = ik - i * k1;
+        w1t[j] = th[l.oW1 + (c * 2 + i) * k1 + k];
+    }
+    for (int j = threadIdx.x; j < C * C * k2; j += NT) {
+        const int c = j % C, r = j / C, cc = r / k2, k = r - cc * k2;
+        w2t[j] = th[l.oW2 + (c * C + cc) * k2 + k];
+    }
+}
+
+// ---- forward on one LDS-resident window: xs (zero-haloed input) -> z1 (ELU output, zero-haloed) -> a2 (logits).
+// item = (channel quad, sample): consecutive lanes take consecutive samples (conflict-free x reads and z1 writes), the four
+// channels' weights of a tap come from one 16-byte broadcast read.
+template <int NT, int NLEV>
+__device__ __forceinline__ void nn_fc1_elu(const NNLayout &l, int k1, const float *xs, const float *th, const float *w1t, float *z1, int Lvalid,
+                                           int zlo, int zhi)
 {
     // z1p[c][p2 + s] for s in [0, Lvalid); entries whose absolute position (zlo + s) lies outside [0, zhi) are fc2's zero padding
-    constexpr int C = 2 * NLEV;
-    const int tid = threadIdx.x, nquad = (Lvalid + 3) / 4;
-    for (int it = tid; it < C * nquad; it += NT) {
-        const int c = it / nquad, s0 = (it - c * nquad) * 4;
-        const float b = th[l.oB1 + c];
-        float a0 = b, a1 = b, a2_ = b, a3 = b;
+    constexpr int C = 2 * NLEV, CQ = C / 4;
+    for (int it = threadIdx.x; it < CQ * Lvalid; it += NT) {
+        const int cq = it / Lvalid, sx = it - cq * Lvalid;
+        const float4 b = *reinterpret_cast<const float4 *>(th + l.oB1 + 4 * cq);
+        float a0 = b.x, a1 = b.y, a2_ = b.z, a3 = b.w;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            const float *w = th + l.oW1 + (c * 2 + i) * k1, *xp = xs + i * l.Lx + s0;
-            float x0 = xp[0], x1 = xp[1], x2 = xp[2];
-            for (int k = 0; k < k1; k++) {             // out[s] = sum_k w[k] x[s + k - p1]: the haloed index of x[s + k - p1] is s + k
-                const float x3 = xp[k + 3], wk = w[k];
-                a0 = fmaf(wk, x0, a0); a1 = fmaf(wk, x1, a1); a2_ = fmaf(wk, x2, a2_); a3 = fmaf(wk, x3, a3);
-                x0 = x1; x1 = x2; x2 = x3;
+            const float *xp = xs + i * l.Lx + sx;              // out[s] = sum_k w[k] x[s + k - p1]: the haloed index of x[s + k - p1] is s + k
+            const float4 *w = reinterpret_cast<const float4 *>(w1t + (i * k1) * C + 4 * cq);
+            for (int k = 0; k < k1; k++) {
+                const float xv = xp[k];
+                const float4 w4 = w[k * CQ];
+                a0 = fmaf(w4.x, xv, a0); a1 = fmaf(w4.y, xv, a1); a2_ = fmaf(w4.z, xv, a2_); a3 = fmaf(w4.w, xv, a3);
             }
         }
         const float av[4] = {a0, a1, a2_, a3};
+        const int pos = zlo + sx;
+        const bool in = pos >= 0 && pos < zhi;
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const int s = s0 + t;
-            if (s < Lvalid) {
-                const int pos = zlo + s;
-                const float z = av[t] > 0.f ? av[t] : __expf(av[t]) - 1.0f;              // F.elu, alpha = 1 (:177)
-                z1[c * l.Lz + l.p2 + s] = (pos >= 0 && pos < zhi) ? z : 0.f;
-            }
+            const float z = av[t] > 0.f ? av[t] : __expf(av[t]) - 1.0f;                  // F.elu, alpha = 1 (:177)
+            z1[(4 * cq + t) * l.Lz + l.p2 + sx] = in ? z : 0.f;
         }
     }
 }
 
 template <int NT, int NLEV>
-__device__ __forceinline__ void nn_fc2(const NNLayout &l, int sps, int k2, int Bt, int astride, const float *z1, const float *th, float *a2, int zoff)
+__device__ __forceinline__ void nn_fc2(const NNLayout &l, int sps, int k2, int Bt, int astride, const float *z1, const float *th, const float *w2t,
+                                       float *a2)
 {
-    constexpr int C = 2 * NLEV;
-    for (int it = threadIdx.x; it < C * Bt; it += NT) {
-        const int c = it / Bt, n = it - c * Bt;
-        float acc = th[l.oB2 + c];
+    constexpr int C = 2 * NLEV, CQ = C / 4;
+    for (int it = threadIdx.x; it < CQ * Bt; it += NT) {
+        const int cq = it / Bt, n = it - cq * Bt;
+        const float4 b = *reinterpret_cast<const float4 *>(th + l.oB2 + 4 * cq);
+        float a0 = b.x, a1 = b.y, a2_ = b.z, a3 = b.w;
+        const float4 *w = reinterpret_cast<const float4 *>(w2t + 4 * cq);
         for (int cc = 0; cc < C; cc++) {
-            const float *w = th + l.oW2 + (c * C + cc) * k2, *zp = z1 + cc * l.Lz + zoff + n * sps;   // z1[n sps + k - p2] -> haloed n sps + k
-            for (int k = 0; k < k2; k++) acc = fmaf(w[k], zp[k], acc);
+            const float *zp = z1 + cc * l.Lz + n * sps;        // z1[n sps + k - p2] -> haloed index n sps + k
+            for (int k = 0; k < k2; k++) {
+                const float zv = zp[k];
+                const float4 w4 = w[(cc * k2 + k) * CQ];
+                a0 = fmaf(w4.x, zv, a0); a1 = fmaf(w4.y, zv, a1); a2_ = fmaf(w4.z, zv, a2_); a3 = fmaf(w4.w, zv, a3);
+            }
         }
-        a2[c * astride + n] = acc;
+        a2[(4 * cq + 0) * astride + n] = a0; a2[(4 * cq + 1) * astride + n] = a1;
+        a2[(4 * cq + 2) * astride + n] = a2_; a2[(4 * cq + 3) * astride + n] = a3;
     }
 }
 
@@ -114,7 +140,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
     const NNLayout l = nn_layout(B, sps, M, NLEV, k1, k2);
     const int L = l.L, p1 = l.p1, p2 = l.p2, Lx = l.Lx, Lz = l.Lz, mh = l.mh, Mh = l.Mh, nm = l.nm, NP = l.NP;
     float *xs = sm + l.xs, *z1 = sm + l.z1, *a2 = sm + l.a2, *mu = sm + l.mu, *vr = sm + l.vr, *es = sm + l.es, *VS = sm + l.VS;
-    float *th = sm + l.th, *gr = sm + l.gr, *am = sm + l.am, *av = sm + l.av, *ax = sm + l.ax, *part = sm + l.part, *red = sm + l.red;
+    float *th = sm + l.th, *gr = sm + l.gr, *am = sm + l.am, *av = sm + l.av, *ax = sm + l.ax, *w1t = sm + l.w1t, *w2t = sm + l.w2t, *red = sm + l.red;
     const float *hs = th + l.oH;                               // h_est[2][M]: re row, im row
 
     float amp[NLEV];
@@ -130,10 +156,14 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
     int step = a.step[run];
     double b1t = pow(0.9, (double)step), b2t = pow(0.999, (double)step);
     __syncthreads();
+    nn_transpose_weights<NT, NLEV>(l, k1, k2, th, w1t, w2t);
+    __syncthreads();
 
     const size_t No = (size_t)a.steps * B;
     const float *rxr = a.rx + (size_t)run * 2 * (size_t)a.S;
     float *qf = a.q_out ? a.q_out + (size_t)run * C * No : nullptr;
+    const int lane = tid & 63, wv = tid >> 6;
+    constexpr int NWV = NT / 64, CQ = C / 4;
 
     for (int s = 0; s < a.steps; s++) {
         // ---- P0: minibatch -> LDS (:276)
@@ -143,9 +173,9 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
         }
         __syncthreads();
         // ---- P1/P2: fc1 + ELU, fc2
-        nn_fc1_elu<NT, NLEV>(l, k1, xs, th, z1, L, 0, L);
+        nn_fc1_elu<NT, NLEV>(l, k1, xs, th, w1t, z1, L, 0, L);
         __syncthreads();
-        nn_fc2<NT, NLEV>(l, sps, k2, B, B, z1, th, a2, 0);
+        nn_fc2<NT, NLEV>(l, sps, k2, B, B, z1, th, w2t, a2);
         __syncthreads();
         // ---- P3: per-axis softmax -> q (in place), moments, entropy term; item = (axis, n)
         float klsum = 0.f;
@@ -242,18 +272,23 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
             }
         }
         __syncthreads();
-        // ---- P7a: fc2 weight / bias gradients; item = (c, cc, k) or (c)
-        for (int it = tid; it < C * C * k2 + C; it += NT) {
-            float acc = 0.f;
-            if (it < C * C * k2) {
-                const int c = it / (C * k2), rem = it - c * (C * k2), cc = rem / k2, k = rem - cc * k2;
-                const float *g = a2 + c * B, *zp = z1 + cc * Lz + k;
-                for (int n = 0; n < B; n++) acc = fmaf(g[n], zp[n * sps], acc);
-                gr[l.oW2 + it] = acc;
-            } else {
-                const float *g = a2 + (it - C * C * k2) * B;
-                for (int n = 0; n < B; n++) acc += g[n];
-                gr[l.oB2 + it - C * C * k2] = acc;
+        // ---- P7a: fc2 weight / bias gradients.  One wave per (cc, k) column: lanes stride over n, 16 channel sums per lane, then
+        //      wave reductions (conflict-free reads; the z1 value of a lane feeds all C channels).  Pseudo column C*k2: the biases.
+        for (int col = wv; col <= C * k2; col += NWV) {
+            const bool bias = col == C * k2;
+            const int cc = bias ? 0 : col / k2, k = bias ? 0 : col - cc * k2;
+            float acc[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) acc[c] = 0.f;
+            for (int n = lane; n < B; n += 64) {
+                const float zv = bias ? 1.0f : z1[cc * Lz + n * sps + k];
+#pragma unroll
+                for (int c = 0; c < C; c++) acc[c] = fmaf(a2[c * B + n], zv, acc[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const float sum = wave_sum(acc[c]);
+                if (lane == 0) gr[bias ? l.oB2 + c : l.oW2 + (c * C + cc) * k2 + k] = sum;
             }
         }
         __syncthreads();
@@ -266,42 +301,36 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
                 if (t < 0 || t % sps) continue;
                 const int n = t / sps;
                 if (n >= B) continue;
-                for (int c = 0; c < C; c++) acc = fmaf(th[l.oW2 + (c * C + cc) * k2 + k], a2[c * B + n], acc);
+                const float4 *w = reinterpret_cast<const float4 *>(w2t + (cc * k2 + k) * C);
+#pragma unroll
+                for (int cq = 0; cq < CQ; cq++) {
+                    const float4 w4 = w[cq];
+                    acc = fmaf(w4.x, a2[(4 * cq + 0) * B + n], acc); acc = fmaf(w4.y, a2[(4 * cq + 1) * B + n], acc);
+                    acc = fmaf(w4.z, a2[(4 * cq + 2) * B + n], acc); acc = fmaf(w4.w, a2[(4 * cq + 3) * B + n], acc);
+                }
             }
             const float z = z1[cc * Lz + p2 + sx];
             z1[cc * Lz + p2 + sx] = acc * (z > 0.f ? 1.0f : z + 1.0f);                    // ELU' = 1 or exp(a1) = z1 + 1
         }
         __syncthreads();
-        // ---- P8: fc1 weight / bias gradients, 4 taps per item, two halves of the sample range; item = (c, i, k-quad, half) or (c, half)
-        {
-            const int nkq = (k1 + 3) / 4, nW = C * 2 * nkq * 2, Lh = (L + 1) / 2;
-            for (int it = tid; it < nW + 2 * C; it += NT) {
-                if (it < nW) {
-                    const int half = it & 1, r = it >> 1, kq = r % nkq, ci = r / nkq;   // ci = c * 2 + i
-                    const int c = ci >> 1, i = ci & 1, k0 = kq * 4, s0 = half * Lh, s1 = min(L, s0 + Lh);
-                    const float *g = z1 + c * Lz + p2, *xp = xs + i * Lx + k0;
-                    float a0 = 0.f, a1 = 0.f, a2_ = 0.f, a3 = 0.f;
-                    float x0 = xp[s0], x1 = xp[s0 + 1], x2 = xp[s0 + 2];
-                    for (int sx = s0; sx < s1; sx++) {          // gw1[c][i][k] = sum_s gz[c][s] x[i][s + k - p1] -> haloed index s + k
-                        const float x3 = xp[sx + 3], gz = g[sx];
-                        a0 = fmaf(gz, x0, a0); a1 = fmaf(gz, x1, a1); a2_ = fmaf(gz, x2, a2_); a3 = fmaf(gz, x3, a3);
-                        x0 = x1; x1 = x2; x2 = x3;
-                    }
-                    const float av4[4] = {a0, a1, a2_, a3};
+        // ---- P8: fc1 weight / bias gradients, same scheme: one wave per (i, k) column, lanes stride over the samples
+        for (int col = wv; col <= 2 * k1; col += NWV) {
+            const bool bias = col == 2 * k1;
+            const int i = bias ? 0 : col / k1, k = bias ? 0 : col - i * k1;
+            float acc[C];
 #pragma unroll
-                    for (int t = 0; t < 4; t++)
-                        if (k0 + t < k1) part[half * (l.NW1 + C) + ci * k1 + k0 + t] = av4[t];
-                } else {
-                    const int r = it - nW, half = r & 1, c = r >> 1, s0 = half * Lh, s1 = min(L, s0 + Lh);
-                    const float *g = z1 + c * Lz + p2;
-                    float acc = 0.f;
-                    for (int sx = s0; sx < s1; sx++) acc += g[sx];
-                    part[half * (l.NW1 + C) + l.NW1 + c] = acc;
-                }
+            for (int c = 0; c < C; c++) acc[c] = 0.f;
+            for (int sx = lane; sx < L; sx += 64) {            // gw1[c][i][k] = sum_s gz[c][s] x[i][s + k - p1] -> haloed index s + k
+                const float xv = bias ? 1.0f : xs[i * Lx + sx + k];
+#pragma unroll
+                for (int c = 0; c < C; c++) acc[c] = fmaf(z1[c * Lz + p2 + sx], xv, acc[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const float sum = wave_sum(acc[c]);
+                if (lane == 0) gr[bias ? l.oB1 + c : l.oW1 + (c * 2 + i) * k1 + k] = sum;
             }
         }
-        __syncthreads();
-        for (int i = tid; i < l.NW1 + C; i += NT) gr[i] = part[i] + part[l.NW1 + C + i];   // oW1 = 0, oB1 = NW1: contiguous
         __syncthreads();
         // ---- P9: Adam(amsgrad) on every parameter (:285)
         step += 1;
@@ -310,6 +339,8 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
         if (!a.no_update) {
             const float bc2s = (float)sqrt(1.0 - b2t), ss = (float)(lr / (1.0 - b1t));
             for (int i = tid; i < NP; i += NT) adam_update_amsgrad(th[i], am[i], av[i], ax[i], gr[i], ss, bc2s);
+            __syncthreads();
+            nn_transpose_weights<NT, NLEV>(l, k1, k2, th, w1t, w2t);
         }
         __syncthreads();
     }
@@ -326,7 +357,7 @@ constexpr int NN_TILE = 256;                           // symbols per tile
 
 template <int NT, int NLEV>
 __device__ __forceinline__ void nn_forward_tile(const NNLayout &l, int sps, int k1, int k2, int64_t Ltot, const float *x0, const float *x1,
-                                                int n0, int Bt, float *xs, float *z1, float *a2, const float *th)
+                                                int n0, int Bt, float *xs, float *z1, float *a2, const float *th, const float *w1t, const float *w2t)
 {
     // tile symbols n0 .. n0+Bt-1: z1 needed at absolute positions [n0 sps - p2, (n0+Bt-1) sps + k2 - p2), x p1 beyond that on both sides
     const int tid = threadIdx.x, p1 = l.p1, p2 = l.p2;
@@ -338,9 +369,9 @@ __device__ __forceinline__ void nn_forward_tile(const NNLayout &l, int sps, int 
     }
     __syncthreads();
     // fc1 writes z1p[c][p2 + s] for s in [0, Lz_need) with absolute position zlo + s: shift the base so that p2 + s -> s
-    nn_fc1_elu<NT, NLEV>(l, k1, xs, th, z1 - p2, Lz_need, zlo, (int)Ltot);
+    nn_fc1_elu<NT, NLEV>(l, k1, xs, th, w1t, z1 - p2, Lz_need, zlo, (int)Ltot);
     __syncthreads();
-    nn_fc2<NT, NLEV>(l, sps, k2, Bt, NN_TILE, z1, th, a2, 0);   // haloed index of z1[n sps + k - p2] relative to zlo is n sps + k
+    nn_fc2<NT, NLEV>(l, sps, k2, Bt, NN_TILE, z1, th, w2t, a2);   // haloed index of z1[n sps + k - p2] relative to zlo is n sps + k
     __syncthreads();
 }
 
@@ -353,14 +384,16 @@ __global__ __launch_bounds__(NT) void nn_forward_kernel(int N, int sps, int M, i
     constexpr int C = 2 * NLEV;
     const int tid = threadIdx.x, run = blockIdx.x;
     const NNLayout l = nn_layout(NN_TILE, sps, M, NLEV, k1, k2);
-    float *xs = sm + l.xs, *z1 = sm + l.z1, *a2 = sm + l.a2, *th = sm + l.th;
+    float *xs = sm + l.xs, *z1 = sm + l.z1, *a2 = sm + l.a2, *th = sm + l.th, *w1t = sm + l.w1t, *w2t = sm + l.w2t;
     for (int i = tid; i < l.NP; i += NT) th[i] = theta[(size_t)run * l.NP + i];
+    __syncthreads();
+    nn_transpose_weights<NT, NLEV>(l, k1, k2, th, w1t, w2t);
     __syncthreads();
     const int64_t Ltot = (int64_t)N * sps;
     const float *x0 = x + (size_t)run * 2 * Ltot, *x1 = x0 + Ltot;
     for (int n0 = 0; n0 < N; n0 += NN_TILE) {
         const int Bt = min(NN_TILE, N - n0);
-        nn_forward_tile<NT, NLEV>(l, sps, k1, k2, Ltot, x0, x1, n0, Bt, xs, z1, a2, th);
+        nn_forward_tile<NT, NLEV>(l, sps, k1, k2, Ltot, x0, x1, n0, Bt, xs, z1, a2, th, w1t, w2t);
         for (int it = tid; it < 2 * Bt; it += NT) {
             const int axq = it / Bt, n = it - axq * Bt;
             float z[NLEV], zmax = -3.0e38f, ssum = 0.f;
@@ -390,19 +423,21 @@ __global__ __launch_bounds__(NT) void nn_validate_kernel(int N, int sps, int M, 
     __shared__ int sh_s;
     const int tid = threadIdx.x, run = blockIdx.x;
     const NNLayout l = nn_layout(NN_TILE, sps, M, NLEV, k1, k2);
-    float *xs = sm + l.xs, *z1 = sm + l.z1, *a2 = sm + l.a2, *th = sm + l.th, *red = sm + l.red;
+    float *xs = sm + l.xs, *z1 = sm + l.z1, *a2 = sm + l.a2, *th = sm + l.th, *w1t = sm + l.w1t, *w2t = sm + l.w2t, *red = sm + l.red;
     unsigned char *decs = reinterpret_cast<unsigned char *>(sm + l.total);      // [N] after the forward working set
     float amp[NLEV];
 #pragma unroll
     for (int i = 0; i < NLEV; i++) amp[i] = amp_g[i];
     for (int i = tid; i < l.NP; i += NT) th[i] = theta[(size_t)run * l.NP + i];
     __syncthreads();
+    nn_transpose_weights<NT, NLEV>(l, k1, k2, th, w1t, w2t);
+    __syncthreads();
     const int64_t Ltot = (int64_t)N * sps;
     const float *x0 = x + (size_t)run * 2 * Ltot, *x1 = x0 + Ltot;
     const int NE = N < VAL_NE ? N : VAL_NE;
     for (int n0 = 0; n0 < N; n0 += NN_TILE) {
         const int Bt = min(NN_TILE, N - n0);
-        nn_forward_tile<NT, NLEV>(l, sps, k1, k2, Ltot, x0, x1, n0, Bt, xs, z1, a2, th);
+        nn_forward_tile<NT, NLEV>(l, sps, k1, k2, Ltot, x0, x1, n0, Bt, xs, z1, a2, th, w1t, w2t);
         for (int n = tid; n < Bt; n += NT) {
             int d[2];
 #pragma unroll
@@ -449,10 +484,10 @@ static int launch_nn_validate(int R, int N, int sps, int M, int k1, int k2, int 
 template <int NLEV>
 static int launch_nn_train(const vaeq_nn_args &a, size_t lds, hipStream_t st)
 {
-    auto k = nn_train_kernel<512, NLEV>;
+    auto k = nn_train_kernel<1024, NLEV>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VAEQ_ERR_LDS;
-    hipLaunchKernelGGL(k, dim3(a.R), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(k, dim3(a.R), dim3(1024), lds, st, a);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
 
