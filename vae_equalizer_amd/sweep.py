@@ -62,6 +62,5 @@ def gather_rows(local_rows, n_runs, rank=None, world=None):
     allbuf = allbuf.cpu().reshape((world,) + shape)
     out = torch.empty((n_runs,) + tuple(local_rows.shape[1:]), dtype=torch.float32)
     for k in range(world):
-        idx = list(range(k, n_runs, world))
-        out[idx] = allbuf[k, :len(idx)]
+        out[k::world] = allbuf[k, :len(range(k, n_runs, world))]                    # run r lives on rank r % world
     return out
