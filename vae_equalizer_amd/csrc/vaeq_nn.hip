@@ -27,7 +27,7 @@ namespace vaeq {
 
 struct NNLayout {
     int C, L, p1, p2, Lx, Lz, mh, Mh, nm, NP, NW1, oW1, oB1, oW2, oB2, oH;
-    int xs, z1, a2, mu, vr, es, VS, th, gr, am, av, ax, w1t, w2t, red, total;
+    int xs, z1, a2, mu, vr, es, VS, th, gr, am, av, ax, w1t, w2t, w2u, red, total;
 };
 
 __host__ __device__ inline int npad4(int x) { return (x + 3) & ~3; }
@@ -52,14 +52,85 @@ __host__ __device__ inline NNLayout nn_layout(int B, int sps, int M, int n, int 
     l.th = take(l.NP); l.gr = take(l.NP); l.am = take(l.NP); l.av = take(l.NP); l.ax = take(l.NP);
     l.w1t = take(l.NW1);                               // fc1.weight as [i][k][c]: the 4 channels of a thread in one 16-byte read
     l.w2t = take(l.C * l.C * k2);                      // fc2.weight as [cc][k][c]
+    l.w2u = take(l.C * l.C * k2);                      // fc2.weight as [k][c][cc] (backward through fc2: 4 input channels per read)
     l.red = take(64);
     l.total = o;
     return l;
 }
 
+// Sum C per-lane partials over the 64 lanes of a wave, all C at once: log2(C) halving rounds (a lane hands over half of its values
+// and keeps the other half) followed by plain butterflies -- C-1 + (6 - log2 C) cross-lane moves instead of 6 C.  Afterwards every
+// lane holds the total of channel wave_reduce_channel<C>(lane).  Fixed order: bitwise reproducible.
+template <int C>
+__device__ __forceinline__ int wave_reduce_channel(int lane)
+{
+    int c = 0;
+#pragma unroll
+    for (int m = 32, bit = C >> 1; bit >= 1; m >>= 1, bit >>= 1) c |= (lane & m) ? bit : 0;
+    return c;
+}
+
+template <int C, int HALF, int MASK>
+struct WaveHalve {                                             // compile-time recursion: every register index below is static
+    static __device__ __forceinline__ void run(float (&acc)[C], int lane)
+    {
+        const bool up = (lane & MASK) != 0;                    // upper lanes keep the upper half of the channel range
+#pragma unroll
+        for (int i = 0; i < HALF; i++) {
+            const float send = up ? acc[i] : acc[i + HALF], keep = up ? acc[i + HALF] : acc[i];
+            acc[i] = keep + __shfl_xor(send, MASK, 64);
+        }
+        if constexpr (HALF > 1) WaveHalve<C, HALF / 2, MASK / 2>::run(acc, lane);
+    }
+};
+
+template <int C>
+__device__ __forceinline__ float wave_reduce_scatter(float (&acc)[C], int lane)
+{
+    WaveHalve<C, C / 2, 32>::run(acc, lane);
+    float v = acc[0];
+#pragma unroll
+    for (int m = 32 / C; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// Weight gradient of one group of 4 adjacent taps for all C output channels: lanes stride over the rows (samples / symbols), a row's
+// 4 input values and C upstream gradients give 4 C MACs (2 C v_pk_fma_f32) per 4 + C LDS reads; then four reduce-scatters.
+// out(t, c, sum) is called by one lane per (tap t, channel c).
+template <int C, typename OutF>
+__device__ __forceinline__ void nn_tapgroup_grad(int n_rows, const float *in, int in_step, const float *g, int g_cstride, bool ones, int lane,
+                                                 OutF out)
+{
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f acc[C][2];
+#pragma unroll
+    for (int c = 0; c < C; c++) acc[c][0] = acc[c][1] = v2f{0.f, 0.f};
+    for (int r = lane; r < n_rows; r += 64) {
+        const float *ip = in + r * in_step;
+        const v2f xA = ones ? v2f{1.f, 0.f} : v2f{ip[0], ip[1]}, xB = ones ? v2f{0.f, 0.f} : v2f{ip[2], ip[3]};
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const float gv = g[c * g_cstride + r];
+            acc[c][0] += gv * xA;
+            acc[c][1] += gv * xB;
+        }
+    }
+    constexpr int WR = 64 / C;
+    const int cme = wave_reduce_channel<C>(lane);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        float tmp[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) tmp[c] = (t & 1) ? acc[c][t >> 1].y : acc[c][t >> 1].x;
+        const float sum = wave_reduce_scatter<C>(tmp, lane);
+        if ((lane & (WR - 1)) == 0) out(t, cme, sum);
+    }
+}
+
 // ---- transposed weight copies (after every parameter update): w1t[(i k1 + k) C + c], w2t[(cc k2 + k) C + c]
 template <int NT, int NLEV>
-__device__ __forceinline__ void nn_transpose_weights(const NNLayout &l, int k1, int k2, const float *th, float *w1t, float *w2t)
+__device__ __forceinline__ void nn_transpose_weights(const NNLayout &l, int k1, int k2, const float *th, float *w1t, float *w2t,
+                                                     float *w2u = nullptr)
 {
     constexpr int C = 2 * NLEV;
     for (int j = threadIdx.x; j < l.NW1; j += NT) {
@@ -70,6 +141,11 @@ __device__ __forceinline__ void nn_transpose_weights(const NNLayout &l, int k1, 
         const int c = j % C, r = j / C, cc = r / k2, k = r - cc * k2;
         w2t[j] = th[l.oW2 + (c * C + cc) * k2 + k];
     }
+    if (w2u)
+        for (int j = threadIdx.x; j < C * C * k2; j += NT) {
+            const int cc = j % C, r = j / C, c = r % C, k = r / C;
+            w2u[j] = th[l.oW2 + (c * C + cc) * k2 + k];
+        }
 }
 
 // ---- forward on one LDS-resident window: xs (zero-haloed input) -> z1 (ELU output, zero-haloed) -> a2 (logits).
@@ -81,27 +157,36 @@ __device__ __forceinline__ void nn_fc1_elu(const NNLayout &l, int k1, const floa
 {
     // z1p[c][p2 + s] for s in [0, Lvalid); entries whose absolute position (zlo + s) lies outside [0, zhi) are fc2's zero padding
     constexpr int C = 2 * NLEV, CQ = C / 4;
-    for (int it = threadIdx.x; it < CQ * Lvalid; it += NT) {
-        const int cq = it / Lvalid, sx = it - cq * Lvalid;
+    typedef float v2f __attribute__((ext_vector_type(2)));     // channel pairs: every MAC below is a v_pk_fma_f32
+    const int H = (Lvalid + 1) / 2;                            // a thread takes samples sx and sx + H: one weight read feeds 8 MACs
+    for (int it = threadIdx.x; it < CQ * H; it += NT) {
+        const int cq = it / H, sx = it - cq * H;
         const float4 b = *reinterpret_cast<const float4 *>(th + l.oB1 + 4 * cq);
-        float a0 = b.x, a1 = b.y, a2_ = b.z, a3 = b.w;
+        v2f a01 = {b.x, b.y}, a23 = {b.z, b.w}, c01 = a01, c23 = a23;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const float *xp = xs + i * l.Lx + sx;              // out[s] = sum_k w[k] x[s + k - p1]: the haloed index of x[s + k - p1] is s + k
             const float4 *w = reinterpret_cast<const float4 *>(w1t + (i * k1) * C + 4 * cq);
             for (int k = 0; k < k1; k++) {
-                const float xv = xp[k];
+                const float xv = xp[k], xw = xp[H + k];
                 const float4 w4 = w[k * CQ];
-                a0 = fmaf(w4.x, xv, a0); a1 = fmaf(w4.y, xv, a1); a2_ = fmaf(w4.z, xv, a2_); a3 = fmaf(w4.w, xv, a3);
+                const v2f w01 = {w4.x, w4.y}, w23 = {w4.z, w4.w};
+                a01 += w01 * xv; a23 += w23 * xv;
+                c01 += w01 * xw; c23 += w23 * xw;
             }
         }
-        const float av[4] = {a0, a1, a2_, a3};
-        const int pos = zlo + sx;
-        const bool in = pos >= 0 && pos < zhi;
+        const float av[2][4] = {{a01.x, a01.y, a23.x, a23.y}, {c01.x, c01.y, c23.x, c23.y}};
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const float z = av[t] > 0.f ? av[t] : __expf(av[t]) - 1.0f;                  // F.elu, alpha = 1 (:177)
-            z1[(4 * cq + t) * l.Lz + l.p2 + sx] = in ? z : 0.f;
+        for (int u = 0; u < 2; u++) {
+            const int sy = sx + u * H;
+            if (sy >= Lvalid) continue;
+            const int pos = zlo + sy;
+            const bool in = pos >= 0 && pos < zhi;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const float z = av[u][t] > 0.f ? av[u][t] : __expf(av[u][t]) - 1.0f;     // F.elu, alpha = 1 (:177)
+                z1[(4 * cq + t) * l.Lz + l.p2 + sy] = in ? z : 0.f;
+            }
         }
     }
 }
@@ -111,21 +196,29 @@ __device__ __forceinline__ void nn_fc2(const NNLayout &l, int sps, int k2, int B
                                        float *a2)
 {
     constexpr int C = 2 * NLEV, CQ = C / 4;
-    for (int it = threadIdx.x; it < CQ * Bt; it += NT) {
-        const int cq = it / Bt, n = it - cq * Bt;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const int H = (Bt + 1) / 2;
+    for (int it = threadIdx.x; it < CQ * H; it += NT) {
+        const int cq = it / H, n = it - cq * H;
         const float4 b = *reinterpret_cast<const float4 *>(th + l.oB2 + 4 * cq);
-        float a0 = b.x, a1 = b.y, a2_ = b.z, a3 = b.w;
+        v2f a01 = {b.x, b.y}, a23 = {b.z, b.w}, c01 = a01, c23 = a23;
         const float4 *w = reinterpret_cast<const float4 *>(w2t + 4 * cq);
         for (int cc = 0; cc < C; cc++) {
             const float *zp = z1 + cc * l.Lz + n * sps;        // z1[n sps + k - p2] -> haloed index n sps + k
             for (int k = 0; k < k2; k++) {
-                const float zv = zp[k];
+                const float zv = zp[k], zw = zp[H * sps + k];
                 const float4 w4 = w[(cc * k2 + k) * CQ];
-                a0 = fmaf(w4.x, zv, a0); a1 = fmaf(w4.y, zv, a1); a2_ = fmaf(w4.z, zv, a2_); a3 = fmaf(w4.w, zv, a3);
+                const v2f w01 = {w4.x, w4.y}, w23 = {w4.z, w4.w};
+                a01 += w01 * zv; a23 += w23 * zv;
+                c01 += w01 * zw; c23 += w23 * zw;
             }
         }
-        a2[(4 * cq + 0) * astride + n] = a0; a2[(4 * cq + 1) * astride + n] = a1;
-        a2[(4 * cq + 2) * astride + n] = a2_; a2[(4 * cq + 3) * astride + n] = a3;
+        a2[(4 * cq + 0) * astride + n] = a01.x; a2[(4 * cq + 1) * astride + n] = a01.y;
+        a2[(4 * cq + 2) * astride + n] = a23.x; a2[(4 * cq + 3) * astride + n] = a23.y;
+        if (n + H < Bt) {
+            a2[(4 * cq + 0) * astride + n + H] = c01.x; a2[(4 * cq + 1) * astride + n + H] = c01.y;
+            a2[(4 * cq + 2) * astride + n + H] = c23.x; a2[(4 * cq + 3) * astride + n + H] = c23.y;
+        }
     }
 }
 
@@ -141,6 +234,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
     const int L = l.L, p1 = l.p1, p2 = l.p2, Lx = l.Lx, Lz = l.Lz, mh = l.mh, Mh = l.Mh, nm = l.nm, NP = l.NP;
     float *xs = sm + l.xs, *z1 = sm + l.z1, *a2 = sm + l.a2, *mu = sm + l.mu, *vr = sm + l.vr, *es = sm + l.es, *VS = sm + l.VS;
     float *th = sm + l.th, *gr = sm + l.gr, *am = sm + l.am, *av = sm + l.av, *ax = sm + l.ax, *w1t = sm + l.w1t, *w2t = sm + l.w2t, *red = sm + l.red;
+    float *w2u = sm + l.w2u;
     const float *hs = th + l.oH;                               // h_est[2][M]: re row, im row
 
     float amp[NLEV];
@@ -156,7 +250,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
     int step = a.step[run];
     double b1t = pow(0.9, (double)step), b2t = pow(0.999, (double)step);
     __syncthreads();
-    nn_transpose_weights<NT, NLEV>(l, k1, k2, th, w1t, w2t);
+    nn_transpose_weights<NT, NLEV>(l, k1, k2, th, w1t, w2t, w2u);
     __syncthreads();
 
     const size_t No = (size_t)a.steps * B;
@@ -218,29 +312,34 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
             es[t] = er; es[nm + t] = ei;
             se += er * er + ei * ei;
         }
-        for (int j = tid; j < M; j += NT) {
+        for (int j = wv; j < M; j += NWV) {                    // one wave per tap, lanes stride over the symbols
             const int lo = (Mh - j + sps - 1) / sps, hi_ = (nm - 1 + Mh - j) / sps;
             float acc = 0.f;
-            for (int np = lo; np <= hi_; np++) acc += vr[np] + vr[B + np];
-            VS[j] = acc;
+            for (int np = lo + lane; np <= hi_; np += 64) acc += vr[np] + vr[B + np];
+            acc = wave_sum(acc);
+            if (lane == 0) VS[j] = acc;
         }
         block_reduce3<NT>(se, klsum, 0.f, red);
         float Cc = red[0];
         for (int j = 0; j < M; j++) Cc = fmaf(hs[j] * hs[j] + hs[M + j] * hs[M + j], VS[j], Cc);
         const float gC = (float)nm / Cc;
         if (tid == 0 && a.loss) a.loss[(size_t)run * a.steps + s] = (float)nm * logf(Cc) + red[1];
-        // ---- P5: dL/dh (item j)
-        for (int j = tid; j < M; j += NT) {
+        // ---- P5: dL/dh, one wave per tap j
+        for (int j = wv; j < M; j += NWV) {
             const int lo = (Mh - j + sps - 1) / sps, hi_ = (nm - 1 + Mh - j) / sps;
             float ar = 0.f, ai = 0.f;
-            for (int np = lo; np <= hi_; np++) {
+            for (int np = lo + lane; np <= hi_; np += 64) {
                 const int t = np * sps - Mh + j;
                 const float a_ = es[t], b_ = es[nm + t], c_ = mu[np], d_ = mu[B + np];
                 ar = fmaf(a_, c_, ar); ar = fmaf(b_, d_, ar);
                 ai = fmaf(b_, c_, ai); ai = fmaf(-a_, d_, ai);
             }
-            gr[l.oH + j] = gC * (-2.0f * ar + 2.0f * hs[j] * VS[j]);
-            gr[l.oH + M + j] = gC * (-2.0f * ai + 2.0f * hs[M + j] * VS[j]);
+            ar = wave_sum(ar);
+            ai = wave_sum(ai);
+            if (lane == 0) {
+                gr[l.oH + j] = gC * (-2.0f * ar + 2.0f * hs[j] * VS[j]);
+                gr[l.oH + M + j] = gC * (-2.0f * ai + 2.0f * hs[M + j] * VS[j]);
+            }
         }
         // ---- P6: dL/dmu, dL/drho -> dL/dq -> softmax backward -> dL/dlogits in place of q; item = n (both axes)
         for (int n = tid; n < B; n += NT) {
@@ -272,63 +371,57 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
             }
         }
         __syncthreads();
-        // ---- P7a: fc2 weight / bias gradients.  One wave per (cc, k) column: lanes stride over n, 16 channel sums per lane, then
-        //      wave reductions (conflict-free reads; the z1 value of a lane feeds all C channels).  Pseudo column C*k2: the biases.
-        for (int col = wv; col <= C * k2; col += NWV) {
-            const bool bias = col == C * k2;
-            const int cc = bias ? 0 : col / k2, k = bias ? 0 : col - cc * k2;
-            float acc[C];
-#pragma unroll
-            for (int c = 0; c < C; c++) acc[c] = 0.f;
-            for (int n = lane; n < B; n += 64) {
-                const float zv = bias ? 1.0f : z1[cc * Lz + n * sps + k];
-#pragma unroll
-                for (int c = 0; c < C; c++) acc[c] = fmaf(a2[c * B + n], zv, acc[c]);
-            }
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                const float sum = wave_sum(acc[c]);
-                if (lane == 0) gr[bias ? l.oB2 + c : l.oW2 + (c * C + cc) * k2 + k] = sum;
+        // ---- P7a: fc2 weight / bias gradients: one wave per (input channel, group of 4 taps); pseudo group at the end: the biases
+        {
+            const int nkq = (k2 + 3) / 4, ngrp = C * nkq;
+            for (int grp = wv; grp <= ngrp; grp += NWV) {
+                const bool bias = grp == ngrp;
+                const int cc = bias ? 0 : grp / nkq, k0 = bias ? 0 : (grp - cc * nkq) * 4;
+                nn_tapgroup_grad<C>(B, z1 + cc * Lz + k0, sps, a2, B, bias, lane, [&](int t, int c, float sum) {
+                    if (bias) { if (t == 0) gr[l.oB2 + c] = sum; }
+                    else if (k0 + t < k2) gr[l.oW2 + (c * C + cc) * k2 + k0 + t] = sum;
+                });
             }
         }
         __syncthreads();
-        // ---- P7b: dL/dz1 through fc2, times ELU' -> dL/da1 in place of z1; item = (cc, s)
-        for (int it = tid; it < C * L; it += NT) {
-            const int cc = it / L, sx = it - cc * L;
-            float acc = 0.f;
+        // ---- P7b: dL/dz1 through fc2, times ELU' -> dL/da1 in place of z1; item = (4 input channels, sample): every dL/dlogit read
+        //      feeds the 4 channels, whose weights come as one 16-byte read of the [k][c][cc] copy
+        for (int it = tid; it < CQ * L; it += NT) {
+            const int ccq = it / L, sx = it - ccq * L;
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
             for (int k = 0; k < k2; k++) {
                 const int t = sx + p2 - k;
                 if (t < 0 || t % sps) continue;
                 const int n = t / sps;
                 if (n >= B) continue;
-                const float4 *w = reinterpret_cast<const float4 *>(w2t + (cc * k2 + k) * C);
+                const float4 *w = reinterpret_cast<const float4 *>(w2u + (k * C) * C + 4 * ccq);
 #pragma unroll
-                for (int cq = 0; cq < CQ; cq++) {
-                    const float4 w4 = w[cq];
-                    acc = fmaf(w4.x, a2[(4 * cq + 0) * B + n], acc); acc = fmaf(w4.y, a2[(4 * cq + 1) * B + n], acc);
-                    acc = fmaf(w4.z, a2[(4 * cq + 2) * B + n], acc); acc = fmaf(w4.w, a2[(4 * cq + 3) * B + n], acc);
+                for (int c = 0; c < C; c++) {
+                    const float av_ = a2[c * B + n];
+                    const float4 w4 = w[c * CQ];
+                    g0 = fmaf(w4.x, av_, g0); g1 = fmaf(w4.y, av_, g1); g2 = fmaf(w4.z, av_, g2); g3 = fmaf(w4.w, av_, g3);
                 }
             }
-            const float z = z1[cc * Lz + p2 + sx];
-            z1[cc * Lz + p2 + sx] = acc * (z > 0.f ? 1.0f : z + 1.0f);                    // ELU' = 1 or exp(a1) = z1 + 1
+            const float gg[4] = {g0, g1, g2, g3};
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int ix = (4 * ccq + u) * Lz + p2 + sx;
+                const float z = z1[ix];
+                z1[ix] = gg[u] * (z > 0.f ? 1.0f : z + 1.0f);                             // ELU' = 1 or exp(a1) = z1 + 1
+            }
         }
         __syncthreads();
-        // ---- P8: fc1 weight / bias gradients, same scheme: one wave per (i, k) column, lanes stride over the samples
-        for (int col = wv; col <= 2 * k1; col += NWV) {
-            const bool bias = col == 2 * k1;
-            const int i = bias ? 0 : col / k1, k = bias ? 0 : col - i * k1;
-            float acc[C];
-#pragma unroll
-            for (int c = 0; c < C; c++) acc[c] = 0.f;
-            for (int sx = lane; sx < L; sx += 64) {            // gw1[c][i][k] = sum_s gz[c][s] x[i][s + k - p1] -> haloed index s + k
-                const float xv = bias ? 1.0f : xs[i * Lx + sx + k];
-#pragma unroll
-                for (int c = 0; c < C; c++) acc[c] = fmaf(z1[c * Lz + p2 + sx], xv, acc[c]);
-            }
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                const float sum = wave_sum(acc[c]);
-                if (lane == 0) gr[bias ? l.oB1 + c : l.oW1 + (c * 2 + i) * k1 + k] = sum;
+        // ---- P8: fc1 weight / bias gradients, same scheme: one wave per (input row, group of 4 taps)
+        {
+            const int nkq = (k1 + 3) / 4, ngrp = 2 * nkq;
+            for (int grp = wv; grp <= ngrp; grp += NWV) {
+                const bool bias = grp == ngrp;
+                const int i = bias ? 0 : grp / nkq, k0 = bias ? 0 : (grp - i * nkq) * 4;
+                // gw1[c][i][k] = sum_s gz[c][s] x[i][s + k - p1] -> haloed index s + k
+                nn_tapgroup_grad<C>(L, xs + i * Lx + k0, 1, z1 + p2, Lz, bias, lane, [&](int t, int c, float sum) {
+                    if (bias) { if (t == 0) gr[l.oB1 + c] = sum; }
+                    else if (k0 + t < k1) gr[l.oW1 + (c * 2 + i) * k1 + k0 + t] = sum;
+                });
             }
         }
         __syncthreads();
@@ -340,7 +433,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
             const float bc2s = (float)sqrt(1.0 - b2t), ss = (float)(lr / (1.0 - b1t));
             for (int i = tid; i < NP; i += NT) adam_update_amsgrad(th[i], am[i], av[i], ax[i], gr[i], ss, bc2s);
             __syncthreads();
-            nn_transpose_weights<NT, NLEV>(l, k1, k2, th, w1t, w2t);
+            nn_transpose_weights<NT, NLEV>(l, k1, k2, th, w1t, w2t, w2u);
         }
         __syncthreads();
     }
@@ -484,10 +577,10 @@ static int launch_nn_validate(int R, int N, int sps, int M, int k1, int k2, int 
 template <int NLEV>
 static int launch_nn_train(const vaeq_nn_args &a, size_t lds, hipStream_t st)
 {
-    auto k = nn_train_kernel<1024, NLEV>;
+    auto k = nn_train_kernel<512, NLEV>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VAEQ_ERR_LDS;
-    hipLaunchKernelGGL(k, dim3(a.R), dim3(1024), lds, st, a);
+    hipLaunchKernelGGL(k, dim3(a.R), dim3(512), lds, st, a);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
 
