@@ -19,12 +19,11 @@
 namespace vaeq {
 
 constexpr int EPI_NT = 256, N_SHIFT = 21, HALF_SHIFT = 10, N_CUT = 10, EDGE = 11;
-constexpr int N_COMBO = 2 * N_SHIFT;          // (lag, E-polarisation)
-constexpr int N_CHUNK = EPI_NT / N_COMBO;     // symbol-axis chunks summed by different threads (6)
-constexpr int EPI_TILE = 1024;                // symbols staged in LDS per correlation tile
+constexpr int N_CHUNK = EPI_NT / 8;           // thread = (E-polarisation b, TX row ac = (a, c), chunk): 2 x 4 x 32
+constexpr int EPI_CH = N_SHIFT;               // symbols per chunk and tile: one full rotation of the 21-entry lag window
+constexpr int EPI_TILE = N_CHUNK * EPI_CH;    // 672 symbols staged in LDS per correlation tile
 
 struct EpiShared {
-    float part[N_CHUNK][N_COMBO][4];          // partial correlations [chunk][(lag,b)][(a,c)]
     float corr[2][2][2][N_SHIFT];             // [c][b][a][lag]
     int shift[2];
     int r;
@@ -32,56 +31,65 @@ struct EpiShared {
     int kept;
     float lo[8], hi[8];                       // decision interval of each TX level (shared_funcs.py:234-236)
     float red[64];
-    float4 txs[EPI_TILE];                     // TX tile: (pol0 I, pol0 Q, pol1 I, pol1 Q) per symbol
-    float es[2][EPI_TILE + 2 * HALF_SHIFT];   // equaliser-side tile with a 10-symbol halo on both sides
+    union {
+        struct {
+            float4 txs[EPI_TILE];                     // TX tile: (pol0 I, pol0 Q, pol1 I, pol1 Q) per symbol
+            float es[2][EPI_TILE + 2 * HALF_SHIFT];   // equaliser-side tile with a 10-symbol halo on both sides
+        } t;
+        float part[N_CHUNK][2][4][N_SHIFT];           // per-chunk partial correlations (after the last tile)
+    } u;
 };
 
-// correlation of the TX reference with E[b][.] rolled by lag-10 (shared_funcs.py:300-304): thread = (lag, b, chunk).
-// The symbol axis is walked in tiles staged in LDS (coalesced global reads once per tile; the inner loop reads one
-// 16-byte TX quad as an LDS broadcast and one E sample per 4 FMAs).
-__device__ void epi_correlate(const float *__restrict__ E /*[2][N] or strided*/, int64_t estride, const __half *__restrict__ tx, int64_t N64,
+// correlation of the TX reference with E[b][.] rolled by lag-10 (shared_funcs.py:300-304).  The symbol axis is walked in tiles staged
+// in LDS; a thread owns one (b, TX row, chunk of 21 symbols) and ALL 21 lags: per symbol one TX value and one new E sample feed 21
+// FMAs -- the lag window lives in 21 registers used as a ring whose rotation is resolved at compile time (21 unrolled steps).
+__device__ __forceinline__ void epi_correlate(const float *__restrict__ E /*[2][N] or strided*/, int64_t estride, const __half *__restrict__ tx, int64_t N64,
                               EpiShared &sh)
 {
     const int tid = threadIdx.x, N = (int)N64;
-    const bool worker = tid < N_COMBO * N_CHUNK;
-    const int chunk = tid / N_COMBO, cb = tid - chunk * N_COMBO, lag = cb >> 1, b = cb & 1;
-    float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;           // [a][c]
+    const int chunk = tid >> 3, b = (tid >> 2) & 1, ac = tid & 3;
+    float acc[N_SHIFT];
+#pragma unroll
+    for (int l = 0; l < N_SHIFT; l++) acc[l] = 0.f;
     for (int t0 = 0; t0 < N; t0 += EPI_TILE) {
         const int tl = min(EPI_TILE, N - t0);
-        for (int i = tid; i < tl; i += EPI_NT)
-            sh.txs[i] = make_float4(__half2float(tx[0 * (size_t)N + t0 + i]), __half2float(tx[1 * (size_t)N + t0 + i]),
-                                    __half2float(tx[2 * (size_t)N + t0 + i]), __half2float(tx[3 * (size_t)N + t0 + i]));
-        for (int i = tid; i < 2 * (tl + 2 * HALF_SHIFT); i += EPI_NT) {     // E[b][t0 - 10 .. t0 + tl + 10), indices mod N
-            const int bb = i / (tl + 2 * HALF_SHIFT), j = i - bb * (tl + 2 * HALF_SHIFT);
-            int m = t0 + j - HALF_SHIFT;
+        for (int i = tid; i < EPI_TILE; i += EPI_NT)           // symbols past the end contribute zeros
+            sh.u.t.txs[i] = i < tl ? make_float4(__half2float(tx[0 * (size_t)N + t0 + i]), __half2float(tx[1 * (size_t)N + t0 + i]),
+                                                 __half2float(tx[2 * (size_t)N + t0 + i]), __half2float(tx[3 * (size_t)N + t0 + i]))
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < 2 * (EPI_TILE + 2 * HALF_SHIFT); i += EPI_NT) {     // E[b][t0 - 10 .. t0 + TILE + 10), indices mod N
+            const int bb = i / (EPI_TILE + 2 * HALF_SHIFT), j = i - bb * (EPI_TILE + 2 * HALF_SHIFT);
+            int m = (t0 + j - HALF_SHIFT) % N;
             if (m < 0) m += N;
-            if (m >= N) m -= N;
-            sh.es[bb][j] = E[(int64_t)bb * estride + m];
+            sh.u.t.es[bb][j] = E[(int64_t)bb * estride + m];
         }
         __syncthreads();
-        if (worker) {
-            const int j0 = tl * chunk / N_CHUNK, j1 = tl * (chunk + 1) / N_CHUNK;
-            const float *eb = sh.es[b] + 2 * HALF_SHIFT - lag;  // roll(E, lag-10)[n] = E[n - (lag-10)] -> es index j + 20 - lag
-            for (int j = j0; j < j1; j++) {
-                const float e = eb[j];
-                const float4 t = sh.txs[j];
-                s00 = fmaf(t.x, e, s00);
-                s01 = fmaf(t.y, e, s01);
-                s10 = fmaf(t.z, e, s10);
-                s11 = fmaf(t.w, e, s11);
+        {
+            // roll(E, lag-10)[n] = E[n - (lag-10)] -> es index j + 20 - lag.  W[i] = es[j0 + i]; symbol j0 + s uses W[s .. s + 20];
+            // ring R[i % 21] = W[i]
+            const float *eb = sh.u.t.es[b] + chunk * EPI_CH;
+            const float *tp = reinterpret_cast<const float *>(sh.u.t.txs + chunk * EPI_CH) + ac;
+            float R[N_SHIFT];
+#pragma unroll
+            for (int i = 0; i < N_SHIFT - 1; i++) R[i] = eb[i];
+#pragma clang loop unroll(full)
+            for (int s = 0; s < EPI_CH; s++) {
+                R[(s + N_SHIFT - 1) % N_SHIFT] = eb[s + N_SHIFT - 1];
+                const float tv = tp[4 * s];
+#pragma unroll
+                for (int l = 0; l < N_SHIFT; l++) acc[l] = fmaf(tv, R[(s + 2 * HALF_SHIFT - l) % N_SHIFT], acc[l]);
             }
         }
         __syncthreads();
     }
-    if (worker) {
-        sh.part[chunk][cb][0] = s00; sh.part[chunk][cb][1] = s01; sh.part[chunk][cb][2] = s10; sh.part[chunk][cb][3] = s11;
-    }
+#pragma unroll
+    for (int l = 0; l < N_SHIFT; l++) sh.u.part[chunk][b][ac][l] = acc[l];
     __syncthreads();
-    if (tid < N_COMBO * 4) {                                    // fixed-order sum over chunks
-        const int cb = tid >> 2, ac = tid & 3, lag = cb >> 1, b = cb & 1, a = ac >> 1, c = ac & 1;
+    if (tid < 2 * 4 * N_SHIFT) {                                // fixed-order sum over chunks
+        const int l = tid % N_SHIFT, bac = tid / N_SHIFT, b2 = bac >> 2, ac2 = bac & 3, a = ac2 >> 1, c = ac2 & 1;
         float s = 0.f;
-        for (int k = 0; k < N_CHUNK; k++) s += sh.part[k][cb][ac];
-        sh.corr[c][b][a][lag] = fabsf(s);
+        for (int k = 0; k < N_CHUNK; k++) s += sh.u.part[k][b2][ac2][l];
+        sh.corr[c][b2][a][l] = fabsf(s);
     }
     __syncthreads();
     if (tid == 0) {                                             // shared_funcs.py:303-314
@@ -122,7 +130,7 @@ __device__ __forceinline__ bool epi_keep(int n, int N, int batch_len, int shift0
 }
 
 template <int NLEV>
-__global__ __launch_bounds__(EPI_NT) void dp_epilogue_kernel(int64_t N, int batch_len, const float *__restrict__ q, const float *__restrict__ y,
+__global__ __launch_bounds__(EPI_NT, 6) void dp_epilogue_kernel(int64_t N, int batch_len, const float *__restrict__ q, const float *__restrict__ y,
                                                              const __half *__restrict__ txg, const float *__restrict__ amp_g,
                                                              const float *__restrict__ var, const float *__restrict__ nu_sc,
                                                              float *__restrict__ ser, int32_t *__restrict__ shift_out,
