@@ -182,6 +182,12 @@ typedef struct vaeq_awgn_args {
 int vaeq_awgn_train(const vaeq_awgn_args *args, void *stream);
 int64_t vaeq_awgn_lds_bytes(int32_t B, int32_t sps, int32_t M, int32_t n_lev);
 
+/* Stand-alone ELBO of the single-polarisation variants for a given q (values): func_VAELE_MQAM_shaping.loss_function (:63-95) with
+ * P[R][n_lev], func_VAENN_MQAM.loss_function (:63-95, entropy instead of KL) with P == NULL.
+ * q[R][2*n_lev][B], x[R][2][B*sps], h[R][2][M] -> loss[R]. */
+int vaeq_awgn_loss(int32_t R, int32_t B, int32_t sps, int32_t M, int32_t n_lev, const float *q, const float *x, const float *h,
+                   const float *amp, const float *P, float *loss, void *stream);
+
 /* twoFIR.forward in eval mode (validation pass, func_VAELE_MQAM_shaping.py:311-313) on N symbols per run:
  * x[R][2][N*sps], W[R][2][M] -> q[R][2*n_lev][N] (nullable), y[R][2][N] (un-normalised). */
 int vaeq_awgn_forward(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, const float *x, const float *W,

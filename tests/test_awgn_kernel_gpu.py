@@ -188,3 +188,29 @@ def test_awgn_validate_rejects_bad_shapes():
         eng.validate(x, torch.zeros(2, 2, 32, dtype=torch.float16, device=DEV))          # N < 64
     with pytest.raises(ValueError):
         eng.validate(torch.zeros(2, 2, 2 * 100, device=DEV), torch.zeros(2, 2, 99, dtype=torch.float16, device=DEV))
+
+
+# ------------------------------------------------------------------ stand-alone operator mirrors of the AWGN modules
+def test_awgn_operator_mirrors_against_golden():
+    """func_VAELE_MQAM_shaping.twoFIR / loss_function and func_VAENN_MQAM.loss_function (values) on the captured minibatches."""
+    from vae_equalizer_amd import func_VAELE_MQAM_shaping as aw
+    from vae_equalizer_amd import func_VAENN_MQAM as nn_
+    for name in AWGN:
+        g = load_golden(name)
+        B, sps = int(g["B"]), int(g["sps"])
+        x = torch.from_numpy(g["rx"][:, :B * sps]).to(DEV)
+        amp = torch.from_numpy(g["amp_levels"]).to(DEV)
+        net = aw.twoFIR(int(g["M_est"]), sps).to(DEV)
+        with torch.no_grad():
+            net.conv_w.weight.copy_(torch.from_numpy(g["W0"]).reshape(1, 2, -1))
+        q, out = net(x, amp, float(g["amp_mean"]), float(g["var"]))
+        assert relerr(_np(out), g["out0"]) < 2e-6 and np.max(np.abs(_np(q) - g["q0"])) < 5e-4
+        loss = aw.loss_function(torch.from_numpy(g["q0"]).to(DEV), x, torch.from_numpy(g["h0"]).to(DEV), DEV, amp, torch.from_numpy(g["P"]).to(DEV))
+        assert abs(float(loss) - g["loss"][0]) / abs(g["loss"][0]) < 1e-5
+    for name in ("G8_vaenn_64qam", "G8_vaenn_16qam_small", "G8_vaenn_4qam_k5"):
+        g = load_golden(name)
+        B, sps, M = int(g["B"]), int(g["sps"]), int(g["M_est"])
+        x = torch.from_numpy(g["rx"][:, :B * sps]).to(DEV)
+        h0 = torch.from_numpy(g["theta0"][-2 * M:].reshape(2, M)).to(DEV)
+        loss = nn_.loss_function(torch.from_numpy(g["q0"]).to(DEV), x, h0, DEV, torch.from_numpy(g["amp_levels"]).to(DEV))
+        assert abs(float(loss) - g["loss"][0]) / abs(g["loss"][0]) < 1e-5

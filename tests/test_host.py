@@ -74,6 +74,31 @@ def test_processing_signatures_match_reference():
     assert pos(fx.processing) == ["mod", "sps", "SNR", "nu", "M_est", "theta_diff", "theta", "lr_optim", "batch_len", "N_train_max",
                                   "num_frames", "flex_step", "channel", "symb_rate", "tau_cd", "tau_pmd", "phiIQ", "N_lrhalf"]
     assert pos(aw.processing) == ["mod", "sps", "SNR", "nu", "M_est", "lr_optim", "batch_len", "N_valid", "N_train", "num_epochs", "epe", "channel"]
+    from vae_equalizer_amd import func_VAENN_MQAM as nn_
+    assert pos(nn_.processing) == ["mod", "sps", "SNR", "M_est", "kernel_1", "kernel_2", "lr_optim", "batch_len", "N_valid", "N_train",
+                                   "num_epochs", "epe", "channel", "net_type"]                # func_VAENN_MQAM.py:215
+
+
+def test_vaenn_tables_and_host_generator():
+    """Constants of func_VAENN_MQAM.processing (:219-237) and the host restatement of its generate_data (:39-61): fixed noise level,
+    uniform symbols, reference aligned at T + M - 1."""
+    import torch
+    from vae_equalizer_amd import channel as ch
+    from vae_equalizer_amd import func_VAENN_MQAM as nn_
+    t = nn_.vaenn_tables("16-QAM", "h1", 2)
+    assert abs(np.mean(np.abs(t["constellation"]) ** 2) - 1) < 1e-12 and len(t["amps"]) == 4 and abs(np.linalg.norm(t["h_channel"]) - 1) < 1e-6
+    rx, data = nn_.generate_data(4000, t["M_channel"], t["constellation"], 200.0, t["h_channel"], 2, "cpu", np.random.RandomState(3))
+    assert rx.shape == (2, 8000) and data.shape == (2, 4000) and data.dtype == torch.float16
+    # noiseless: rx is the zero-stuffed reference filtered by rrc * h (samples whose pulse support lies inside the reference)
+    g = np.convolve(ch.rrcfir(8, 2, 0.1), t["h_channel"])
+    up = np.zeros(2 * 3999 + 1, complex)
+    up[::2] = data[0].numpy().astype(float) + 1j * data[1].numpy().astype(float)
+    clean = np.convolve(up, g, mode="valid")
+    o = 2 * (8 + t["M_channel"] - 1)
+    got = (rx[0].numpy() + 1j * rx[1].numpy())[o:o + len(clean)]
+    assert np.max(np.abs(got - clean[:len(got)])) < 3e-3                       # fp16 reference levels
+    with pytest.raises(UnboundLocalError):
+        nn_.vaenn_tables("16-QAM", "h7", 2)
 
 
 def test_init_tables_bit_exact():

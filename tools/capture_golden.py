@@ -525,6 +525,22 @@ def capture_G8(sfun, awgn):
          args=np.array([str(v) for v in ("16-QAM", 2, 20, 25, 25, 3, 4e-3, 300, 5000, 1200, 120, 2, "h1", "Net")]))
 
 
+def capture_G9(sfun, awgn):
+    """Config 4 (optical DP 64-QAM VAEflex) through the reference's processing(): 70 frames x 2000 symbols = 190 window steps per
+    frame, long enough to converge (~15 min on one core)."""
+    import contextlib
+    import io
+    import func_VAEflex_DP_MQAM_shaping as ref_flex
+
+    t0 = time.time()
+    with SeededRng(91), contextlib.redirect_stdout(io.StringIO()):
+        SER, Var_est, var = ref_flex.processing("64-QAM", 2, 23, 0.0, 25, 0.006 * np.pi, np.pi / 10, 2.5e-3, 100, 2000, 70, 10, "h0", 90e9,
+                                                -26e-24, 0.1e-12 * np.sqrt(1000), np.array([0.0314, 0.0314], dtype=np.complex64), 170)
+    print(f"   G9 flex run: {time.time() - t0:.0f}s  SER last {SER[:, -1].tolist()}")
+    save("G9_flex_run", SER=t2n(SER), Var_est=t2n(Var_est), var=t2n(var), seed=np.int64(91), seconds=np.float64(time.time() - t0),
+         N_frame_max=np.int64(2000), num_frames=np.int64(70), theta_diff=np.float64(0.006 * np.pi))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -533,7 +549,7 @@ def main():
     torch.set_num_threads(1)
     os.makedirs(OUT, exist_ok=True)
     sfun, awgn = _import_reference()
-    todo = [s for s in args.only.split(",") if s] or ["G0", "G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8"]
+    todo = [s for s in args.only.split(",") if s] or ["G0", "G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9"]
     for g in todo:
         print(f"[{g}]")
         if g == "G7":

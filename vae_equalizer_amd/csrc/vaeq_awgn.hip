@@ -492,6 +492,70 @@ static int launch_validate(int R, int N, int sps, int M, int n_shift, const floa
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
 
+
+// Stand-alone ELBO of the single-polarisation variants for a given q (values only):
+//   func_VAELE_MQAM_shaping.loss_function (:63-95):  nm log C + sum q log(q / P + 1e-12)      (P != nullptr)
+//   func_VAENN_MQAM.loss_function (:63-95):          nm log C + sum q log(q + 1e-12)          (P == nullptr)
+// One workgroup per run; q[R][2n][B], x[R][2][B*sps], h[R][2][M] -> loss[R].
+template <int NLEV>
+__global__ __launch_bounds__(256) void awgn_loss_kernel(int B, int sps, int M, const float *__restrict__ q, const float *__restrict__ x,
+                                                        const float *__restrict__ h, const float *__restrict__ amp_g, const float *__restrict__ P,
+                                                        float *__restrict__ loss)
+{
+    extern __shared__ float4 smem4[];
+    float *sm = reinterpret_cast<float *>(smem4);
+    __shared__ float red[64];
+    __shared__ float hs[2 * 64], VS[64];
+    const int run = blockIdx.x, tid = threadIdx.x;
+    const int L = B * sps, mh = M / 2, Mh = 2 * mh, nm = L - Mh;
+    float *mu = sm, *vr = sm + 2 * B;
+    float amp[NLEV], invP[NLEV];
+#pragma unroll
+    for (int i = 0; i < NLEV; i++) { amp[i] = amp_g[i]; invP[i] = P ? 1.0f / P[(size_t)run * NLEV + i] : 1.0f; }
+    for (int i = tid; i < 2 * M; i += 256) hs[i] = h[(size_t)run * 2 * M + i];
+    const float *qr = q + (size_t)run * 2 * NLEV * B, *x0 = x + (size_t)run * 2 * L, *x1 = x0 + L;
+    float klsum = 0.f;
+    for (int it = tid; it < 2 * B; it += 256) {
+        const int c = it / B, n = it - c * B;
+        const bool inr = (n >= mh) && (n < B - mh);
+        float qq[NLEV], e1 = 0.f, e2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NLEV; i++) { qq[i] = qr[(size_t)(c * NLEV + i) * B + n]; e1 = fmaf(amp[i], qq[i], e1); }
+#pragma unroll
+        for (int i = 0; i < NLEV; i++) {
+            const float d = amp[i] - e1;
+            e2 = fmaf(qq[i] * d, d, e2);
+            if (inr) klsum = fmaf(qq[i], __logf(qq[i] * invP[i] + 1e-12f), klsum);
+        }
+        mu[it] = e1; vr[it] = e2;
+    }
+    __syncthreads();
+    float se = 0.f;
+    for (int t = tid; t < nm; t += 256) {
+        float dr = 0.f, di = 0.f;
+        for (int j = (t + Mh) % sps; j <= Mh; j += sps) {
+            const int np = (t + Mh - j) / sps;
+            const float a_ = mu[np], b_ = mu[B + np], c_ = hs[j], d_ = hs[M + j];
+            dr = fmaf(c_, a_, dr); dr = fmaf(-d_, b_, dr);
+            di = fmaf(c_, b_, di); di = fmaf(d_, a_, di);
+        }
+        const float er = x0[mh + t] - dr, ei = x1[mh + t] - di;
+        se += er * er + ei * ei;
+    }
+    for (int j = tid; j < M; j += 256) {
+        const int lo = (Mh - j + sps - 1) / sps, hi_ = (nm - 1 + Mh - j) / sps;
+        float acc = 0.f;
+        for (int np = lo; np <= hi_; np++) acc += vr[np] + vr[B + np];
+        VS[j] = acc;
+    }
+    block_reduce3<256>(se, klsum, 0.f, red);
+    if (tid == 0) {
+        float C = red[0];
+        for (int j = 0; j < M; j++) C = fmaf(hs[j] * hs[j] + hs[M + j] * hs[M + j], VS[j], C);
+        loss[run] = (float)nm * logf(C) + red[1];
+    }
+}
+
 template <int NT, int NLEV>
 static int launch_awgn(const vaeq_awgn_args &a, size_t lds, hipStream_t st)
 {
@@ -582,4 +646,31 @@ extern "C" int vaeq_awgn_validate(int32_t R, int64_t N, int32_t sps, int32_t M, 
     case 8: return vaeq::launch_validate<8>(R, (int)N, sps, M, n_shift, x, W, amp, amp_mean, var, d, y_ws, ser, shift, st);
     }
     return VAEQ_ERR_SHAPE;
+}
+
+extern "C" int vaeq_awgn_loss(int32_t R, int32_t B, int32_t sps, int32_t M, int32_t n_lev, const float *q, const float *x, const float *h,
+                              const float *amp, const float *P, float *loss, void *stream)
+{
+    if (R == 0) return VAEQ_OK;                                // an empty batch owns no memory: its pointers may be NULL
+    if (!q || !x || !h || !amp || !loss) return VAEQ_ERR_NULL;
+    if (R < 0 || B <= 0 || sps <= 0 || M <= 0 || (M & 1) == 0 || M > 63 || (int64_t)B * sps - 2 * (M / 2) <= 0 || B <= 2 * (M / 2)) return VAEQ_ERR_SHAPE;
+    const size_t lds = (size_t)4 * B * sizeof(float);
+    if (lds > 150 * 1024) return VAEQ_ERR_LDS;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define VAEQ_AL(NL)                                                                                                                     \
+    {                                                                                                                                   \
+        auto k = vaeq::awgn_loss_kernel<NL>;                                                                                            \
+        if (lds > 32 * 1024 &&                                                                                                          \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
+            return VAEQ_ERR_LDS;                                                                                                        \
+        hipLaunchKernelGGL(k, dim3(R), dim3(256), lds, st, B, sps, M, q, x, h, amp, P, loss);                                           \
+    }
+    switch (n_lev) {
+    case 2: VAEQ_AL(2) break;
+    case 4: VAEQ_AL(4) break;
+    case 8: VAEQ_AL(8) break;
+    default: return VAEQ_ERR_SHAPE;
+    }
+#undef VAEQ_AL
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }

@@ -370,3 +370,21 @@ def dp_epilogue_compact(eq, dec, y, data, amp_levels, nu_sc, var, batch_len=None
                                                      nat.ptr(shift, torch.int32), nat.ptr(rflag, torch.int32), nat.current_stream(dev)),
                   "vaeq_dp_epilogue_compact")
     return dict(SER=ser, shift_q=shift[:, 0].long(), r_q=rflag[:, 0].long(), shift_c=shift[:, 1].long(), r_c=rflag[:, 1].long())
+
+
+def awgn_loss(q, x, h, amp_levels, P=None):
+    """ELBO of the single-polarisation variants for a given q (vaeq_awgn_loss): q[R,2n,B] (or [2n,B]), x[R,2,B*sps], h[R,2,M];
+    P[R,n] / [n] -> the VAE-LE form (KL to the prior), P None -> the VAE-NN form (entropy).  Returns loss[R] (or a 0-dim tensor)."""
+    single = q.dim() == 2
+    if single:
+        q, x, h = q.unsqueeze(0), x.unsqueeze(0), h.unsqueeze(0)
+    dev, R, B = q.device, q.shape[0], q.shape[-1]
+    amp = _f32(amp_levels, dev).reshape(-1).contiguous()
+    n = amp.numel()
+    q, x, h = q.contiguous().float(), x.contiguous().float(), h.contiguous().float()
+    Pt = None if P is None else _f32(P, dev).expand(R, n).contiguous()
+    loss = torch.empty(R, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().vaeq_awgn_loss(R, B, x.shape[-1] // B, h.shape[-1], n, nat.ptr(q), nat.ptr(x), nat.ptr(h), nat.ptr(amp),
+                                           nat.ptr(Pt), nat.ptr(loss), nat.current_stream(dev)), "vaeq_awgn_loss")
+    return loss[0] if single else loss

@@ -25,6 +25,34 @@ def awgn_tables(mod, nu, SNR, channel, sps):
     return dict(amps=t["amps"], P=t["P"], amp_mean=amp_mean, var=10 ** (-SNR / 10), h_channel=h_channel, M_channel=len(ir), n=n)
 
 
+generate_data = ch.generate_data                       # (:39-61) host restatement, reference signature + optional rng / noise streams
+
+
+class twoFIR(torch.nn.Module):
+    """Complex FIR + output normalisation + per-axis soft demapper (:206-231); ``conv_w.weight`` keeps the reference's
+    Conv1d(2, 1, M) layout.  forward() runs vaeq_awgn_forward (inference; training goes through engine.AWGNEngine)."""
+
+    def __init__(self, M_est, sps):
+        super().__init__()
+        self.sps = sps
+        self.conv_w = torch.nn.Conv1d(2, 1, M_est, bias=False, padding=M_est // 2, stride=sps).to(dtype=torch.float32)
+        torch.nn.init.dirac_(self.conv_w.weight)
+
+    def forward(self, x, amp_levels, amp_mean, var):
+        W = self.conv_w.weight.detach()
+        eng = AWGNEngine(1, W.shape[-1], amp_levels, np.full(len(amp_levels), 1.0 / len(amp_levels)), float(amp_mean), float(var), x.device,
+                         self.sps)
+        eng.set_state(W, None)
+        q, y = eng.forward(x.reshape(1, 2, -1))
+        return q[0], y[0]
+
+
+def loss_function(q, rx, h, device, amp_levels, P):
+    """ELBO of one minibatch (:63-95), value only: q[2n,B], rx[2,B*sps], h[2,M] (HIP: vaeq_awgn_loss)."""
+    from .engine import awgn_loss
+    return awgn_loss(q, rx, h.detach(), amp_levels, P)
+
+
 def find_shift(q, tx, N_shift, amp_levels, num_lev, device=None):
     """:188-204 -- lag of the best |correlation| between E_q[x_I] and the TX I (or Q) sequence over the first 1000 symbols."""
     E = torch.einsum("i,in->n", amp_levels, q[:num_lev, :1000])

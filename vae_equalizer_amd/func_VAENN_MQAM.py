@@ -48,6 +48,12 @@ def generate_data(N, M, constellation, SNR, h_channel, sps, device, rng=None):
             torch.from_numpy(np.ascontiguousarray(ref)).to(device, torch.float16))
 
 
+def loss_function(q, rx, h, device, amp_levels):
+    """ELBO of one minibatch (:63-95), value only: q[2n,B], rx[2,B*sps], h[2,M] (HIP: vaeq_awgn_loss with the entropy term)."""
+    from .engine import awgn_loss
+    return awgn_loss(q, rx, h.detach(), amp_levels, None)
+
+
 def run_vaenn_batch(runs, mod, sps, M_est, kernel_1, kernel_2, batch_len, N_valid, N_train, num_epochs, epe, channel, device=None,
                     verbose=False, generator="hip", seed=0, theta0=None):
     """R VAE-NN runs at once: ``runs`` = list of dict(SNR, lr_optim, seed).  Per epoch one generator call, ONE training launch
