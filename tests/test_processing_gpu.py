@@ -278,3 +278,24 @@ def test_vaenn_device_pipeline_monte_carlo():
     assert locked.sum() >= 10, tail
     assert (SER[~locked, -1] < SER[~locked, 0] - 0.05).all(), SER[~locked][:, [0, -1]]
     assert abs(SER[locked, -20:].mean() - g["SER"][-20:].mean()) < 6e-4, (SER[locked, -20:].mean(), g["SER"][-20:].mean())
+
+
+def test_vaeflex_converging_run_vs_reference():
+    """Config 4 (optical DP 64-QAM VAEflex, window 100 / step 10) through processing() on the 70 frames x 2000 symbols the reference saw
+    under seed 91 (13 300 window steps): same convergence behaviour, converged SER and noise estimate within Monte-Carlo error."""
+    from vae_equalizer_amd.func_VAEflex_DP_MQAM_shaping import processing
+    g = load_golden("G9_flex_run")
+    F, N = int(g["num_frames"]), int(g["N_frame_max"])
+    SER, Var_est, var = processing("64-QAM", 2, 23, 0.0, 25, float(g["theta_diff"]), np.pi / 10, 2.5e-3, 100, N, F, 10, "h0", 90e9, -26e-24,
+                                   TAU_PMD, PHI, 170, seed=int(g["seed"]), verbose=False)
+    ours, ref = SER.numpy(), g["SER"]
+    assert ours.shape == ref.shape == (4, F)
+    assert np.max(np.abs(ours[:, :2] - ref[:, :2])) < 0.03                     # same frames: the first 380 steps agree closely
+    conv = lambda s: int(np.argmax((s < 0.1).all(0)))
+    assert (ref[:, -1] < 0.1).all() and (ours[:, -1] < 0.1).all()
+    assert abs(conv(ours) - conv(ref)) <= 12, (conv(ours), conv(ref))
+    lo = max(conv(ours), conv(ref)) + 4
+    assert F - lo >= 8, (conv(ours), conv(ref))
+    assert np.all(np.abs(ours[:, lo:].mean(1) - ref[:, lo:].mean(1)) < 6e-3), (ours[:, lo:].mean(1), ref[:, lo:].mean(1))
+    ve, vr = Var_est.numpy()[:, lo:].mean(1), g["Var_est"][:, lo:].mean(1)
+    assert np.max(np.abs(ve - vr) / vr) < 0.05, (ve, vr)
