@@ -299,3 +299,24 @@ def test_vaeflex_converging_run_vs_reference():
     assert np.all(np.abs(ours[:, lo:].mean(1) - ref[:, lo:].mean(1)) < 6e-3), (ours[:, lo:].mean(1), ref[:, lo:].mean(1))
     ve, vr = Var_est.numpy()[:, lo:].mean(1), g["Var_est"][:, lo:].mean(1)
     assert np.max(np.abs(ve - vr) / vr) < 0.05, (ve, vr)
+
+
+def test_vaele_pcs_run_vs_reference():
+    """Config 5's shape: optical DP 64-QAM with probabilistic shaping (nu = 0.0270955, H = 5.72 bit) through processing() on the
+    200 frames x 3000 symbols the reference saw under seed 101 (6000 minibatch steps): convergence frame, converged SER (both
+    estimators: the constellation-based one uses the PCS-aware decision thresholds) and noise estimate."""
+    from vae_equalizer_amd.func_VAELE_DP_MQAM_shaping import processing
+    g = load_golden("G10_pcs_run")
+    F, N = int(g["num_frames"]), int(g["N_frame_max"])
+    SER, Var_est, var = processing("64-QAM", 2, 23, float(g["nu"]), 25, float(g["theta_diff"]), np.pi / 10, 2.5e-3, 100, N, F, 10, "h0", 90e9,
+                                   -26e-24, TAU_PMD, PHI, 170, seed=int(g["seed"]), verbose=False)
+    ours, ref = SER.numpy(), g["SER"]
+    assert np.allclose(var.numpy(), g["var"], rtol=1e-6)
+    assert np.max(np.abs(ours[:, :2] - ref[:, :2])) < 0.03
+    conv = lambda s: int(np.argmax((s < 0.1).all(0)))
+    assert abs(conv(ours) - conv(ref)) <= 25, (conv(ours), conv(ref))
+    lo = max(conv(ours), conv(ref)) + 4
+    assert F - lo >= 20, (conv(ours), conv(ref))
+    assert np.all(np.abs(ours[:, lo:].mean(1) - ref[:, lo:].mean(1)) < 2.5e-3), (ours[:, lo:].mean(1), ref[:, lo:].mean(1))
+    ve, vr = Var_est.numpy()[:, lo:].mean(1), g["Var_est"][:, lo:].mean(1)
+    assert np.max(np.abs(ve - vr) / vr) < 0.05, (ve, vr)

@@ -541,6 +541,22 @@ def capture_G9(sfun, awgn):
          N_frame_max=np.int64(2000), num_frames=np.int64(70), theta_diff=np.float64(0.006 * np.pi))
 
 
+def capture_G10(sfun, awgn):
+    """Config 5's shape (optical DP 64-QAM + PCS, H = 5.72 bit): one VAE-LE run through the reference's processing(), 200 frames x 3000
+    symbols at SNR 23 dB."""
+    import contextlib
+    import io
+    import func_VAELE_DP_MQAM_shaping as ref_vaele
+
+    t0 = time.time()
+    with SeededRng(101), contextlib.redirect_stdout(io.StringIO()):
+        SER, Var_est, var = ref_vaele.processing("64-QAM", 2, 23, NU_572, 25, 0.006 * np.pi, np.pi / 10, 2.5e-3, 100, 3000, 200, 10, "h0", 90e9,
+                                                 -26e-24, 0.1e-12 * np.sqrt(1000), np.array([0.0314, 0.0314], dtype=np.complex64), 170)
+    print(f"   G10 PCS run: {time.time() - t0:.0f}s  SER last {SER[:, -1].tolist()}")
+    save("G10_pcs_run", SER=t2n(SER), Var_est=t2n(Var_est), var=t2n(var), seed=np.int64(101), seconds=np.float64(time.time() - t0),
+         N_frame_max=np.int64(3000), num_frames=np.int64(200), theta_diff=np.float64(0.006 * np.pi), nu=np.float64(NU_572))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -549,7 +565,7 @@ def main():
     torch.set_num_threads(1)
     os.makedirs(OUT, exist_ok=True)
     sfun, awgn = _import_reference()
-    todo = [s for s in args.only.split(",") if s] or ["G0", "G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9"]
+    todo = [s for s in args.only.split(",") if s] or ["G0", "G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10"]
     for g in todo:
         print(f"[{g}]")
         if g == "G7":
