@@ -315,8 +315,8 @@ def generate_awgn_batch_hip(R, N, amps, P, SNR, h_channel, sps, device, seed, fr
     rx = torch.empty(R, 2, sps * N, dtype=torch.float32, device=dev)
     data = torch.empty(R, 2, N, dtype=torch.float16, device=dev)
     sigma = torch.empty(R, dtype=torch.float32, device=dev)
-    sig = torch.empty(R, geo["Ls"], 2, dtype=torch.float32, device=dev)
-    pw = torch.empty(R, dtype=torch.float32, device=dev)
+    sig = torch.empty((R, geo["Ls"], 2) if sps != 2 else (1,), dtype=torch.float32, device=dev)   # sps == 2: the fused kernels need none
+    pw = torch.empty(R, (geo["Ls"] + 2047) // 2048, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         nat.check(nat.lib().vaeq_gen_awgn(R, N, geo["N_conv"], sps, n, geo["Lg"], geo["Ls"], geo["ref_offset"], nat.ptr(amp_t), nat.ptr(cdf),
                                           nat.ptr(g_t), nat.ptr(snr), C.c_uint64(_mix_seed(seed, 0)), C.c_uint32(frame), nat.ptr(sig),

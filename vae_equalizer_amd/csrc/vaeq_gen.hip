@@ -65,10 +65,23 @@ constexpr int TX_TILE = 2048, TX_NT = 256, TX_MAXG = 96, TX_SYMPH = (TX_TILE / 2
 // (4-way polyphase) and -- for the symbols the tile owns -- written out as the TX reference data[r][p][c][n - ref_lo] (fp16).
 // Thread t computes the 8 consecutive samples 8t..8t+7: per symbol one LDS read feeds 8 complex MACs; the taps g[kb-6 .. kb+7] of
 // four consecutive symbols come from 14 broadcast reads.
+// MODE 0: write sig (the DP path: the FFT needs it).  Single-polarisation path without any sig round trip through HBM:
+// MODE 1: only the tile's sum |sig|^2 -> part[run][tile] (fixed-order block reduction);
+// MODE 2: sigma from the tile sums (or sigma_fixed), noise added in registers (same Philox words as gen_finish_kernel), planar rx out.
+struct TxFuse {
+    float *part;                 // [R][n_tiles]
+    const float *snr_db;         // [R]
+    const float *sigma_fixed;    // nullable [R]
+    float *rx;                   // [R][2][Lout]
+    float *sigma_out;            // nullable [R]
+    int Lout, sps;
+};
+
+template <int MODE>
 __global__ __launch_bounds__(TX_NT) void gen_tx_kernel(int N_conv, int n_lev, int Lg, int Ls, int Lrow, const float *__restrict__ amp,
                                                        const float *__restrict__ cdf_g, const float2 *__restrict__ g, uint64_t seed,
                                                        uint32_t frame, int npol, float2 *__restrict__ sig, int N, int ref_lo,
-                                                       __half *__restrict__ data)
+                                                       __half *__restrict__ data, TxFuse fz)
 {
     __shared__ float2 sym[4 * TX_SYMPH];
     __shared__ float2 gsp[TX_GLO + TX_MAXG + TX_GHI];
@@ -104,7 +117,7 @@ __global__ __launch_bounds__(TX_NT) void gen_tx_kernel(int N_conv, int n_lev, in
     }
     __syncthreads();
     const int sb = s0 + 8 * tid;
-    if (sb >= Lrow) return;
+    if (MODE == 0 && sb >= Lrow) return;
     cacc acc[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) acc[i] = cacc0();
@@ -123,10 +136,51 @@ __global__ __launch_bounds__(TX_NT) void gen_tx_kernel(int N_conv, int n_lev, in
             for (int i = 0; i < 8; i++) cmac(acc[i], tp[6 - 2 * mm + i].x, tp[6 - 2 * mm + i].y, sv);
         }
     }
-    float2 *o = sig + ((size_t)run * npol + pol) * Lrow + sb;
+    if (MODE == 0) {
+        float2 *o = sig + ((size_t)run * npol + pol) * Lrow + sb;
 #pragma unroll
-    for (int i = 0; i < 8; i++)
-        if (sb + i < Lrow) o[i] = sb + i < Ls ? cfin(acc[i]) : make_float2(0.f, 0.f);
+        for (int i = 0; i < 8; i++)
+            if (sb + i < Lrow) o[i] = sb + i < Ls ? cfin(acc[i]) : make_float2(0.f, 0.f);
+        return;
+    }
+    __shared__ float red[64];
+    if (MODE == 1) {
+        float pw = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float2 v = cfin(acc[i]);
+            if (sb + i < Ls) pw += v.x * v.x + v.y * v.y;
+        }
+        block_reduce3<TX_NT>(pw, 0.f, 0.f, red);
+        if (tid == 0) fz.part[(size_t)run * gridDim.x + blockIdx.x] = red[0];
+        return;
+    }
+    float sigma;                                               // MODE 2
+    if (fz.sigma_fixed) sigma = fz.sigma_fixed[run];
+    else {
+        float pw = 0.f;
+        for (unsigned t = 0; t < gridDim.x; t++) pw += fz.part[(size_t)run * gridDim.x + t];      // fixed order
+        sigma = sqrtf(pw / (float)Ls * (float)fz.sps * 0.5f / exp10f(fz.snr_db[run] * 0.1f));
+    }
+    if (fz.sigma_out && blockIdx.x == 0 && tid == 0) fz.sigma_out[run] = sigma;
+    float *rI = fz.rx + (size_t)run * 2 * fz.Lout, *rQ = rI + fz.Lout;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {                              // sample pairs (sb + 2u, sb + 2u + 1): noise word j = sample / 2
+        const int i0 = sb + 2 * u;
+        if (i0 >= fz.Lout) break;
+        const Philox4 r = philox4x32_10((uint32_t)(i0 >> 1), run, frame, (uint32_t)(STREAM_NOISE * 2 + pol), (uint32_t)seed, (uint32_t)(seed >> 32));
+        float sn0, cs0, sn1, cs1;
+        const float rad0 = sigma * sqrtf(-2.0f * __logf(u01(r.x))), rad1 = sigma * sqrtf(-2.0f * __logf(u01(r.z)));
+        __sincosf(6.283185307179586f * u01(r.y), &sn0, &cs0);
+        __sincosf(6.283185307179586f * u01(r.w), &sn1, &cs1);
+        const float2 v0 = cfin(acc[2 * u]), v1 = cfin(acc[2 * u + 1]);
+        rI[i0] = v0.x + rad0 * cs0;
+        rQ[i0] = v0.y + rad0 * sn0;
+        if (i0 + 1 < fz.Lout) {
+            rI[i0 + 1] = v1.x + rad1 * cs1;
+            rQ[i0 + 1] = v1.y + rad1 * sn1;
+        }
+    }
 }
 
 // any sps: one thread per output sample, symbols and reference drawn per use
@@ -246,8 +300,8 @@ static void launch_tx(int R, int npol, int N, int N_conv, int sps, int n_lev, in
                       const float *cdf, const float2 *g, uint64_t seed, uint32_t frame, float2 *sig, __half *data, hipStream_t st)
 {
     if (sps == 2) {
-        hipLaunchKernelGGL(gen_tx_kernel, dim3((Lrow + TX_TILE - 1) / TX_TILE, npol, R), dim3(TX_NT), 0, st, N_conv, n_lev, Lg, Ls, Lrow, amp, cdf,
-                           g, seed, frame, npol, sig, N, ref_offset, data);
+        hipLaunchKernelGGL(gen_tx_kernel<0>, dim3((Lrow + TX_TILE - 1) / TX_TILE, npol, R), dim3(TX_NT), 0, st, N_conv, n_lev, Lg, Ls, Lrow, amp, cdf,
+                           g, seed, frame, npol, sig, N, ref_offset, data, TxFuse{});
         return;
     }
     hipLaunchKernelGGL(gen_tx_generic_kernel, dim3((Lrow + 255) / 256 > 64 ? 64 : (Lrow + 255) / 256, npol, R), dim3(256), 0, st, N_conv, sps, n_lev,
@@ -312,17 +366,28 @@ extern "C" int vaeq_gen_dp_finish(int32_t R, int32_t N, int32_t sps, int32_t Ls,
 // Single-polarisation AWGN / ISI channel (AWGN_channel/func_VAELE_MQAM_shaping.py:39-61) for R runs: the same three stages with one
 // polarisation and no dispersion step: PCS symbols (:45), zero-stuffing + pulse shaping + channel impulse response as one 'valid'
 // FIR with g = rrc * h_channel (:47-52), sigma_n from the mean power (:54), complex AWGN (:55), planar rx[R][2][sps*N] (:57) and the
-// TX reference data[R][2][N] (fp16, :59).  sig_ws: [R][Ls] complex64 scratch, power_ws: [R] floats.
+// TX reference data[R][2][N] (fp16, :59).  power_ws: [R][ceil(Ls / 2048)] floats; sig_ws ([R][Ls] complex64) only for sps != 2.
 extern "C" int vaeq_gen_awgn(int32_t R, int32_t N, int32_t N_conv, int32_t sps, int32_t n_lev, int32_t Lg, int32_t Ls, int32_t ref_offset,
                              const float *amp, const float *cdf, const float *g_complex, const float *snr_db, uint64_t seed, uint32_t frame,
                              float *sig_ws, float *power_ws, float *rx, void *data_f16, float *sigma_out, const float *sigma_fixed,
                              void *stream)
 {
     if (R == 0) return VAEQ_OK;                                // an empty batch owns no memory: its pointers may be NULL
-    if (!amp || !cdf || !g_complex || (!snr_db && !sigma_fixed) || !sig_ws || !power_ws || !rx) return VAEQ_ERR_NULL;
+    if (!amp || !cdf || !g_complex || (!snr_db && !sigma_fixed) || (sps != 2 && !sig_ws) || !power_ws || !rx) return VAEQ_ERR_NULL;
     if (!tx_shape_ok(R, N, N_conv, sps, n_lev, Lg, Ls, Ls, ref_offset)) return VAEQ_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float2 *sig = reinterpret_cast<float2 *>(sig_ws);
+    if (sps == 2) {                                            // fused: the clean signal never goes through HBM
+        const dim3 grid((Ls + vaeq::TX_TILE - 1) / vaeq::TX_TILE, 1, R);
+        const float2 *g2 = reinterpret_cast<const float2 *>(g_complex);
+        vaeq::TxFuse fz{power_ws, snr_db, sigma_fixed, rx, sigma_out, sps * N, sps};
+        if (!sigma_fixed)
+            hipLaunchKernelGGL(vaeq::gen_tx_kernel<1>, grid, dim3(vaeq::TX_NT), 0, st, N_conv, n_lev, Lg, Ls, Ls, amp, cdf, g2, seed, frame, 1, sig, N,
+                               ref_offset, static_cast<__half *>(nullptr), fz);
+        hipLaunchKernelGGL(vaeq::gen_tx_kernel<2>, grid, dim3(vaeq::TX_NT), 0, st, N_conv, n_lev, Lg, Ls, Ls, amp, cdf, g2, seed, frame, 1, sig, N,
+                           ref_offset, reinterpret_cast<__half *>(data_f16), fz);
+        return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+    }
     vaeq::launch_tx(R, 1, N, N_conv, sps, n_lev, Lg, Ls, Ls, ref_offset, amp, cdf, reinterpret_cast<const float2 *>(g_complex), seed, frame, sig,
                     reinterpret_cast<__half *>(data_f16), st);
     vaeq::launch_finish(R, 1, N, sps, Ls, Ls, snr_db, seed, frame, sig, power_ws, rx, sigma_out, st, sigma_fixed);
