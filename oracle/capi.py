@@ -299,3 +299,53 @@ def nn_train(state, rx, n_steps, B, amp, k1, k2, M, lr, sps=2, dtype=np.float32)
     f(n_steps, B, sps, M, n, k1, k2, S, _p(rx), _p(state.theta), _p(state.m), _p(state.v), _p(state.vmax), C.byref(state.step), _p(amp),
       C.c_double(lr), _p(loss))
     return loss
+
+
+# ---- Net_BN (BatchNorm variant): theta = [w1 | b1 | w2 | b2 | gamma | beta | h], bn = [running_mean | running_var]
+def nnbn_param_count(n, k1, k2, M):
+    return nn_param_count(n, k1, k2, M) + 4 * n
+
+
+def nnbn_step_grads(x, theta, bn, amp, k1, k2, M, sps=2, dtype=np.float32):
+    """Training-mode forward + loss + backward of Net_BN; returns the UPDATED running statistics too."""
+    sfx, ct, npt = _sfx(dtype)
+    x, theta, amp = _arr(x, npt), _arr(theta, npt), _arr(amp, npt)
+    bn = np.array(bn, dtype=npt).reshape(-1)
+    L, n = x.shape[-1], amp.shape[0]
+    B = L // sps
+    assert theta.size == nnbn_param_count(n, k1, k2, M) and bn.size == 4 * n
+    q, g = np.empty((2 * n, B), npt), np.empty(theta.size, npt)
+    f = getattr(lib(), "vaeq_oracle_nnbn_step_grads" + sfx)
+    f.restype = ct
+    loss = f(B, sps, M, n, k1, k2, _p(x), _p(theta), _p(bn), _p(amp), _p(q), _p(g))
+    return dict(q=q, loss=npt(loss), g=g, bn=bn)
+
+
+def nnbn_forward_eval(x, theta, bn, n, k1, k2, sps=2, dtype=np.float32):
+    sfx, ct, npt = _sfx(dtype)
+    x, theta, bn = _arr(x, npt), _arr(theta, npt), _arr(bn, npt)
+    B = x.shape[-1] // sps
+    q = np.empty((2 * n, B), npt)
+    f = getattr(lib(), "vaeq_oracle_nnbn_forward_eval" + sfx)
+    f.restype = None
+    f(B, sps, n, k1, k2, _p(x), _p(theta), _p(bn), _p(q))
+    return q
+
+
+class NNBNState(NNState):
+    def __init__(self, theta, n, dtype=np.float32):
+        super().__init__(theta, dtype)
+        self.bn = np.concatenate([np.zeros(2 * n, dtype), np.ones(2 * n, dtype)])     # running_mean = 0, running_var = 1
+
+
+def nnbn_train(state, rx, n_steps, B, amp, k1, k2, M, lr, sps=2, dtype=np.float32):
+    sfx, ct, npt = _sfx(dtype)
+    rx, amp = _arr(rx, npt), _arr(amp, npt)
+    S, n = rx.shape[-1], amp.shape[0]
+    assert n_steps * B * sps <= S and state.theta.size == nnbn_param_count(n, k1, k2, M)
+    loss = np.empty(n_steps, npt)
+    f = getattr(lib(), "vaeq_oracle_nnbn_train" + sfx)
+    f.restype = None
+    f(n_steps, B, sps, M, n, k1, k2, S, _p(rx), _p(state.theta), _p(state.bn), _p(state.m), _p(state.v), _p(state.vmax), C.byref(state.step),
+      _p(amp), C.c_double(lr), _p(loss))
+    return loss

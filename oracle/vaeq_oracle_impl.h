@@ -684,6 +684,190 @@ void FN(vaeq_oracle_nn_train)(int n_steps, int B, int sps, int M, int n, int k1,
     }
     free(mb);
 }
+
+/* ---- Net_BN (NN:190-211): Net with BatchNorm1d(C) between the ELU and fc2, fc1 initialised with kaiming_uniform_.
+ * theta = [w1 | b1 | w2 | b2 | gamma C | beta C | h 2M] (net.parameters() order, then h_est); bn = [running_mean C | running_var C].
+ * training != 0: batch statistics over the L samples of the minibatch (biased variance, eps 1e-5), running stats updated with
+ * momentum 0.1 and the unbiased variance; training == 0: running statistics (net.eval(), NN:287). */
+#define NNBN_NP(C_, k1_, k2_, M_) (NN_NP(C_, k1_, k2_, M_) + 2 * (C_))
+void FN(vaeq_oracle_nnbn_forward)(int B, int sps, int n, int k1, int k2, int training, const REAL *x, const REAL *theta, REAL *bn,
+                                  REAL *zhat /*[C][L]*/, REAL *stat /*[2][C] mean, rstd*/, REAL *zb /*[C][L]*/, REAL *a2, REAL *q)
+{
+    const int C = 2 * n, L = B * sps, p1 = k1 / 2, p2 = k2 / 2;
+    const REAL *w1 = theta, *b1 = w1 + C * 2 * k1, *w2 = b1 + C, *b2 = w2 + C * C * k2, *gam = b2 + C, *bet = gam + C;
+    for (int c = 0; c < C; c++) {
+        for (int s = 0; s < L; s++) {
+            REAL a = b1[c];
+            for (int i = 0; i < 2; i++)
+                for (int k = 0; k < k1; k++) {
+                    const int sx = s + k - p1;
+                    if (sx >= 0 && sx < L) a += w1[(c * 2 + i) * k1 + k] * x[i * L + sx];
+                }
+            zhat[c * L + s] = a > 0 ? a : FN(r_exp)(a) - 1;      /* ELU output, normalised in place below */
+        }
+        REAL mean, rstd;
+        if (training) {
+            REAL sm = 0, sv = 0;
+            for (int s = 0; s < L; s++) sm += zhat[c * L + s];
+            mean = sm / (REAL)L;
+            for (int s = 0; s < L; s++) sv += (zhat[c * L + s] - mean) * (zhat[c * L + s] - mean);
+            const REAL var = sv / (REAL)L;
+            rstd = 1 / FN(r_sqrt)(var + (REAL)1e-5);
+            bn[c] = (REAL)0.9 * bn[c] + (REAL)0.1 * mean;
+            bn[C + c] = (REAL)0.9 * bn[C + c] + (REAL)0.1 * (var * (REAL)L / (REAL)(L - 1));
+        } else {
+            mean = bn[c];
+            rstd = 1 / FN(r_sqrt)(bn[C + c] + (REAL)1e-5);
+        }
+        stat[c] = mean; stat[C + c] = rstd;
+        for (int s = 0; s < L; s++) {
+            zhat[c * L + s] = (zhat[c * L + s] - mean) * rstd;
+            zb[c * L + s] = gam[c] * zhat[c * L + s] + bet[c];
+        }
+    }
+    for (int c = 0; c < C; c++)
+        for (int nn = 0; nn < B; nn++) {
+            REAL a = b2[c];
+            for (int cc = 0; cc < C; cc++)
+                for (int k = 0; k < k2; k++) {
+                    const int sx = nn * sps + k - p2;
+                    if (sx >= 0 && sx < L) a += w2[(c * C + cc) * k2 + k] * zb[cc * L + sx];
+                }
+            a2[c * B + nn] = a;
+        }
+    for (int ax = 0; ax < 2; ax++)
+        for (int nn = 0; nn < B; nn++) {
+            REAL xres = 0;
+            for (int i = 0; i < sps; i++) xres += x[ax * L + nn * sps + i] / (REAL)sps;
+            REAL lg[MAXLEV], mx = -1e30, sum = 0;
+            for (int i = 0; i < n; i++) { lg[i] = a2[(ax * n + i) * B + nn] + xres; if (lg[i] > mx) mx = lg[i]; }
+            for (int i = 0; i < n; i++) { lg[i] = FN(r_exp)(lg[i] - mx); sum += lg[i]; }
+            for (int i = 0; i < n; i++) q[(ax * n + i) * B + nn] = lg[i] / sum;
+        }
+}
+
+REAL FN(vaeq_oracle_nnbn_step_grads)(int B, int sps, int M, int n, int k1, int k2, const REAL *x, const REAL *theta, REAL *bn,
+                                     const REAL *amp, REAL *q, REAL *g)
+{
+    const int C = 2 * n, L = B * sps, mh = M / 2, Mh = 2 * mh, nm = L - Mh, p1 = k1 / 2, p2 = k2 / 2;
+    const REAL *w2 = theta + C * 2 * k1 + C, *gam = w2 + C * C * k2 + C, *h = theta + NNBN_NP(C, k1, k2, M) - 2 * M;
+    REAL *gw1 = g, *gb1 = gw1 + C * 2 * k1, *gw2 = gb1 + C, *gb2 = gw2 + C * C * k2, *gga = gb2 + C, *gbe = gga + C, *gh = gbe + C;
+    REAL *buf = (REAL *)malloc(sizeof(REAL) * ((size_t)3 * C * L + 2 * C + 2 * C * B + 8 * L + 2 * nm));
+    REAL *zhat = buf, *zb = zhat + C * L, *gz = zb + C * L, *stat = gz + C * L, *a2 = stat + 2 * C, *ga2 = a2 + C * B;
+    REAL *Eq = ga2 + C * B, *Eq2 = Eq + 2 * L, *gEq = Eq2 + 2 * L, *gEq2 = gEq + 2 * L, *Dre = gEq2 + 2 * L, *Dim = Dre + nm;
+    REAL ones[MAXLEV], Cc;
+    for (int i = 0; i < MAXLEV; i++) ones[i] = 1;
+    FN(vaeq_oracle_nnbn_forward)(B, sps, n, k1, k2, 1, x, theta, bn, zhat, stat, zb, a2, q);
+    const REAL loss = FN(awgn_loss_core)(B, sps, M, n, q, x, h, amp, ones, Eq, Eq2, Dre, Dim, &Cc);
+    const REAL gC = (REAL)nm / Cc;
+    for (int i = 0; i < 2 * L; i++) { gEq[i] = 0; gEq2[i] = 0; }
+    for (int j = 0; j <= Mh; j++) {
+        const REAL hr = h[j], hi = h[M + j], hh = hr * hr + hi * hi;
+        REAL ghr = 0, ghi = 0, vs = 0;
+        for (int t = 0; t < nm; t++) {
+            const int s = t + Mh - j;
+            const REAL dDr = -2 * (x[mh + t] - Dre[t]) * gC, dDi = -2 * (x[L + mh + t] - Dim[t]) * gC;
+            ghr += dDr * Eq[s] + dDi * Eq[L + s];
+            ghi += -dDr * Eq[L + s] + dDi * Eq[s];
+            gEq[s] += dDr * hr + dDi * hi;
+            gEq[L + s] += -dDr * hi + dDi * hr;
+            gEq2[s] += gC * hh;
+            gEq2[L + s] += gC * hh;
+            gEq[s] += gC * hh * (-2 * Eq[s]);
+            gEq[L + s] += gC * hh * (-2 * Eq[L + s]);
+            vs += (Eq2[s] - Eq[s] * Eq[s]) + (Eq2[L + s] - Eq[L + s] * Eq[L + s]);
+        }
+        gh[j] = ghr + gC * 2 * hr * vs;
+        gh[M + j] = ghi + gC * 2 * hi * vs;
+    }
+    for (int ax = 0; ax < 2; ax++)
+        for (int nn = 0; nn < B; nn++) {
+            const REAL gmu = gEq[ax * L + nn * sps], grho = gEq2[ax * L + nn * sps];
+            const int inr = (nn >= mh && nn < B - mh);
+            REAL gq[MAXLEV], dot = 0;
+            for (int i = 0; i < n; i++) {
+                const REAL qq = q[(ax * n + i) * B + nn];
+                gq[i] = amp[i] * gmu + (amp[i] * amp[i]) * grho;
+                if (inr) gq[i] += FN(r_log)(qq + (REAL)1e-12) + qq / (qq + (REAL)1e-12);
+                dot += qq * gq[i];
+            }
+            for (int i = 0; i < n; i++) ga2[(ax * n + i) * B + nn] = q[(ax * n + i) * B + nn] * (gq[i] - dot);
+        }
+    for (int i = 0; i < C * L; i++) gz[i] = 0;
+    for (int c = 0; c < C; c++) {                                /* fc2 backward (input = BN output zb) */
+        REAL sb = 0;
+        for (int nn = 0; nn < B; nn++) sb += ga2[c * B + nn];
+        gb2[c] = sb;
+        for (int cc = 0; cc < C; cc++)
+            for (int k = 0; k < k2; k++) {
+                REAL sw = 0;
+                const REAL w = w2[(c * C + cc) * k2 + k];
+                for (int nn = 0; nn < B; nn++) {
+                    const int sx = nn * sps + k - p2;
+                    if (sx < 0 || sx >= L) continue;
+                    sw += ga2[c * B + nn] * zb[cc * L + sx];
+                    gz[cc * L + sx] += w * ga2[c * B + nn];
+                }
+                gw2[(c * C + cc) * k2 + k] = sw;
+            }
+    }
+    for (int c = 0; c < C; c++) {                                /* BatchNorm backward (batch statistics), then ELU' */
+        REAL s1 = 0, s2 = 0;
+        for (int s = 0; s < L; s++) { s1 += gz[c * L + s]; s2 += gz[c * L + s] * zhat[c * L + s]; }
+        gbe[c] = s1;
+        gga[c] = s2;
+        const REAL mean = stat[c], rstd = stat[C + c];
+        for (int s = 0; s < L; s++) {
+            const REAL zh = zhat[c * L + s];
+            const REAL gzz = gam[c] * rstd * (gz[c * L + s] - s1 / (REAL)L - zh * s2 / (REAL)L);
+            const REAL z = zh / rstd + mean;                     /* ELU output before the normalisation */
+            gz[c * L + s] = gzz * (z > 0 ? 1 : z + 1);
+        }
+    }
+    for (int c = 0; c < C; c++) {                                /* fc1 backward */
+        REAL sb = 0;
+        for (int s = 0; s < L; s++) sb += gz[c * L + s];
+        gb1[c] = sb;
+        for (int i = 0; i < 2; i++)
+            for (int k = 0; k < k1; k++) {
+                REAL sw = 0;
+                for (int s = 0; s < L; s++) {
+                    const int sx = s + k - p1;
+                    if (sx >= 0 && sx < L) sw += gz[c * L + s] * x[i * L + sx];
+                }
+                gw1[(c * 2 + i) * k1 + k] = sw;
+            }
+    }
+    free(buf);
+    return loss;
+}
+
+void FN(vaeq_oracle_nnbn_train)(int n_steps, int B, int sps, int M, int n, int k1, int k2, int S, const REAL *rx, REAL *theta, REAL *bn,
+                                REAL *am, REAL *av, REAL *avmax, int *step, const REAL *amp, double lr, REAL *loss)
+{
+    const int C = 2 * n, L = B * sps, np_ = NNBN_NP(C, k1, k2, M);
+    REAL *mb = (REAL *)malloc(sizeof(REAL) * ((size_t)2 * L + C * B + np_));
+    REAL *q = mb + 2 * L, *g = q + C * B;
+    for (int s = 0; s < n_steps; s++) {
+        for (int r = 0; r < 2; r++) memcpy(mb + r * L, rx + (size_t)r * S + (size_t)s * L, sizeof(REAL) * L);
+        loss[s] = FN(vaeq_oracle_nnbn_step_grads)(B, sps, M, n, k1, k2, mb, theta, bn, amp, q, g);
+        *step += 1;
+        FN(vaeq_oracle_adam)(np_, theta, g, am, av, avmax, *step, lr, 1);
+    }
+    free(mb);
+}
+
+/* eval-mode forward (net.eval(): running statistics) */
+void FN(vaeq_oracle_nnbn_forward_eval)(int B, int sps, int n, int k1, int k2, const REAL *x, const REAL *theta, const REAL *bn, REAL *q)
+{
+    const int C = 2 * n, L = B * sps;
+    REAL *buf = (REAL *)malloc(sizeof(REAL) * ((size_t)2 * C * L + 2 * C + C * B));
+    REAL bnc[2 * 2 * MAXLEV];
+    for (int i = 0; i < 2 * C; i++) bnc[i] = bn[i];
+    FN(vaeq_oracle_nnbn_forward)(B, sps, n, k1, k2, 0, x, theta, bnc, buf, buf + 2 * C * L, buf + C * L, buf + 2 * C * L + 2 * C, q);
+    free(buf);
+}
+#undef NNBN_NP
 #undef NN_NP
 
 #undef FN

@@ -228,3 +228,35 @@ def test_vaenn_free_run(name):
     ok = np.abs(g["g0"]) > 1e-4 * np.abs(g["g0"]).max()
     assert np.max(np.abs(st3.theta - g["theta1"])[ok]) < 2e-6
     assert np.max(np.abs(st3.theta - g["theta1"])) < 2.01 * float(g["lr"])
+
+
+# ------------------------------------------------------------------ row f3, BatchNorm variant Net_BN (G11)
+G11 = ["G11_vaennbn_64qam", "G11_vaennbn_16qam_small"]
+
+
+@pytest.mark.parametrize("name", G11)
+def test_vaennbn_step_and_running_statistics(name):
+    """Net_BN: training-mode forward (batch statistics), all gradients incl. BatchNorm's gamma / beta, the running statistics after the
+    step, the free run and the eval-mode forward on the running statistics."""
+    g = load_golden(name)
+    B, sps, k1, k2, M, ns = int(g["B"]), int(g["sps"]), int(g["k1"]), int(g["k2"]), int(g["M_est"]), int(g["n_steps"])
+    n = len(g["amp_levels"])
+    x = g["rx"][:, :B * sps]
+    for dt in (np.float32, np.float64):
+        r = oracle.nnbn_step_grads(x, g["theta0"], g["bn0"], g["amp_levels"], k1, k2, M, sps, dt)
+        assert np.max(np.abs(r["q"] - g["q0"])) < 5e-6
+        assert abs(r["loss"] - g["loss"][0]) / abs(g["loss"][0]) < 2e-6
+        assert relerr(r["bn"], g["bn1"]) < 2e-6
+        C_ = 2 * n
+        o = np.cumsum([0, C_ * 2 * k1, C_, C_ * C_ * k2, C_, C_, C_, 2 * M])
+        for a, b in zip(o[:-1], o[1:]):
+            assert relerr(r["g"][a:b], g["g0"][a:b]) < 3e-4, (a, b)
+    st = oracle.NNBNState(g["theta0"], n, np.float32)
+    loss = oracle.nnbn_train(st, g["rx"], ns, B, g["amp_levels"], k1, k2, M, float(g["lr"]), sps, np.float32)
+    assert np.max(np.abs(loss[:2] - g["loss"][:2]) / np.abs(g["loss"][:2])) < 2e-5
+    assert np.max(np.abs(loss - g["loss"]) / np.abs(g["loss"])) < 2e-3
+    assert relerr(st.bn, g[f"bn{ns}"]) < 1e-3
+    assert np.max(np.abs(st.theta - g[f"theta{ns}"])) < 2 * ns * float(g["lr"])
+    Ne = B * min(ns, 3)
+    qe = oracle.nnbn_forward_eval(g["rx"][:, :Ne * sps], g[f"theta{ns}"], g[f"bn{ns}"], n, k1, k2, sps, np.float64)
+    assert np.max(np.abs(qe - g["q_eval"])) < 5e-6

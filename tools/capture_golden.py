@@ -557,6 +557,79 @@ def capture_G10(sfun, awgn):
          N_frame_max=np.int64(3000), num_frames=np.int64(200), theta_diff=np.float64(0.006 * np.pi), nu=np.float64(NU_572))
 
 
+def _nnbn_case(mod, SNR, M_est, k1, k2, B, seed, n_steps, lr=4e-3, channel="h1"):
+    """Net_BN (NN:190-211) teacher-forced + free run, incl. the BatchNorm running statistics and an eval-mode forward."""
+    import func_VAENN_MQAM as nnref  # reference module
+
+    sps = 2
+    torch.manual_seed(seed)
+    ir = np.array({"h1": [0.0545 + 0.05j, 0.2823 - 0.11971j, -0.7676 + 0.2788j, -0.0641 - 0.0576j, 0.0466 - 0.02275j]}[channel]).astype(np.complex64)
+    h_channel = np.zeros(sps * (len(ir) - 1) + 1, dtype=np.complex64)
+    h_channel[0::sps] = ir
+    h_channel /= np.linalg.norm(h_channel)
+    nlev = {"4-QAM": 2, "16-QAM": 4, "64-QAM": 8}[mod]
+    ask = np.arange(-(nlev - 1), nlev, 2).astype(np.float64)
+    constellation = (ask[:, None] + 1j * ask[None, :]).reshape(-1)
+    constellation = constellation / np.sqrt(np.mean(np.abs(constellation) ** 2))
+    amp_levels = torch.tensor(constellation.real[::nlev], dtype=torch.float32)
+    with SeededRng(seed):
+        rx, data = nnref.generate_data(B * n_steps, len(ir), constellation, SNR, h_channel, sps, "cpu")
+    net = nnref.Net_BN(k1, k2, nlev, sps)
+    net.train()
+    h_est = np.zeros([2, M_est])
+    h_est[0, M_est // 2] = 1
+    h_est = torch.tensor(h_est, requires_grad=True, dtype=torch.float32)
+    opt = torch.optim.Adam(net.parameters(), lr=lr, amsgrad=True)
+    opt.add_param_group({"params": h_est})
+    params = [net.fc1.weight, net.fc1.bias, net.fc2.weight, net.fc2.bias, net.batch1.weight, net.batch1.bias, h_est]
+    assert [id(p_) for p_ in net.parameters()] == [id(p_) for p_ in params[:-1]]          # the flat order used by the kernels
+    flat = lambda ts: np.concatenate([t2n(t).reshape(-1) for t in ts])
+    bnstat = lambda: np.concatenate([t2n(net.batch1.running_mean), t2n(net.batch1.running_var)])
+    res = dict(rx=t2n(rx), theta0=flat(params), bn0=bnstat(), amp_levels=t2n(amp_levels), lr=np.float64(lr), B=np.int64(B), M_est=np.int64(M_est),
+               k1=np.int64(k1), k2=np.int64(k2), sps=np.int64(sps), n_steps=np.int64(n_steps), mod=np.array(mod), SNR=np.float64(SNR))
+    losses = np.zeros(n_steps, dtype=np.float32)
+    mb = torch.empty(1, 2, B * sps)
+    for s in range(n_steps):
+        mb[0] = rx[:, s * B * sps:(s + 1) * B * sps]
+        opt.zero_grad()
+        q = net(mb)
+        loss = nnref.loss_function(q.squeeze(), mb.squeeze(), h_est, "cpu", amp_levels)
+        loss.backward()
+        losses[s] = loss.item()
+        if s < 2:
+            res[f"q{s}"], res[f"g{s}"], res[f"bn{s + 1}"] = t2n(q[0]), flat([p_.grad for p_ in params]), bnstat()
+        opt.step()
+        if s < 2 or s + 1 == n_steps:
+            res[f"theta{s + 1}"] = flat(params)
+    res["loss"], res[f"bn{n_steps}"] = losses, bnstat()
+    net.eval()
+    with torch.no_grad():
+        mb2 = rx[None, :, :B * sps * min(n_steps, 3)]
+        res["q_eval"] = t2n(net(mb2)[0])                                        # running statistics
+    res["vmax"] = flat([opt.state[p_]["max_exp_avg_sq"] for p_ in params])
+    return res
+
+
+def capture_G11(sfun, awgn):
+    import contextlib
+    import io
+    import func_VAENN_MQAM as nnref  # reference module
+
+    save("G11_vaennbn_64qam", **_nnbn_case("64-QAM", 24, 25, 25, 3, 300, seed=111, n_steps=6))
+    save("G11_vaennbn_16qam_small", **_nnbn_case("16-QAM", 20, 9, 11, 3, 60, seed=112, n_steps=3, lr=2e-3))
+    torch.manual_seed(114)
+    net0 = nnref.Net_BN(25, 3, 4, 2)
+    h0 = np.zeros([2, 25])
+    h0[0, 12] = 1
+    theta0 = np.concatenate([t2n(p_).reshape(-1) for p_ in net0.parameters()] + [h0.reshape(-1)])
+    t0 = time.time()
+    torch.manual_seed(114)
+    with SeededRng(114), contextlib.redirect_stdout(io.StringIO()):
+        SER = nnref.processing("16-QAM", 2, 20, 25, 25, 3, 4e-3, 300, 5000, 1200, 120, 2, "h1", "Net_BN")
+    print(f"   G11 run: {time.time() - t0:.0f}s  SER {np.round(t2n(SER), 4).tolist()}")
+    save("G11_vaennbn_run", SER=t2n(SER), theta0=theta0.astype(np.float32), seed=np.int64(114), seconds=np.float64(time.time() - t0))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -565,7 +638,7 @@ def main():
     torch.set_num_threads(1)
     os.makedirs(OUT, exist_ok=True)
     sfun, awgn = _import_reference()
-    todo = [s for s in args.only.split(",") if s] or ["G0", "G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10"]
+    todo = [s for s in args.only.split(",") if s] or ["G0", "G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11"]
     for g in todo:
         print(f"[{g}]")
         if g == "G7":
