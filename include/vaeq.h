@@ -245,7 +245,9 @@ int vaeq_gen_dp_frame(int32_t R, int32_t N, int32_t N_conv, int32_t sps, int32_t
  * Conv1d(C, C, k2, pad k2/2, stride sps) -> per-axis softmax, C = 2 n_lev; loss_function (:63-95); Adam(amsgrad=True) on all
  * parameters (:248-253).  One run's parameters are ONE flat vector in the order of net.parameters() followed by h_est:
  *   theta = [fc1.weight C*2*k1 | fc1.bias C | fc2.weight C*C*k2 | fc2.bias C | h_est 2*M],  vaeq_nn_param_count() floats;
- * the Adam vectors (m, v, max v) and dbg_g use the same layout.  (Net_BN, the BatchNorm variant, is not implemented.)
+ * the Adam vectors (m, v, max v) and dbg_g use the same layout.  Net_BN (:190-211, batch_norm = 1): BatchNorm1d(C) between the ELU
+ * and fc2; theta gains [batch1.weight C | batch1.bias C] in front of h_est, and bn_running[R][2][C] = (running_mean, running_var)
+ * is caller-owned state updated by every training step (momentum 0.1) and read by the eval-mode entry points.
  * vaeq_nn_train replaces the minibatch loop (:274-285) for R runs: step s uses symbols [s*B, (s+1)*B) of rx[R][2][S]. */
 typedef struct vaeq_nn_args {
     int32_t R, steps, B, sps, M, n_lev, k1, k2;
@@ -261,20 +263,24 @@ typedef struct vaeq_nn_args {
     float *loss;         /* nullable [R][steps] */
     float *q_out;        /* nullable [R][2*n_lev][steps*B] */
     float *dbg_g;        /* nullable [R][NP]: gradient of the LAST step */
-    int32_t no_update;   /* 1: skip the Adam update */
+    int32_t no_update;   /* 1: skip the Adam update (and the running-statistics update) */
+    int32_t batch_norm;  /* 0: Net, 1: Net_BN */
+    float *bn_running;   /* Net_BN: [R][2][C] in/out */
 } vaeq_nn_args;
 
 int vaeq_nn_train(const vaeq_nn_args *args, void *stream);
-int64_t vaeq_nn_param_count(int32_t M, int32_t n_lev, int32_t k1, int32_t k2);
-int64_t vaeq_nn_lds_bytes(int32_t B, int32_t sps, int32_t M, int32_t n_lev, int32_t k1, int32_t k2);
-/* Net.forward in eval mode on N symbols per run (:293-295): x[R][2][N*sps], theta[R][NP] -> q[R][2*n_lev][N]. */
+int64_t vaeq_nn_param_count(int32_t M, int32_t n_lev, int32_t k1, int32_t k2, int32_t batch_norm);
+int64_t vaeq_nn_lds_bytes(int32_t B, int32_t sps, int32_t M, int32_t n_lev, int32_t k1, int32_t k2, int32_t batch_norm);
+/* Net.forward in eval mode on N symbols per run (:293-295): x[R][2][N*sps], theta[R][NP] -> q[R][2*n_lev][N].
+ * bn_running: NULL for Net; [R][2][C] for Net_BN (net.eval(): the running statistics normalise). */
 int vaeq_nn_forward(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, int32_t k1, int32_t k2, const float *x,
-                    const float *theta, float *q, void *stream);
+                    const float *theta, const float *bn_running, float *q, void *stream);
 
 /* The whole VAE-NN validation block (:287-301: eval forward, find_shift :147-166, SER_q :97-123) in one call, q not materialised:
  * x[R][2][N*sps], theta[R][NP], data_f16[R][2][N] -> ser[R], shift[R] (nullable). */
 int vaeq_nn_validate(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, int32_t k1, int32_t k2, int32_t n_shift, const float *x,
-                     const float *theta, const float *amp, const void *data_f16, float *ser, int32_t *shift, void *stream);
+                     const float *theta, const float *bn_running, const float *amp, const void *data_f16, float *ser, int32_t *shift,
+                     void *stream);
 
 /* Single-polarisation AWGN / ISI channel of AWGN_channel/func_VAELE_MQAM_shaping.py:39-61 (generate_data) for R runs, same three
  * stages without the dispersion step: g[Lg] = rrc * h_channel; scratch: power_ws [R][ceil(Ls / 2048)] floats, and sig_ws [R][Ls]

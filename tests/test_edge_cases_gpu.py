@@ -119,10 +119,12 @@ def test_nn_entry_points_reject_bad_arguments_and_accept_empty_batches():
     from vae_equalizer_amd import _native as nat
     from vae_equalizer_amd.engine import NNEngine
     L = nat.lib()
-    assert L.vaeq_nn_param_count(25, 8, 25, 3) == 16 * 2 * 25 + 16 + 16 * 16 * 3 + 16 + 50
-    assert L.vaeq_nn_param_count(24, 8, 25, 3) == ERR_SHAPE and L.vaeq_nn_param_count(25, 8, 24, 3) == ERR_SHAPE
-    assert L.vaeq_nn_param_count(25, 3, 25, 3) == ERR_SHAPE and L.vaeq_nn_param_count(25, 8, 25, 11) == ERR_SHAPE
-    assert L.vaeq_nn_lds_bytes(300, 2, 25, 8, 25, 3) > 0 and L.vaeq_nn_lds_bytes(20, 2, 25, 8, 25, 3) == ERR_SHAPE      # B <= 2 (M // 2)
+    assert L.vaeq_nn_param_count(25, 8, 25, 3, 0) == 16 * 2 * 25 + 16 + 16 * 16 * 3 + 16 + 50
+    assert L.vaeq_nn_param_count(25, 8, 25, 3, 1) == 16 * 2 * 25 + 16 + 16 * 16 * 3 + 16 + 32 + 50                     # + BatchNorm weight, bias
+    assert L.vaeq_nn_param_count(24, 8, 25, 3, 0) == ERR_SHAPE and L.vaeq_nn_param_count(25, 8, 24, 3, 0) == ERR_SHAPE
+    assert L.vaeq_nn_param_count(25, 3, 25, 3, 0) == ERR_SHAPE and L.vaeq_nn_param_count(25, 8, 25, 11, 0) == ERR_SHAPE
+    assert L.vaeq_nn_lds_bytes(300, 2, 25, 8, 25, 3, 0) > 0 and L.vaeq_nn_lds_bytes(20, 2, 25, 8, 25, 3, 0) == ERR_SHAPE  # B <= 2 (M // 2)
+    assert L.vaeq_nn_lds_bytes(300, 2, 25, 8, 25, 3, 1) > L.vaeq_nn_lds_bytes(300, 2, 25, 8, 25, 3, 0)
     p = C.c_void_p(torch.zeros(4096, device=DEV).data_ptr())
     i32 = C.c_void_p(torch.zeros(4, dtype=torch.int32, device=DEV).data_ptr())
     base = dict(R=1, steps=1, B=60, sps=2, M=9, n_lev=4, k1=11, k2=3, S=120, rx=p, theta=p, adam_m=p, adam_v=p, adam_x=p, step=i32, amp=p, lr=p,
@@ -133,9 +135,10 @@ def test_nn_entry_points_reject_bad_arguments_and_accept_empty_batches():
     assert call(S=119) == ERR_SHAPE and call(k1=10) == ERR_SHAPE and call(n_lev=5) == ERR_SHAPE and call(steps=0) == ERR_SHAPE
     assert call(B=3000, S=6000) == ERR_LDS                                       # 16 x 6000 floats of hidden activations do not fit
     assert call(R=0, rx=None, theta=None) == OK
-    assert L.vaeq_nn_validate(1, 32, 2, 9, 4, 11, 3, 21, p, p, p, p, p, i32, None) == ERR_SHAPE                       # N < 64
-    assert L.vaeq_nn_validate(1, 1000, 2, 9, 4, 11, 3, 21, p, None, p, p, p, i32, None) == ERR_NULL
-    assert L.vaeq_nn_forward(0, 1000, 2, 9, 4, 11, 3, None, None, None, None) == OK
+    assert call(batch_norm=1) == ERR_NULL and call(batch_norm=1, bn_running=p) == OK   # Net_BN needs its running statistics
+    assert L.vaeq_nn_validate(1, 32, 2, 9, 4, 11, 3, 21, p, p, None, p, p, p, i32, None) == ERR_SHAPE                 # N < 64
+    assert L.vaeq_nn_validate(1, 1000, 2, 9, 4, 11, 3, 21, p, None, None, p, p, p, i32, None) == ERR_NULL
+    assert L.vaeq_nn_forward(0, 1000, 2, 9, 4, 11, 3, None, None, None, None, None) == OK
     assert L.vaeq_awgn_loss(1, 60, 2, 9, 4, p, p, p, p, None, p, None) == OK and L.vaeq_awgn_loss(1, 8, 2, 9, 4, p, p, p, p, None, p, None) == ERR_SHAPE
     eng = NNEngine(0, 9, 11, 3, _amp(4), DEV)
     assert eng.train(torch.zeros(0, 2, 240, device=DEV), 60, 2, 1e-3)["loss"].shape == (0, 2)

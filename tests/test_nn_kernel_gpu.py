@@ -114,3 +114,59 @@ def test_nn_validate_matches_torch_mirror(name, N):
         assert abs(float(ser[i]) - e_ref) <= 2.0 / N, (i, float(ser[i]), e_ref)
     if N >= 1000:
         assert [int(v) for v in sh] == [0, 4, -7, 9] and float(ser.max()) < 0.06
+
+
+# ------------------------------------------------------------------ Net_BN (BatchNorm variant), G11
+G11 = ["G11_vaennbn_64qam", "G11_vaennbn_16qam_small"]
+
+
+def _bn_engine(g, R=1):
+    from vae_equalizer_amd.engine import NNEngine
+    eng = NNEngine(R, int(g["M_est"]), int(g["k1"]), int(g["k2"]), g["amp_levels"], DEV, int(g["sps"]), batch_norm=True)
+    assert eng.NP == g["theta0"].size
+    eng.theta.copy_(torch.from_numpy(g["theta0"]).to(DEV).expand(R, -1))
+    eng.bn.copy_(torch.from_numpy(g["bn0"]).to(DEV).expand(R, -1))
+    return eng
+
+
+@pytest.mark.parametrize("name", G11)
+def test_nnbn_teacher_forced_step(name):
+    """Net_BN: q with batch statistics, ELBO, the gradient of all parameters incl. BatchNorm's weight and bias, the running
+    statistics after the step, the AMSGrad update."""
+    g = load_golden(name)
+    B, sps = int(g["B"]), int(g["sps"])
+    eng = _bn_engine(g)
+    rx = torch.from_numpy(g["rx"][None, :, :B * sps]).to(DEV)
+    r = eng.train(rx, B, 1, float(g["lr"]), want_q=True, debug_grads=True)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(_np(r["q"])[0] - g["q0"])) < 1e-5
+    assert abs(_np(r["loss"])[0, 0] - g["loss"][0]) / abs(g["loss"][0]) < 1e-5
+    assert relerr(_np(eng.bn)[0], g["bn1"]) < 5e-6
+    o = eng.offsets()
+    assert len(o) == 8
+    for a, b in zip(o[:-1], o[1:]):
+        assert relerr(_np(r["g"])[0, a:b], g["g0"][a:b]) < 3e-4, (a, b)
+    ok = np.abs(g["g0"]) > 1e-4 * np.abs(g["g0"]).max()
+    assert np.max(np.abs(_np(eng.theta)[0] - g["theta1"])[ok]) < 1e-5
+    assert np.max(np.abs(_np(eng.theta)[0] - g["theta1"])) < 2.01 * float(g["lr"])
+
+
+@pytest.mark.parametrize("name", G11)
+def test_nnbn_free_run_and_eval_forward(name):
+    g = load_golden(name)
+    B, ns, lr, sps = int(g["B"]), int(g["n_steps"]), float(g["lr"]), int(g["sps"])
+    eng = _bn_engine(g, R=2)
+    r = eng.train(torch.from_numpy(g["rx"][None]).to(DEV).expand(2, -1, -1).contiguous(), B, ns, lr)
+    torch.cuda.synchronize()
+    loss = _np(r["loss"])
+    assert np.array_equal(loss[0], loss[1])
+    assert np.max(np.abs(loss[0, :2] - g["loss"][:2]) / np.abs(g["loss"][:2])) < 2e-5
+    assert np.max(np.abs(loss[0] - g["loss"]) / np.abs(g["loss"])) < 2e-3
+    assert relerr(_np(eng.bn)[0], g[f"bn{ns}"]) < 1e-3
+    assert np.max(np.abs(_np(eng.theta)[0] - g[f"theta{ns}"])) < 2 * ns * lr
+    # eval mode (net.eval(): running statistics) with the reference's own parameters and statistics
+    eng.theta.copy_(torch.from_numpy(g[f"theta{ns}"])[None].expand(2, -1))
+    eng.bn.copy_(torch.from_numpy(g[f"bn{ns}"])[None].expand(2, -1))
+    Ne = B * min(ns, 3)
+    q = eng.forward(torch.from_numpy(g["rx"][None, :, :Ne * sps]).to(DEV).expand(2, -1, -1).contiguous())
+    assert np.max(np.abs(_np(q)[0] - g["q_eval"])) < 1e-5

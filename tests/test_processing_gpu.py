@@ -262,8 +262,22 @@ def test_vaenn_processing_vs_reference_trajectory():
     conv = lambda s: int(np.argmax(s < 0.02))
     assert abs(conv(SER) - conv(ref)) <= 8, (conv(SER), conv(ref))             # reference: validation 25
     assert abs(SER[-20:].mean() - ref[-20:].mean()) < 8e-4, (SER[-20:].mean(), ref[-20:].mean())
-    with pytest.raises(NotImplementedError):
-        processing("16-QAM", 2, 20, 25, 25, 3, 4e-3, 300, 5000, 1200, 2, 2, "h1", "Net_BN", verbose=False)
+    with pytest.raises(UnboundLocalError):
+        processing("16-QAM", 2, 20, 25, 25, 3, 4e-3, 300, 5000, 1200, 2, 2, "h1", "Net_LN", verbose=False)
+
+
+def test_vaennbn_processing_vs_reference_trajectory():
+    """Net_BN through processing(): the frames and the initial network the reference saw under seed 114 (120 epochs)."""
+    from vae_equalizer_amd.func_VAENN_MQAM import processing
+    g = load_golden("G11_vaennbn_run")
+    SER = processing("16-QAM", 2, 20, 25, 25, 3, 4e-3, 300, 5000, 1200, 120, 2, "h1", "Net_BN", seed=int(g["seed"]), theta0=g["theta0"],
+                     generator="numpy", verbose=False).numpy()
+    ref = g["SER"]
+    assert SER.shape == ref.shape == (60,)
+    assert np.max(np.abs(SER[:5] - ref[:5])) < 0.03
+    conv = lambda s: int(np.argmax(s < 0.02))
+    assert abs(conv(SER) - conv(ref)) <= 10, (conv(SER), conv(ref))            # reference: validation 37
+    assert abs(SER[-15:].mean() - ref[-15:].mean()) < 8e-4, (SER[-15:].mean(), ref[-15:].mean())
 
 
 def test_vaenn_device_pipeline_monte_carlo():

@@ -8,7 +8,7 @@ import torch
 
 mod = '64-QAM'          # Modulation Format: {4,16,64}-QAM
 sps = 2                 # samples per symbol
-net_type_vec = ['Net']  # topology ('Net_BN' is not implemented)
+net_type_vec = ['Net']  # ['Net_BN'] # topology
 channel = 'h1'          # 'h2'
 M_vec = [25]            # taps of the estimated channel impulse response
 k1_vec, k2_vec = [25], [3]  # kernel size (of layer1, layer2)
@@ -44,8 +44,6 @@ def main():
         print('Run code on: ', device, f'({world} rank(s))')
     name = save_dict = None
     for net_type in net_type_vec:
-        if net_type != 'Net':
-            raise NotImplementedError(net_type)
         points = list(sweep_points())
         mine = sweep.my_slice(len(points), rank, world)
         local = torch.zeros(len(mine), num_epochs // epe, dtype=torch.float32)
@@ -56,7 +54,7 @@ def main():
                          seed=None if base_seed is None else base_seed + 1000 * mine[k]) for k in sel]
             M, k1, k2, batch_len = shape
             local[sel] = run_vaenn_batch(runs, mod, sps, M, k1, k2, batch_len, N_valid, train_len, num_epochs, epe, channel, device=device,
-                                         generator=generator, seed=(base_seed or 0) + 7919 * rank)
+                                         generator=generator, seed=(base_seed or 0) + 7919 * rank, net_type=net_type)
         rows = sweep.gather_rows(local, len(points), rank, world)
         if rank != 0:
             continue

@@ -78,7 +78,7 @@ class NNArgs(C.Structure):
         ("k1", C.c_int32), ("k2", C.c_int32), ("S", C.c_int64),
         ("rx", C.c_void_p), ("theta", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("adam_x", C.c_void_p),
         ("step", C.c_void_p), ("amp", C.c_void_p), ("lr", C.c_void_p), ("loss", C.c_void_p), ("q_out", C.c_void_p), ("dbg_g", C.c_void_p),
-        ("no_update", C.c_int32),
+        ("no_update", C.c_int32), ("batch_norm", C.c_int32), ("bn_running", C.c_void_p),
     ]
 
 
@@ -136,15 +136,15 @@ def lib():
         L.vaeq_nn_train.restype = C.c_int
         L.vaeq_nn_train.argtypes = [C.POINTER(NNArgs), C.c_void_p]
         L.vaeq_nn_param_count.restype = C.c_int64
-        L.vaeq_nn_param_count.argtypes = [C.c_int32] * 4
+        L.vaeq_nn_param_count.argtypes = [C.c_int32] * 5
         L.vaeq_nn_lds_bytes.restype = C.c_int64
-        L.vaeq_nn_lds_bytes.argtypes = [C.c_int32] * 6
+        L.vaeq_nn_lds_bytes.argtypes = [C.c_int32] * 7
         L.vaeq_nn_forward.restype = C.c_int
-        L.vaeq_nn_forward.argtypes = [C.c_int32, C.c_int64] + [C.c_int32] * 5 + [C.c_void_p] * 4
+        L.vaeq_nn_forward.argtypes = [C.c_int32, C.c_int64] + [C.c_int32] * 5 + [C.c_void_p] * 5
         L.vaeq_awgn_loss.restype = C.c_int
         L.vaeq_awgn_loss.argtypes = [C.c_int32] * 5 + [C.c_void_p] * 7
         L.vaeq_nn_validate.restype = C.c_int
-        L.vaeq_nn_validate.argtypes = [C.c_int32, C.c_int64] + [C.c_int32] * 6 + [C.c_void_p] * 7
+        L.vaeq_nn_validate.argtypes = [C.c_int32, C.c_int64] + [C.c_int32] * 6 + [C.c_void_p] * 8
         L.vaeq_gen_dp_frame.restype = C.c_int
         L.vaeq_gen_dp_frame.argtypes = ([C.c_int32] * 9 + [C.c_void_p] * 5 + [C.c_double] * 3 + [C.c_float] * 4 + [C.c_uint64, C.c_uint32]
                                         + [C.c_void_p] * 6)

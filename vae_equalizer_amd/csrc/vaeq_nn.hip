@@ -26,13 +26,13 @@
 namespace vaeq {
 
 struct NNLayout {
-    int C, L, p1, p2, Lx, Lz, mh, Mh, nm, NP, NW1, oW1, oB1, oW2, oB2, oH;
-    int xs, z1, a2, mu, vr, es, VS, th, gr, am, av, ax, w1t, w2t, w2u, red, total;
+    int C, L, p1, p2, Lx, Lz, mh, Mh, nm, NP, NW1, oW1, oB1, oW2, oB2, oG, oBt, oH;
+    int xs, z1, zb, bnst, a2, mu, vr, es, VS, th, gr, am, av, ax, w1t, w2t, w2u, red, total;
 };
 
 __host__ __device__ inline int npad4(int x) { return (x + 3) & ~3; }
 
-__host__ __device__ inline NNLayout nn_layout(int B, int sps, int M, int n, int k1, int k2)
+__host__ __device__ inline NNLayout nn_layout(int B, int sps, int M, int n, int k1, int k2, bool bn = false)
 {
     NNLayout l;
     l.C = 2 * n; l.L = B * sps; l.p1 = k1 / 2; l.p2 = k2 / 2;
@@ -40,11 +40,15 @@ __host__ __device__ inline NNLayout nn_layout(int B, int sps, int M, int n, int 
     l.Lz = npad4(l.L + 2 * l.p2 + 4);
     l.mh = M / 2; l.Mh = 2 * l.mh; l.nm = l.L - l.Mh;
     l.NW1 = l.C * 2 * k1;
-    l.oW1 = 0; l.oB1 = l.NW1; l.oW2 = l.oB1 + l.C; l.oB2 = l.oW2 + l.C * l.C * k2; l.oH = l.oB2 + l.C; l.NP = l.oH + 2 * M;
+    l.oW1 = 0; l.oB1 = l.NW1; l.oW2 = l.oB1 + l.C; l.oB2 = l.oW2 + l.C * l.C * k2;
+    l.oG = l.oB2 + l.C; l.oBt = l.oG + l.C;            // BatchNorm weight / bias (Net_BN only)
+    l.oH = bn ? l.oBt + l.C : l.oG; l.NP = l.oH + 2 * M;
     int o = 0;
     auto take = [&](int cnt) { int r = o; o += npad4(cnt); return r; };
     l.xs = take(2 * l.Lx);
     l.z1 = take(l.C * l.Lz);
+    l.zb = bn ? take(l.C * l.Lz) : l.z1;               // Net_BN: BatchNorm output (fc2's input); z1 then holds the normalised zhat
+    l.bnst = take(bn ? 6 * l.C : 0);                   // mean, rstd (batch) | running_mean, running_var | eval scale, shift
     l.a2 = take(l.C * B);
     l.mu = take(2 * B); l.vr = take(2 * B);
     l.es = take(2 * l.nm);
@@ -153,7 +157,7 @@ __device__ __forceinline__ void nn_transpose_weights(const NNLayout &l, int k1, 
 // channels' weights of a tap come from one 16-byte broadcast read.
 template <int NT, int NLEV>
 __device__ __forceinline__ void nn_fc1_elu(const NNLayout &l, int k1, const float *xs, const float *th, const float *w1t, float *z1, int Lvalid,
-                                           int zlo, int zhi)
+                                           int zlo, int zhi, const float *aff = nullptr)
 {
     // z1p[c][p2 + s] for s in [0, Lvalid); entries whose absolute position (zlo + s) lies outside [0, zhi) are fc2's zero padding
     constexpr int C = 2 * NLEV, CQ = C / 4;
@@ -184,7 +188,8 @@ __device__ __forceinline__ void nn_fc1_elu(const NNLayout &l, int k1, const floa
             const bool in = pos >= 0 && pos < zhi;
 #pragma unroll
             for (int t = 0; t < 4; t++) {
-                const float z = av[u][t] > 0.f ? av[u][t] : __expf(av[u][t]) - 1.0f;     // F.elu, alpha = 1 (:177)
+                float z = av[u][t] > 0.f ? av[u][t] : __expf(av[u][t]) - 1.0f;           // F.elu, alpha = 1 (:177)
+                if (aff) z = fmaf(aff[4 * cq + t], z, aff[C + 4 * cq + t]);              // eval-mode BatchNorm: running statistics folded
                 z1[(4 * cq + t) * l.Lz + l.p2 + sy] = in ? z : 0.f;
             }
         }
@@ -222,7 +227,7 @@ __device__ __forceinline__ void nn_fc2(const NNLayout &l, int sps, int k2, int B
     }
 }
 
-template <int NT, int NLEV>
+template <int NT, int NLEV, bool BN>
 __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
 {
     extern __shared__ float4 smem4[];
@@ -230,8 +235,9 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
     constexpr int C = 2 * NLEV;
     const int tid = threadIdx.x, run = blockIdx.x;
     const int B = a.B, sps = a.sps, M = a.M, k1 = a.k1, k2 = a.k2;
-    const NNLayout l = nn_layout(B, sps, M, NLEV, k1, k2);
+    const NNLayout l = nn_layout(B, sps, M, NLEV, k1, k2, BN);
     const int L = l.L, p1 = l.p1, p2 = l.p2, Lx = l.Lx, Lz = l.Lz, mh = l.mh, Mh = l.Mh, nm = l.nm, NP = l.NP;
+    float *zb = sm + l.zb, *bnst = sm + l.bnst;                // BN ? separate buffers : zb aliases z1
     float *xs = sm + l.xs, *z1 = sm + l.z1, *a2 = sm + l.a2, *mu = sm + l.mu, *vr = sm + l.vr, *es = sm + l.es, *VS = sm + l.VS;
     float *th = sm + l.th, *gr = sm + l.gr, *am = sm + l.am, *av = sm + l.av, *ax = sm + l.ax, *w1t = sm + l.w1t, *w2t = sm + l.w2t, *red = sm + l.red;
     float *w2u = sm + l.w2u;
@@ -247,6 +253,10 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
     }
     for (int i = tid; i < 2 * Lx; i += NT) xs[i] = 0.f;        // halos stay zero
     for (int i = tid; i < C * Lz; i += NT) z1[i] = 0.f;
+    if (BN) {
+        for (int i = tid; i < C * Lz; i += NT) zb[i] = 0.f;
+        for (int i = tid; i < 2 * C; i += NT) bnst[2 * C + i] = a.bn_running[(size_t)run * 2 * C + i];
+    }
     int step = a.step[run];
     double b1t = pow(0.9, (double)step), b2t = pow(0.999, (double)step);
     __syncthreads();
@@ -269,7 +279,32 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
         // ---- P1/P2: fc1 + ELU, fc2
         nn_fc1_elu<NT, NLEV>(l, k1, xs, th, w1t, z1, L, 0, L);
         __syncthreads();
-        nn_fc2<NT, NLEV>(l, sps, k2, B, B, z1, th, w2t, a2);
+        if (BN) {                                              // BatchNorm1d in training mode (:203): batch statistics over the L samples
+            for (int c = wv; c < C; c += NWV) {
+                float *zr = z1 + c * Lz + p2;
+                float sm_ = 0.f;
+                for (int sx = lane; sx < L; sx += 64) sm_ += zr[sx];
+                const float mean = wave_sum(sm_) / (float)L;
+                float sv = 0.f;
+                for (int sx = lane; sx < L; sx += 64) { const float d = zr[sx] - mean; sv = fmaf(d, d, sv); }
+                const float var = wave_sum(sv) / (float)L, rstd = 1.0f / sqrtf(var + 1e-5f);
+                if (lane == 0) {
+                    bnst[c] = mean; bnst[C + c] = rstd;
+                    if (!a.no_update) {                        // running statistics: momentum 0.1, unbiased variance
+                        bnst[2 * C + c] = 0.9f * bnst[2 * C + c] + 0.1f * mean;
+                        bnst[3 * C + c] = 0.9f * bnst[3 * C + c] + 0.1f * (var * (float)L / (float)(L - 1));
+                    }
+                }
+                const float ga = th[l.oG + c], be = th[l.oBt + c];
+                for (int sx = lane; sx < L; sx += 64) {
+                    const float zh = (zr[sx] - mean) * rstd;
+                    zr[sx] = zh;                               // z1 keeps zhat for the backward pass
+                    zb[c * Lz + p2 + sx] = fmaf(ga, zh, be);
+                }
+            }
+            __syncthreads();
+        }
+        nn_fc2<NT, NLEV>(l, sps, k2, B, B, zb, th, w2t, a2);
         __syncthreads();
         // ---- P3: per-axis softmax -> q (in place), moments, entropy term; item = (axis, n)
         float klsum = 0.f;
@@ -377,7 +412,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
             for (int grp = wv; grp <= ngrp; grp += NWV) {
                 const bool bias = grp == ngrp;
                 const int cc = bias ? 0 : grp / nkq, k0 = bias ? 0 : (grp - cc * nkq) * 4;
-                nn_tapgroup_grad<C>(B, z1 + cc * Lz + k0, sps, a2, B, bias, lane, [&](int t, int c, float sum) {
+                nn_tapgroup_grad<C>(B, zb + cc * Lz + k0, sps, a2, B, bias, lane, [&](int t, int c, float sum) {
                     if (bias) { if (t == 0) gr[l.oB2 + c] = sum; }
                     else if (k0 + t < k2) gr[l.oW2 + (c * C + cc) * k2 + k0 + t] = sum;
                 });
@@ -406,11 +441,33 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int ix = (4 * ccq + u) * Lz + p2 + sx;
-                const float z = z1[ix];
-                z1[ix] = gg[u] * (z > 0.f ? 1.0f : z + 1.0f);                             // ELU' = 1 or exp(a1) = z1 + 1
+                if (BN) zb[ix] = gg[u];                                                   // dL/d(BatchNorm output); zb's values are spent
+                else {
+                    const float z = z1[ix];
+                    z1[ix] = gg[u] * (z > 0.f ? 1.0f : z + 1.0f);                         // ELU' = 1 or exp(a1) = z1 + 1
+                }
             }
         }
         __syncthreads();
+        if (BN) {                                              // BatchNorm backward (batch statistics), then ELU'
+            for (int c = wv; c < C; c += NWV) {
+                float *zr = z1 + c * Lz + p2;
+                const float *gp = zb + c * Lz + p2;
+                float s1 = 0.f, s2 = 0.f;
+                for (int sx = lane; sx < L; sx += 64) { s1 += gp[sx]; s2 = fmaf(gp[sx], zr[sx], s2); }
+                s1 = wave_sum(s1);
+                s2 = wave_sum(s2);
+                if (lane == 0) { gr[l.oG + c] = s2; gr[l.oBt + c] = s1; }
+                const float mean = bnst[c], rstd = bnst[C + c], gs = th[l.oG + c] * rstd, m1 = s1 / (float)L, m2 = s2 / (float)L;
+                for (int sx = lane; sx < L; sx += 64) {
+                    const float zh = zr[sx];
+                    const float gz = gs * (gp[sx] - m1 - zh * m2);
+                    const float z = zh / rstd + mean;          // ELU output before the normalisation
+                    zr[sx] = gz * (z > 0.f ? 1.0f : z + 1.0f);
+                }
+            }
+            __syncthreads();
+        }
         // ---- P8: fc1 weight / bias gradients, same scheme: one wave per (input row, group of 4 taps)
         {
             const int nkq = (k1 + 3) / 4, ngrp = 2 * nkq;
@@ -443,6 +500,8 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
         if (a.dbg_g) a.dbg_g[g] = gr[i];
     }
     if (tid == 0 && !a.no_update) a.step[run] = step;
+    if (BN && !a.no_update)
+        for (int i = tid; i < 2 * C; i += NT) a.bn_running[(size_t)run * 2 * C + i] = bnst[2 * C + i];
 }
 
 // ---- eval-mode forward over N symbols in tiles (validation, :293-301): q[R][C][N]
@@ -450,7 +509,8 @@ constexpr int NN_TILE = 256;                           // symbols per tile
 
 template <int NT, int NLEV>
 __device__ __forceinline__ void nn_forward_tile(const NNLayout &l, int sps, int k1, int k2, int64_t Ltot, const float *x0, const float *x1,
-                                                int n0, int Bt, float *xs, float *z1, float *a2, const float *th, const float *w1t, const float *w2t)
+                                                int n0, int Bt, float *xs, float *z1, float *a2, const float *th, const float *w1t, const float *w2t,
+                                                const float *aff = nullptr)
 {
     // tile symbols n0 .. n0+Bt-1: z1 needed at absolute positions [n0 sps - p2, (n0+Bt-1) sps + k2 - p2), x p1 beyond that on both sides
     const int tid = threadIdx.x, p1 = l.p1, p2 = l.p2;
@@ -462,7 +522,7 @@ __device__ __forceinline__ void nn_forward_tile(const NNLayout &l, int sps, int 
     }
     __syncthreads();
     // fc1 writes z1p[c][p2 + s] for s in [0, Lz_need) with absolute position zlo + s: shift the base so that p2 + s -> s
-    nn_fc1_elu<NT, NLEV>(l, k1, xs, th, w1t, z1 - p2, Lz_need, zlo, (int)Ltot);
+    nn_fc1_elu<NT, NLEV>(l, k1, xs, th, w1t, z1 - p2, Lz_need, zlo, (int)Ltot, aff);
     __syncthreads();
     nn_fc2<NT, NLEV>(l, sps, k2, Bt, NN_TILE, z1, th, w2t, a2);   // haloed index of z1[n sps + k - p2] relative to zlo is n sps + k
     __syncthreads();
@@ -470,23 +530,31 @@ __device__ __forceinline__ void nn_forward_tile(const NNLayout &l, int sps, int 
 
 template <int NT, int NLEV>
 __global__ __launch_bounds__(NT) void nn_forward_kernel(int N, int sps, int M, int k1, int k2, const float *__restrict__ x,
-                                                        const float *__restrict__ theta, float *__restrict__ q)
+                                                        const float *__restrict__ theta, const float *__restrict__ bn_running,
+                                                        float *__restrict__ q)
 {
     extern __shared__ float4 smem4[];
     float *sm = reinterpret_cast<float *>(smem4);
     constexpr int C = 2 * NLEV;
     const int tid = threadIdx.x, run = blockIdx.x;
-    const NNLayout l = nn_layout(NN_TILE, sps, M, NLEV, k1, k2);
+    const bool bn = bn_running != nullptr;
+    const NNLayout l = nn_layout(NN_TILE, sps, M, NLEV, k1, k2, bn);
     float *xs = sm + l.xs, *z1 = sm + l.z1, *a2 = sm + l.a2, *th = sm + l.th, *w1t = sm + l.w1t, *w2t = sm + l.w2t;
+    float *aff = bn ? sm + l.bnst + 4 * C : nullptr;
     for (int i = tid; i < l.NP; i += NT) th[i] = theta[(size_t)run * l.NP + i];
     __syncthreads();
+    if (bn && tid < C) {                                       // net.eval(): running statistics folded into one affine map per channel
+        const float sc = th[l.oG + tid] / sqrtf(bn_running[(size_t)run * 2 * C + C + tid] + 1e-5f);
+        aff[tid] = sc;
+        aff[C + tid] = th[l.oBt + tid] - bn_running[(size_t)run * 2 * C + tid] * sc;
+    }
     nn_transpose_weights<NT, NLEV>(l, k1, k2, th, w1t, w2t);
     __syncthreads();
     const int64_t Ltot = (int64_t)N * sps;
     const float *x0 = x + (size_t)run * 2 * Ltot, *x1 = x0 + Ltot;
     for (int n0 = 0; n0 < N; n0 += NN_TILE) {
         const int Bt = min(NN_TILE, N - n0);
-        nn_forward_tile<NT, NLEV>(l, sps, k1, k2, Ltot, x0, x1, n0, Bt, xs, z1, a2, th, w1t, w2t);
+        nn_forward_tile<NT, NLEV>(l, sps, k1, k2, Ltot, x0, x1, n0, Bt, xs, z1, a2, th, w1t, w2t, aff);
         for (int it = tid; it < 2 * Bt; it += NT) {
             const int axq = it / Bt, n = it - axq * Bt;
             float z[NLEV], zmax = -3.0e38f, ssum = 0.f;
@@ -506,8 +574,9 @@ __global__ __launch_bounds__(NT) void nn_forward_kernel(int N, int sps, int M, i
 // E_q[x_I] of the first 1000 symbols, then the common shift search + SER; q never leaves the chip.
 template <int NT, int NLEV>
 __global__ __launch_bounds__(NT) void nn_validate_kernel(int N, int sps, int M, int k1, int k2, int n_shift, const float *__restrict__ x,
-                                                         const float *__restrict__ theta, const float *__restrict__ amp_g,
-                                                         const __half *__restrict__ data, float *__restrict__ ser_out, int *__restrict__ shift_out)
+                                                         const float *__restrict__ theta, const float *__restrict__ bn_running,
+                                                         const float *__restrict__ amp_g, const __half *__restrict__ data,
+                                                         float *__restrict__ ser_out, int *__restrict__ shift_out)
 {
     extern __shared__ float4 smem4[];
     float *sm = reinterpret_cast<float *>(smem4);
@@ -515,14 +584,22 @@ __global__ __launch_bounds__(NT) void nn_validate_kernel(int N, int sps, int M, 
     __shared__ float corr[2][VAL_MAXSHIFT];
     __shared__ int sh_s;
     const int tid = threadIdx.x, run = blockIdx.x;
-    const NNLayout l = nn_layout(NN_TILE, sps, M, NLEV, k1, k2);
+    constexpr int C = 2 * NLEV;
+    const bool bn = bn_running != nullptr;
+    const NNLayout l = nn_layout(NN_TILE, sps, M, NLEV, k1, k2, bn);
     float *xs = sm + l.xs, *z1 = sm + l.z1, *a2 = sm + l.a2, *th = sm + l.th, *w1t = sm + l.w1t, *w2t = sm + l.w2t, *red = sm + l.red;
+    float *aff = bn ? sm + l.bnst + 4 * C : nullptr;
     unsigned char *decs = reinterpret_cast<unsigned char *>(sm + l.total);      // [N] after the forward working set
     float amp[NLEV];
 #pragma unroll
     for (int i = 0; i < NLEV; i++) amp[i] = amp_g[i];
     for (int i = tid; i < l.NP; i += NT) th[i] = theta[(size_t)run * l.NP + i];
     __syncthreads();
+    if (bn && tid < C) {
+        const float sc = th[l.oG + tid] / sqrtf(bn_running[(size_t)run * 2 * C + C + tid] + 1e-5f);
+        aff[tid] = sc;
+        aff[C + tid] = th[l.oBt + tid] - bn_running[(size_t)run * 2 * C + tid] * sc;
+    }
     nn_transpose_weights<NT, NLEV>(l, k1, k2, th, w1t, w2t);
     __syncthreads();
     const int64_t Ltot = (int64_t)N * sps;
@@ -530,7 +607,7 @@ __global__ __launch_bounds__(NT) void nn_validate_kernel(int N, int sps, int M, 
     const int NE = N < VAL_NE ? N : VAL_NE;
     for (int n0 = 0; n0 < N; n0 += NN_TILE) {
         const int Bt = min(NN_TILE, N - n0);
-        nn_forward_tile<NT, NLEV>(l, sps, k1, k2, Ltot, x0, x1, n0, Bt, xs, z1, a2, th, w1t, w2t);
+        nn_forward_tile<NT, NLEV>(l, sps, k1, k2, Ltot, x0, x1, n0, Bt, xs, z1, a2, th, w1t, w2t, aff);
         for (int n = tid; n < Bt; n += NT) {
             int d[2];
 #pragma unroll
@@ -562,22 +639,22 @@ __global__ __launch_bounds__(NT) void nn_validate_kernel(int N, int sps, int M, 
 }
 
 template <int NLEV>
-static int launch_nn_validate(int R, int N, int sps, int M, int k1, int k2, int n_shift, const float *x, const float *theta, const float *amp,
-                              const __half *data, float *ser, int *shift, hipStream_t st)
+static int launch_nn_validate(int R, int N, int sps, int M, int k1, int k2, int n_shift, const float *x, const float *theta, const float *bn,
+                              const float *amp, const __half *data, float *ser, int *shift, hipStream_t st)
 {
-    const size_t lds = (size_t)nn_layout(NN_TILE, sps, M, NLEV, k1, k2).total * 4 + (((size_t)N + 15) & ~(size_t)15);
+    const size_t lds = (size_t)nn_layout(NN_TILE, sps, M, NLEV, k1, k2, bn != nullptr).total * 4 + (((size_t)N + 15) & ~(size_t)15);
     if (lds > 150 * 1024) return VAEQ_ERR_LDS;
     auto k = nn_validate_kernel<512, NLEV>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VAEQ_ERR_LDS;
-    hipLaunchKernelGGL(k, dim3(R), dim3(512), lds, st, N, sps, M, k1, k2, n_shift, x, theta, amp, data, ser, shift);
+    hipLaunchKernelGGL(k, dim3(R), dim3(512), lds, st, N, sps, M, k1, k2, n_shift, x, theta, bn, amp, data, ser, shift);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
 
 template <int NLEV>
 static int launch_nn_train(const vaeq_nn_args &a, size_t lds, hipStream_t st)
 {
-    auto k = nn_train_kernel<512, NLEV>;
+    void (*k)(const vaeq_nn_args) = a.batch_norm ? nn_train_kernel<512, NLEV, true> : nn_train_kernel<512, NLEV, false>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VAEQ_ERR_LDS;
     hipLaunchKernelGGL(k, dim3(a.R), dim3(512), lds, st, a);
@@ -585,13 +662,15 @@ static int launch_nn_train(const vaeq_nn_args &a, size_t lds, hipStream_t st)
 }
 
 template <int NLEV>
-static int launch_nn_forward(int R, int N, int sps, int M, int k1, int k2, const float *x, const float *theta, float *q, hipStream_t st)
+static int launch_nn_forward(int R, int N, int sps, int M, int k1, int k2, const float *x, const float *theta, const float *bn, float *q,
+                             hipStream_t st)
 {
-    const size_t lds = (size_t)nn_layout(NN_TILE, sps, M, NLEV, k1, k2).total * 4;
+    const size_t lds = (size_t)nn_layout(NN_TILE, sps, M, NLEV, k1, k2, bn != nullptr).total * 4;
+    if (lds > 160 * 1024) return VAEQ_ERR_LDS;
     auto k = nn_forward_kernel<512, NLEV>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VAEQ_ERR_LDS;
-    hipLaunchKernelGGL(k, dim3(R), dim3(512), lds, st, N, sps, M, k1, k2, x, theta, q);
+    hipLaunchKernelGGL(k, dim3(R), dim3(512), lds, st, N, sps, M, k1, k2, x, theta, bn, q);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
 
@@ -604,16 +683,16 @@ static bool nn_shape_ok(int B, int sps, int M, int n_lev, int k1, int k2)
 
 }  // namespace vaeq
 
-extern "C" int64_t vaeq_nn_param_count(int32_t M, int32_t n_lev, int32_t k1, int32_t k2)
+extern "C" int64_t vaeq_nn_param_count(int32_t M, int32_t n_lev, int32_t k1, int32_t k2, int32_t batch_norm)
 {
     if (!vaeq::nn_shape_ok(2 * (M / 2) + 1, 1, M, n_lev, k1, k2)) return VAEQ_ERR_SHAPE;
-    return vaeq::nn_layout(64, 1, M, n_lev, k1, k2).NP;
+    return vaeq::nn_layout(64, 1, M, n_lev, k1, k2, batch_norm != 0).NP;
 }
 
-extern "C" int64_t vaeq_nn_lds_bytes(int32_t B, int32_t sps, int32_t M, int32_t n_lev, int32_t k1, int32_t k2)
+extern "C" int64_t vaeq_nn_lds_bytes(int32_t B, int32_t sps, int32_t M, int32_t n_lev, int32_t k1, int32_t k2, int32_t batch_norm)
 {
     if (!vaeq::nn_shape_ok(B, sps, M, n_lev, k1, k2)) return VAEQ_ERR_SHAPE;
-    return (int64_t)vaeq::nn_layout(B, sps, M, n_lev, k1, k2).total * 4;
+    return (int64_t)vaeq::nn_layout(B, sps, M, n_lev, k1, k2, batch_norm != 0).total * 4;
 }
 
 extern "C" int vaeq_nn_train(const vaeq_nn_args *pa, void *stream)
@@ -622,10 +701,11 @@ extern "C" int vaeq_nn_train(const vaeq_nn_args *pa, void *stream)
     const vaeq_nn_args &a = *pa;
     if (a.R == 0) return VAEQ_OK;                              // an empty batch owns no memory: its pointers may be NULL
     if (!a.rx || !a.theta || !a.adam_m || !a.adam_v || !a.adam_x || !a.step || !a.amp || !a.lr) return VAEQ_ERR_NULL;
-    const int64_t lds = vaeq_nn_lds_bytes(a.B, a.sps, a.M, a.n_lev, a.k1, a.k2);
+    if (a.batch_norm && !a.bn_running) return VAEQ_ERR_NULL;
+    const int64_t lds = vaeq_nn_lds_bytes(a.B, a.sps, a.M, a.n_lev, a.k1, a.k2, a.batch_norm);
     if (lds < 0) return (int)lds;
     if (lds > 160 * 1024) return VAEQ_ERR_LDS;
-    if (a.R < 0 || a.steps <= 0 || (int64_t)a.steps * a.B * a.sps > a.S) return VAEQ_ERR_SHAPE;
+    if (a.R < 0 || a.steps <= 0 || (int64_t)a.steps * a.B * a.sps > a.S || (a.batch_norm && (int64_t)a.B * a.sps < 2)) return VAEQ_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     switch (a.n_lev) {
     case 2: return vaeq::launch_nn_train<2>(a, (size_t)lds, st);
@@ -636,24 +716,23 @@ extern "C" int vaeq_nn_train(const vaeq_nn_args *pa, void *stream)
 }
 
 extern "C" int vaeq_nn_forward(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, int32_t k1, int32_t k2, const float *x,
-                               const float *theta, float *q, void *stream)
+                               const float *theta, const float *bn_running, float *q, void *stream)
 {
     if (R == 0 || N == 0) return VAEQ_OK;
     if (!x || !theta || !q) return VAEQ_ERR_NULL;
     if (R < 0 || N < 0 || N > 0x3fffffff || !vaeq::nn_shape_ok(vaeq::NN_TILE, sps, M, n_lev, k1, k2)) return VAEQ_ERR_SHAPE;
-    if ((int64_t)vaeq::nn_layout(vaeq::NN_TILE, sps, M, n_lev, k1, k2).total * 4 > 160 * 1024) return VAEQ_ERR_LDS;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     switch (n_lev) {
-    case 2: return vaeq::launch_nn_forward<2>(R, (int)N, sps, M, k1, k2, x, theta, q, st);
-    case 4: return vaeq::launch_nn_forward<4>(R, (int)N, sps, M, k1, k2, x, theta, q, st);
-    case 8: return vaeq::launch_nn_forward<8>(R, (int)N, sps, M, k1, k2, x, theta, q, st);
+    case 2: return vaeq::launch_nn_forward<2>(R, (int)N, sps, M, k1, k2, x, theta, bn_running, q, st);
+    case 4: return vaeq::launch_nn_forward<4>(R, (int)N, sps, M, k1, k2, x, theta, bn_running, q, st);
+    case 8: return vaeq::launch_nn_forward<8>(R, (int)N, sps, M, k1, k2, x, theta, bn_running, q, st);
     }
     return VAEQ_ERR_SHAPE;
 }
 
 extern "C" int vaeq_nn_validate(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, int32_t k1, int32_t k2, int32_t n_shift,
-                                const float *x, const float *theta, const float *amp, const void *data_f16, float *ser, int32_t *shift,
-                                void *stream)
+                                const float *x, const float *theta, const float *bn_running, const float *amp, const void *data_f16, float *ser,
+                                int32_t *shift, void *stream)
 {
     if (R == 0) return VAEQ_OK;                                // an empty batch owns no memory: its pointers may be NULL
     if (!x || !theta || !amp || !data_f16 || !ser) return VAEQ_ERR_NULL;
@@ -662,9 +741,9 @@ extern "C" int vaeq_nn_validate(int32_t R, int64_t N, int32_t sps, int32_t M, in
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const __half *d = reinterpret_cast<const __half *>(data_f16);
     switch (n_lev) {
-    case 2: return vaeq::launch_nn_validate<2>(R, (int)N, sps, M, k1, k2, n_shift, x, theta, amp, d, ser, shift, st);
-    case 4: return vaeq::launch_nn_validate<4>(R, (int)N, sps, M, k1, k2, n_shift, x, theta, amp, d, ser, shift, st);
-    case 8: return vaeq::launch_nn_validate<8>(R, (int)N, sps, M, k1, k2, n_shift, x, theta, amp, d, ser, shift, st);
+    case 2: return vaeq::launch_nn_validate<2>(R, (int)N, sps, M, k1, k2, n_shift, x, theta, bn_running, amp, d, ser, shift, st);
+    case 4: return vaeq::launch_nn_validate<4>(R, (int)N, sps, M, k1, k2, n_shift, x, theta, bn_running, amp, d, ser, shift, st);
+    case 8: return vaeq::launch_nn_validate<8>(R, (int)N, sps, M, k1, k2, n_shift, x, theta, bn_running, amp, d, ser, shift, st);
     }
     return VAEQ_ERR_SHAPE;
 }

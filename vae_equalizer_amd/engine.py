@@ -249,11 +249,14 @@ class NNEngine:
     """R independent AWGN VAE-NN runs (AWGN_channel/func_VAENN_MQAM.py): flat per-run parameter vectors
     theta = [fc1.weight | fc1.bias | fc2.weight | fc2.bias | h_est] and their AMSGrad state on the device."""
 
-    def __init__(self, R, M_est, kernel_1, kernel_2, amp_levels, device="cuda:0", sps=2):
+    def __init__(self, R, M_est, kernel_1, kernel_2, amp_levels, device="cuda:0", sps=2, batch_norm=False):
         self.device = torch.device(device)
         self.amp = _f32(amp_levels, self.device).reshape(-1).contiguous()
         self.R, self.M, self.k1, self.k2, self.sps, self.n_lev = int(R), int(M_est), int(kernel_1), int(kernel_2), int(sps), self.amp.numel()
-        NP = int(nat.lib().vaeq_nn_param_count(self.M, self.n_lev, self.k1, self.k2))
+        self.batch_norm = bool(batch_norm)                      # Net_BN (:190-211): theta gains [gamma | beta], bn = running statistics
+        C_ = 2 * self.n_lev
+        self.bn = torch.cat([torch.zeros(self.R, C_), torch.ones(self.R, C_)], 1).to(self.device).contiguous() if self.batch_norm else None
+        NP = int(nat.lib().vaeq_nn_param_count(self.M, self.n_lev, self.k1, self.k2, int(self.batch_norm)))
         if NP < 0:
             raise ValueError(f"unsupported VAE-NN shape M={M_est} k1={kernel_1} k2={kernel_2} n_lev={self.n_lev}: "
                              + nat.lib().vaeq_strerror(NP).decode())
@@ -266,7 +269,10 @@ class NNEngine:
         C_ = 2 * self.n_lev
         o = [0, C_ * 2 * self.k1]
         o += [o[-1] + C_, o[-1] + C_ + C_ * C_ * self.k2]
-        o += [o[-1] + C_, o[-1] + C_ + 2 * self.M]
+        o += [o[-1] + C_]
+        if self.batch_norm:
+            o += [o[-1] + C_, o[-1] + 2 * C_]
+        o += [o[-1] + 2 * self.M]
         return o
 
     def init_parameters(self, generator=None):
@@ -274,12 +280,19 @@ class NNEngine:
         h_est (:244-246), independently per run."""
         C_, o = 2 * self.n_lev, self.offsets()
         u = lambda n, bound: (torch.rand(self.R, n, generator=generator, device=self.device) * 2 - 1) * bound
-        self.theta[:, o[0]:o[1]] = u(o[1] - o[0], (6.0 / (2 * self.k1 + C_ * self.k1)) ** 0.5)           # fan_in 2 k1, fan_out C k1
+        # Net: xavier_uniform_ on fc1 (fan_in 2 k1, fan_out C k1, :173); Net_BN: kaiming_uniform_ (a = 0: bound sqrt(6 / fan_in), :195)
+        self.theta[:, o[0]:o[1]] = u(o[1] - o[0], (6.0 / (2 * self.k1)) ** 0.5 if self.batch_norm else (6.0 / (2 * self.k1 + C_ * self.k1)) ** 0.5)
         self.theta[:, o[1]:o[2]] = u(C_, (2 * self.k1) ** -0.5)
         self.theta[:, o[2]:o[3]] = u(o[3] - o[2], (6.0 / (2 * C_ * self.k2)) ** 0.5)
         self.theta[:, o[3]:o[4]] = u(C_, (C_ * self.k2) ** -0.5)
-        self.theta[:, o[4]:] = 0
-        self.theta[:, o[4] + self.M // 2] = 1
+        if self.batch_norm:
+            self.theta[:, o[4]:o[5]] = 1                        # BatchNorm weight
+            self.theta[:, o[5]:o[6]] = 0                        # BatchNorm bias
+            self.bn[:, :C_] = 0
+            self.bn[:, C_:] = 1
+        oh = o[-2]
+        self.theta[:, oh:] = 0
+        self.theta[:, oh + self.M // 2] = 1
         for t in (self.m, self.v, self.vmax):
             t.zero_()
         self.step.zero_()
@@ -298,7 +311,8 @@ class NNEngine:
         a = nat.NNArgs(R=R, steps=steps, B=B, sps=self.sps, M=self.M, n_lev=self.n_lev, k1=self.k1, k2=self.k2, S=S, rx=nat.ptr(rx),
                        theta=nat.ptr(self.theta), adam_m=nat.ptr(self.m), adam_v=nat.ptr(self.v), adam_x=nat.ptr(self.vmax),
                        step=nat.ptr(self.step, torch.int32), amp=nat.ptr(self.amp), lr=nat.ptr(lr_t), loss=nat.ptr(out["loss"]),
-                       q_out=nat.ptr(out["q"]), dbg_g=nat.ptr(out["g"]), no_update=int(no_update))
+                       q_out=nat.ptr(out["q"]), dbg_g=nat.ptr(out["g"]), no_update=int(no_update), batch_norm=int(self.batch_norm),
+                       bn_running=nat.ptr(self.bn))
         with torch.cuda.device(dev):
             nat.check(nat.lib().vaeq_nn_train(C.byref(a), nat.current_stream(dev)), "vaeq_nn_train")
         out["_keepalive"] = (lr_t, rx)
@@ -311,7 +325,7 @@ class NNEngine:
         q = torch.empty(R, 2 * self.n_lev, N, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             nat.check(nat.lib().vaeq_nn_forward(R, N, self.sps, self.M, self.n_lev, self.k1, self.k2, nat.ptr(x), nat.ptr(self.theta),
-                                                nat.ptr(q), nat.current_stream(self.device)), "vaeq_nn_forward")
+                                                nat.ptr(self.bn), nat.ptr(q), nat.current_stream(self.device)), "vaeq_nn_forward")
         return q
 
     def validate(self, x, data, n_shift=21):
@@ -325,7 +339,7 @@ class NNEngine:
         shift = torch.empty(R, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             nat.check(nat.lib().vaeq_nn_validate(R, N, self.sps, self.M, self.n_lev, self.k1, self.k2, int(n_shift), nat.ptr(x),
-                                                 nat.ptr(self.theta), nat.ptr(self.amp), nat.ptr(data, torch.float16), nat.ptr(ser),
+                                                 nat.ptr(self.theta), nat.ptr(self.bn), nat.ptr(self.amp), nat.ptr(data, torch.float16), nat.ptr(ser),
                                                  nat.ptr(shift, torch.int32), nat.current_stream(self.device)), "vaeq_nn_validate")
         return ser, shift
 

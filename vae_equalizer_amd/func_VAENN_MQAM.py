@@ -1,7 +1,7 @@
 """Drop-in for AWGN_channel/func_VAENN_MQAM.py: same ``processing`` signature (:215) and return value (:304); the
 training loop and the validation pass run on the HIP kernels (engine.NNEngine: vaeq_nn_train, vaeq_nn_validate).
 
-Not implemented: ``net_type='Net_BN'`` (the BatchNorm variant, :190-211) -- ``processing`` raises for it."""
+Both topologies of the reference are implemented: ``net_type='Net'`` and ``'Net_BN'`` (BatchNorm1d between the ELU and fc2)."""
 import numpy as np
 import torch
 
@@ -55,7 +55,7 @@ def loss_function(q, rx, h, device, amp_levels):
 
 
 def run_vaenn_batch(runs, mod, sps, M_est, kernel_1, kernel_2, batch_len, N_valid, N_train, num_epochs, epe, channel, device=None,
-                    verbose=False, generator="hip", seed=0, theta0=None):
+                    verbose=False, generator="hip", seed=0, theta0=None, net_type="Net"):
     """R VAE-NN runs at once: ``runs`` = list of dict(SNR, lr_optim, seed).  Per epoch one generator call, ONE training launch
     (N_train // batch_len minibatches) and, on evaluated epochs, one fused validation launch for all runs (:266-301).
 
@@ -66,7 +66,9 @@ def run_vaenn_batch(runs, mod, sps, M_est, kernel_1, kernel_2, batch_len, N_vali
     device = default_device() if device is None else torch.device(device)
     R = len(runs)
     t = vaenn_tables(mod, channel, sps)
-    eng = NNEngine(R, M_est, kernel_1, kernel_2, t["amps"], device, sps)
+    if net_type not in ("Net", "Net_BN"):
+        raise UnboundLocalError(f"unknown net_type {net_type!r} (the reference leaves `net` unbound, :239-243)")
+    eng = NNEngine(R, M_est, kernel_1, kernel_2, t["amps"], device, sps, batch_norm=(net_type == "Net_BN"))
     if theta0 is None:
         gen = torch.Generator(device=device)
         gen.manual_seed(int(seed) + 12345)
@@ -111,10 +113,9 @@ def run_vaenn_batch(runs, mod, sps, M_est, kernel_1, kernel_2, batch_len, N_vali
 def processing(mod, sps, SNR, M_est, kernel_1, kernel_2, lr_optim, batch_len, N_valid, N_train, num_epochs, epe, channel, net_type, *,
                seed=None, device=None, verbose=True, generator="numpy", theta0=None):
     """One VAE-NN run -> SER_valid[num_epochs//epe] (CPU float32), the reference's positional signature (:215)."""
-    if net_type != "Net":
-        raise NotImplementedError(f"net_type {net_type!r}: only 'Net' is implemented (Net_BN, :190-211, is not)")
     device = default_device() if device is None else torch.device(device)
     if verbose:
         print("We are using the following device for learning:", device)
     return run_vaenn_batch([dict(SNR=SNR, lr_optim=lr_optim, seed=seed)], mod, sps, M_est, kernel_1, kernel_2, batch_len, N_valid, N_train,
-                           num_epochs, epe, channel, device=device, verbose=verbose, generator=generator, seed=seed or 0, theta0=theta0)[0]
+                           num_epochs, epe, channel, device=device, verbose=verbose, generator=generator, seed=seed or 0, theta0=theta0,
+                           net_type=net_type)[0]
