@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Shader-clock cycles per phase of the last step of one wave of the DP wave kernel under full load (library built with the phase
-stamps: gpurun_variants/libvaeq_dpprof.so).  VAEQ_LIB=... python tools/probe_dp_phases.py [R]"""
+stamps: tools/build_phase_probe.sh dp_wave -> gpurun_variants/libvaeq_dp_waveprof.so).  VAEQ_LIB=... python tools/probe_dp_phases.py [R]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-phase wall-clock times of the DP epilogue kernel for run 0 (library built with phase stamps, gpurun_variants/libvaeq_epiprof.so)."""
+"""Per-phase wall-clock times of the DP epilogue kernel for run 0 (tools/build_phase_probe.sh epilogue -> gpurun_variants/libvaeq_epilogueprof.so)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-phase wall-clock ticks (100 MHz) of the last VAE-NN training step of run 0, from a library built with the phase stamps
-(gpurun_variants/libvaeq_nnprof.so, see git history of this file for the patch): VAEQ_LIB=... python tools/probe_nn_phases.py"""
+(tools/build_phase_probe.sh nn -> gpurun_variants/libvaeq_nnprof.so): VAEQ_LIB=... python tools/probe_nn_phases.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
