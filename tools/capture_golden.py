@@ -15,6 +15,10 @@ numpy==1.18.4; this image has numpy 2.2), see SURVEY.md section 8c:
 The reference seeds nothing; determinism comes from patching
 ``np.random.default_rng`` / ``np.random.seed`` / ``torch.manual_seed`` here.
 
+Fixture families: G0 init tables, G1-G3 DP step / free runs (VAE-LE, VAEflex), G4 AWGN VAE-LE, G5 DP epilogue, G6 generator,
+G7 processing()-level runs (configs 1-3), G8 AWGN VAE-NN (Net), G9 converging VAEflex run (config 4), G10 converging PCS VAE-LE
+run (config 5 shape), G11 VAE-NN with BatchNorm (Net_BN).
+
 Usage:  python tools/capture_golden.py [--only G1,G2] [--full-run]
 """
 import argparse

@@ -79,6 +79,22 @@ def SER_q(q, tx, sps, num_lev, device=None):
     return torch.stack([((data - d) != 0).any(dim=0).float().mean() for d in (dec, dec_pi, dec_pi4, dec_3pi4)]).min()
 
 
+def SER_symb(rx, tx, sps, amp_levels, num_lev, device=None):
+    """:125-153 -- SER of nearest-level decisions on the (un-equalised) symbol-rate samples, each axis normalised to unit power,
+    minimum over the four quadrant rotations (the reference keeps it for its commented-out "unprocessed SER" print, :315)."""
+    N = tx.shape[1]
+    scale = (num_lev - 1) / 2
+    data = torch.round(scale * tx.float() + scale)
+    sI, sQ = rx[0, :N * sps:sps], rx[1, :N * sps:sps]
+    sI, sQ = sI / torch.sqrt(2 * torch.mean(sI ** 2)), sQ / torch.sqrt(2 * torch.mean(sQ ** 2))
+    dec = torch.stack([torch.argmin(torch.abs(sI[None] - amp_levels[:, None]), dim=0),
+                       torch.argmin(torch.abs(sQ[None] - amp_levels[:, None]), dim=0)]).float()
+    dec_pi = -(dec - scale * 2)
+    dec_pi4 = torch.stack([-(dec[1] - scale * 2), dec[0]])
+    dec_3pi4 = -(dec_pi4 - scale * 2)
+    return torch.stack([((data - d) != 0).any(dim=0).float().mean() for d in (dec, dec_pi, dec_pi4, dec_3pi4)]).min()
+
+
 def run_awgn_batch(runs, mod, sps, M_est, batch_len, N_valid, N_train, num_epochs, epe, channel, device=None, verbose=False,
                    generator="numpy", seed=0):
     """R AWGN VAE-LE runs at once: ``runs`` = list of dict(SNR, nu, lr_optim, seed).  Per epoch ONE training launch and, on evaluated

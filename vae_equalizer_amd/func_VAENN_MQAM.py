@@ -8,7 +8,7 @@ import torch
 from . import channel as ch
 from .dp_runs import default_device
 from .engine import NNEngine
-from .func_VAELE_MQAM_shaping import SER_q, find_shift  # noqa: F401  (identical helpers in both reference files)
+from .func_VAELE_MQAM_shaping import SER_q, SER_symb, find_shift  # noqa: F401  (identical helpers in both reference files)
 from .shared_funcs import _CHANNELS, _LEVELS
 
 
