@@ -644,10 +644,10 @@ static int launch_nn_validate(int R, int N, int sps, int M, int k1, int k2, int 
 {
     const size_t lds = (size_t)nn_layout(NN_TILE, sps, M, NLEV, k1, k2, bn != nullptr).total * 4 + (((size_t)N + 15) & ~(size_t)15);
     if (lds > 150 * 1024) return VAEQ_ERR_LDS;
-    auto k = nn_validate_kernel<512, NLEV>;
+    auto k = nn_validate_kernel<1024, NLEV>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VAEQ_ERR_LDS;
-    hipLaunchKernelGGL(k, dim3(R), dim3(512), lds, st, N, sps, M, k1, k2, n_shift, x, theta, bn, amp, data, ser, shift);
+    hipLaunchKernelGGL(k, dim3(R), dim3(1024), lds, st, N, sps, M, k1, k2, n_shift, x, theta, bn, amp, data, ser, shift);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
 
@@ -667,10 +667,10 @@ static int launch_nn_forward(int R, int N, int sps, int M, int k1, int k2, const
 {
     const size_t lds = (size_t)nn_layout(NN_TILE, sps, M, NLEV, k1, k2, bn != nullptr).total * 4;
     if (lds > 160 * 1024) return VAEQ_ERR_LDS;
-    auto k = nn_forward_kernel<512, NLEV>;
+    auto k = nn_forward_kernel<1024, NLEV>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VAEQ_ERR_LDS;
-    hipLaunchKernelGGL(k, dim3(R), dim3(512), lds, st, N, sps, M, k1, k2, x, theta, bn, q);
+    hipLaunchKernelGGL(k, dim3(R), dim3(1024), lds, st, N, sps, M, k1, k2, x, theta, bn, q);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
 
