@@ -113,6 +113,20 @@ def test_eval_run_awgn_script_mat_schema(tmp_path, monkeypatch):
     assert "SERvsSNR_VAELE_shaping_0_h1_64-QAM_2_2000_2_1200_" in name
 
 
+@pytest.mark.parametrize("net_type,gen", [("Net", "hip"), ("Net_BN", "numpy")])
+def test_eval_run_vaenn_script_mat_schema(tmp_path, monkeypatch, net_type, gen):
+    """Eval_run_vaenn.main() on a tiny sweep: result tensor shape and the .mat schema of the reference (:36, :58-68)."""
+    from vae_equalizer_amd import Eval_run_vaenn as ev
+    monkeypatch.setattr(ev, "iter", 2); monkeypatch.setattr(ev, "num_epochs", 4); monkeypatch.setattr(ev, "N_valid", 2000)
+    monkeypatch.setattr(ev, "train_len", 900); monkeypatch.setattr(ev, "SNR_vec", [20, 24]); monkeypatch.setattr(ev, "net_type_vec", [net_type])
+    monkeypatch.setattr(ev, "savePATH", str(tmp_path) + "/"); monkeypatch.setattr(ev, "base_seed", 3); monkeypatch.setattr(ev, "generator", gen)
+    name, d = ev.main()
+    assert d["SER"].shape == (2, 1, 1, 1, 1, 1, 2, 2) and np.isfinite(d["SER"]).all() and (d["SER"] > 0.3).all()       # 4 epochs: far from locked
+    m = io.loadmat(name)["dict"]
+    assert set(m.dtype.names) == {"SER", "SNR", "k2", "k1", "M", "lr", "N_train"}
+    assert f"SERvsSNR_{net_type}_h1_64-QAM_2_2000_2_900_" in name
+
+
 def test_hip_epilogue_on_converged_reference_frame():
     """vaeq_dp_epilogue on G5's converged frame == the reference's own shift / swap / SER results."""
     from vae_equalizer_amd.engine import dp_epilogue
