@@ -76,8 +76,9 @@ def run_dp_batch(runs, mod, sps, M_est, batch_len, N_frame_max, num_frames, flex
         tgen = torch.Generator(device=device)
         tgen.manual_seed(int(runs[0].seed) if runs[0].seed is not None else torch.seed())
 
-    SER = torch.empty(R, 4, num_frames, dtype=torch.float32)
-    Var_est = torch.empty(R, 2, num_frames, dtype=torch.float32)
+    # per-frame results stay on the device until the end: no host synchronisation inside the frame loop (unless verbose)
+    SER = torch.empty(R, 4, num_frames, dtype=torch.float32, device=device)
+    Var_est = torch.empty(R, 2, num_frames, dtype=torch.float32, device=device)
     last = None
     for frame in range(num_frames):
         # lr schedule: group 0 (W) only, set (not multiplied) to lr/2 (func_VAELE_DP_MQAM_shaping.py:45-46)
@@ -115,9 +116,9 @@ def run_dp_batch(runs, mod, sps, M_est, batch_len, N_frame_max, num_frames, flex
         out = eng.train(rx, batch_len, steps, cur_lr_W, lr0, stride=stride, keep_off=k0, keep_len=klen, want_q=need_q, want_compact=True)
         q, y = (out["q"][:, 0] if need_q else None), out["y"][:, 0]
         ve = out["var_est"][:, 0]                                               # [R,2,steps]
-        Var_est[:, :, frame] = ve.mean(dim=2).cpu()                             # :69
+        Var_est[:, :, frame] = ve.mean(dim=2)                                   # :69
         res = dp_epilogue_compact(out["eq"][:, 0], out["dec"][:, 0], y, data, amp, nu_sc_t, var, None if flex else batch_len)
-        SER[:, :, frame] = res["SER"].cpu()
+        SER[:, :, frame] = res["SER"]
         if verbose:
             loss = out["loss"][:, 0, -1].cpu()
             snr_est = torch.tensor(pow_mean, dtype=torch.float32) / ve.mean(dim=(1, 2)).cpu()   # :68
@@ -130,7 +131,7 @@ def run_dp_batch(runs, mod, sps, M_est, batch_len, N_frame_max, num_frames, flex
                 print("\t\t\t\t\t\t\tSER_x = ", SER[i, 2, frame].item(), "\tSER_y = ", SER[i, 3, frame].item(), "\t(soft demapper)")
         if keep_last and frame == num_frames - 1:
             last = dict(q=q, y=y, data=data, rx=rx, **res)
-    ret = dict(SER=SER, Var_est=Var_est, var=torch.tensor(var_np), engine=eng)
+    ret = dict(SER=SER.cpu(), Var_est=Var_est.cpu(), var=torch.tensor(var_np), engine=eng)
     if last is not None:
         ret["last"] = last
     return ret
