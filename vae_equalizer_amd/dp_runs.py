@@ -28,6 +28,29 @@ class DPRun:
     seed: int = None
 
 
+_POOL = None
+
+
+def _host_pool():
+    """Thread pool for the host-side channel model (sized to the CPU share of this process)."""
+    global _POOL
+    if _POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        try:
+            n = len(os.sched_getaffinity(0))
+        except AttributeError:
+            n = os.cpu_count() or 1
+        try:
+            q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                n = min(n, max(1, int(q) // int(p)))
+        except (OSError, ValueError):
+            pass
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(n, 32)))
+    return _POOL
+
+
 def default_device():
     if not torch.cuda.is_available():
         from ._native import VaeqError
@@ -97,16 +120,18 @@ def run_dp_batch(runs, mod, sps, M_est, batch_len, N_frame_max, num_frames, flex
             rx, data = ch.generate_batch_gpu(R, N_frame, amps, P, SNRs, h_channel, srate, sps, tau_cd, tau_pmd, phiIQ, theta,
                                              device, generator=tgen)
         else:
-            rxs, datas = [], []
-            for i, r in enumerate(runs):
-                st = streams[i]
-                rx_i, d_i, _ = ch.generate_data_shaping(N_frame, amps, r.SNR, h_channel, tabs[i]["P"], 2, r.symb_rate, sps, tau_cd,
-                                                        tau_pmd, phiIQ, theta[i], "cpu", rng=st.next_rng() if st else None,
-                                                        noise=st.noise if st else None)
-                rxs.append(rx_i)
-                datas.append(d_i)
-            rx = torch.stack(rxs).to(device, non_blocking=True)
-            data = torch.stack(datas).to(device, non_blocking=True)
+            def host_frame(i):                                  # the reference-faithful numpy channel model, one run
+                r, st = runs[i], streams[i]
+                return ch.generate_data_shaping(N_frame, amps, r.SNR, h_channel, tabs[i]["P"], 2, r.symb_rate, sps, tau_cd, tau_pmd, phiIQ,
+                                                theta[i], "cpu", rng=st.next_rng() if st else None, noise=st.noise if st else None)[:2]
+            # seeded runs own their random streams, so they can be generated concurrently (numpy releases the GIL in the FFTs and
+            # convolutions); unseeded runs share numpy's global stream like the reference and stay sequential
+            if R > 1 and all(st is not None for st in streams):
+                pairs = list(_host_pool().map(host_frame, range(R)))
+            else:
+                pairs = [host_frame(i) for i in range(R)]
+            rx = torch.stack([p[0] for p in pairs]).to(device, non_blocking=True)
+            data = torch.stack([p[1] for p in pairs]).to(device, non_blocking=True)
         theta = theta + theta_diff                                              # :51
         if flex:
             data = data[:, :, :, batch_len // 2:N_out + batch_len // 2]          # func_VAEflex...:51
