@@ -4,7 +4,7 @@ import numpy as np
 import torch
 
 from . import channel as ch
-from .dp_runs import default_device
+from .dp_runs import _host_pool, default_device
 from .engine import AWGNEngine
 from .shared_funcs import _CHANNELS, qam_tables
 
@@ -125,13 +125,13 @@ def run_awgn_batch(runs, mod, sps, M_est, batch_len, N_valid, N_train, num_epoch
             return ch.generate_awgn_batch_hip(R, N, t0["amps"], P_all, snr_all, t0["h_channel"], sps, device, seed, draws[0] - 1)
         if generator != "numpy":
             raise ValueError(f"unknown generator {generator!r}")
-        rxs, ds = [], []
-        for t, r, st in zip(tabs, runs, streams):
-            rx, d = ch.generate_data(N, t["M_channel"], t["amps"], r["SNR"], t["h_channel"], sps, "cpu", t["P"],
-                                     rng=st.next_rng() if st else None, noise=st.noise if st else None)
-            rxs.append(rx)
-            ds.append(d)
-        return torch.stack(rxs).to(device), torch.stack(ds).to(device)
+        def host(i):
+            t, r, st = tabs[i], runs[i], streams[i]
+            return ch.generate_data(N, t["M_channel"], t["amps"], r["SNR"], t["h_channel"], sps, "cpu", t["P"],
+                                    rng=st.next_rng() if st else None, noise=st.noise if st else None)
+        seeded = R > 1 and all(st is not None for st in streams)                   # own random streams: safe to generate concurrently
+        pairs = list(_host_pool().map(host, range(R))) if seeded else [host(i) for i in range(R)]
+        return torch.stack([p[0] for p in pairs]).to(device), torch.stack([p[1] for p in pairs]).to(device)
 
     for epoch in range(num_epochs):
         rx, _ = draw(N_train)

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from . import channel as ch
-from .dp_runs import default_device
+from .dp_runs import _host_pool, default_device
 from .engine import NNEngine
 from .func_VAELE_MQAM_shaping import SER_q, SER_symb, find_shift  # noqa: F401  (identical helpers in both reference files)
 from .shared_funcs import _CHANNELS, _LEVELS
@@ -92,7 +92,9 @@ def run_vaenn_batch(runs, mod, sps, M_est, kernel_1, kernel_2, batch_len, N_vali
             return ch.generate_awgn_batch_hip(R, N, t["amps"], P, snr, t["h_channel"], sps, device, seed, draws[0] - 1, sigma_fixed=sigma)
         if generator != "numpy":
             raise ValueError(f"unknown generator {generator!r}")
-        pairs = [generate_data(N, t["M_channel"], t["constellation"], r["SNR"], t["h_channel"], sps, "cpu", rng) for r, rng in zip(runs, rngs)]
+        host = lambda i: generate_data(N, t["M_channel"], t["constellation"], runs[i]["SNR"], t["h_channel"], sps, "cpu", rngs[i])
+        seeded = R > 1 and all(g is not None for g in rngs)                         # own random streams: safe to generate concurrently
+        pairs = list(_host_pool().map(host, range(R))) if seeded else [host(i) for i in range(R)]
         return torch.stack([p[0] for p in pairs]).to(device), torch.stack([p[1] for p in pairs]).to(device)
 
     for epoch in range(num_epochs):
