@@ -150,3 +150,27 @@ def test_awgn_generator_statistics_and_structure():
         assert abs(np.mean(noise)) < 4 * sigma[r] / np.sqrt(len(noise))
         ac = np.abs(np.vdot(noise[1:], noise[:-1])) / np.vdot(noise, noise).real
         assert ac < 5 / np.sqrt(len(noise))                                   # white
+
+
+def test_awgn_generator_generic_oversampling():
+    """sps = 3 takes the generic stage-1 / reference kernels (one thread per sample): same structure checks as for sps = 2."""
+    import numpy as np
+    from vae_equalizer_amd import channel as ch
+    from vae_equalizer_amd.func_VAELE_MQAM_shaping import awgn_tables
+    R, N, sps = 3, 3000, 3
+    snr = np.array([12, 20, 28], np.float32)
+    t = awgn_tables("16-QAM", 0.0, 20, "h2", sps)
+    rx, data, sigma = ch.generate_awgn_batch_hip(R, N, t["amps"], t["P"], snr, t["h_channel"], sps, "cuda:0", 77, 0, return_sigma=True)
+    assert rx.shape == (R, 2, sps * N) and data.shape == (R, 2, N)
+    rx, data, sigma = rx.cpu().numpy().astype(np.float64), data.cpu().numpy().astype(np.float64), sigma.cpu().numpy()
+    geo = ch.awgn_frame_geometry(N, t["h_channel"], sps)
+    for r in range(R):
+        up = np.zeros(sps * (N - 1) + 1, complex)
+        up[::sps] = data[r, 0] + 1j * data[r, 1]
+        clean = np.convolve(up, geo["g"].astype(complex), mode="valid")
+        o = sps * geo["ref_offset"]
+        got = (rx[r, 0] + 1j * rx[r, 1])[o:o + len(clean)]
+        noise = got - clean[:len(got)]
+        want_sigma = np.sqrt(sps * np.mean(np.abs(clean) ** 2) / 2 / 10 ** (snr[r] / 10))
+        assert abs(sigma[r] / want_sigma - 1) < 0.04
+        assert abs(np.std(noise.real) / sigma[r] - 1) < 0.04 and abs(np.std(noise.imag) / sigma[r] - 1) < 0.04
