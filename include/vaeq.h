@@ -300,6 +300,16 @@ int vaeq_awgn_validate(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_l
                        const float *amp, const float *amp_mean, const float *var, const void *data_f16, float *y_ws, float *ser,
                        int32_t *shift, void *stream);
 
+/* ------------------------------------------------------------------------
+ * the constant-modulus baselines of the DP scripts and their carrier phase estimation.
+ * vaeq_cma: CMA (shared_funcs.py:341-383, mode 0) / CMAbatch (:385-433, mode 1 with symb_step = batchlen) / CMAflex (:435-488,
+ * mode 1) on one frame per run: rx[R][2][2][N] -> out[R][2][2][N/sps], e[R][N/sps][2] (nullable); taps h[R][2][2][2][M] and the
+ * per-run step size lr[R] as in the reference (h is updated in place; R_mod is the modulus constant `R` of the reference).
+ * vaeq_cpe: Viterbi-Viterbi carrier phase estimation (:139-186), y[R][2][2][N] -> y_out[R][2][2][N], M_ma = 501 in the reference. */
+int vaeq_cma(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t mode, int32_t batchlen, int32_t symb_step, const float *rx, float R_mod,
+             float *h, const float *lr, float *out, float *e, void *stream);
+int vaeq_cpe(int32_t R, int64_t N, int32_t M_ma, const float *y, float *y_out, void *stream);
+
 int vaeq_version(void);
 const char *vaeq_strerror(int code);
 

@@ -349,3 +349,21 @@ def nnbn_train(state, rx, n_steps, B, amp, k1, k2, M, lr, sps=2, dtype=np.float3
     f(n_steps, B, sps, M, n, k1, k2, S, _p(rx), _p(state.theta), _p(state.bn), _p(state.m), _p(state.v), _p(state.vmax), C.byref(state.step),
       _p(amp), C.c_double(lr), _p(loss))
     return loss
+
+
+# ------------------------------------------------------------------ row f4: constant-modulus baselines
+def cma(rx, h, lr, sps=2, mode="CMA", batchlen=100, symb_step=10, R=1.0, dtype=np.float32):
+    """CMA / CMAbatch / CMAflex (shared_funcs.py:341-488) on one frame rx[2,2,N]; h[2,2,2,M] is updated IN PLACE (pass a copy).
+    Returns (out[2,2,N//sps], e[N//sps,2])."""
+    sfx, ct, npt = _sfx(dtype)
+    rx = _arr(rx, npt)
+    assert h.dtype == npt and h.flags["C_CONTIGUOUS"]
+    N, M = rx.shape[-1], h.shape[-1]
+    K = N // sps
+    out, e = np.empty((2, 2, K), npt), np.empty((K, 2), npt)
+    m = {"CMA": 0, "CMAbatch": 1, "CMAflex": 1}[mode]
+    step = batchlen if mode == "CMAbatch" else symb_step
+    f = getattr(lib(), "vaeq_oracle_cma" + sfx)
+    f.restype = None
+    f(N, sps, M, m, batchlen, step, _p(rx), ct(R), _p(h), C.c_double(lr), _p(out), _p(e))
+    return out, e

@@ -155,3 +155,24 @@ def awgn_validate(q, data, amp_levels):
     shift = awgn_find_shift(q, data, 21, amp_levels)
     n = amp_levels.shape[0]
     return awgn_SER_q(q[:, 11 + shift:-11], data[:, 11:-11 - shift], n), shift
+
+
+def cpe(y, M_ma=501):
+    """Viterbi-Viterbi carrier phase estimation (shared_funcs.py:139-186): y[2,2,N] -> phase-corrected y.  4th power, moving
+    average over M_ma symbols (zero padded), atan2 / 4, unwrapping of pi/2 jumps, de-rotation."""
+    y = np.asarray(y, dtype=np.float64)
+    out = np.zeros_like(y)
+    for p in range(2):
+        a, b = y[p, 0], y[p, 1]
+        a2, b2 = a * a, b * b
+        p4r = a2 * a2 - 6 * a2 * b2 + b2 * b2
+        p4i = 4 * (a2 * a * b - a * b2 * b)
+        ker = np.full(M_ma, 1.0 / M_ma)
+        mr, mi = np.convolve(p4r, ker, mode="same"), np.convolve(p4i, ker, mode="same")
+        phi = np.arctan2(mi, -mr) / 4
+        d = np.diff(phi)
+        corr = np.concatenate([[0.0], np.cumsum((d < -np.pi / 4).astype(float) - (d > np.pi / 4).astype(float))]) * (np.pi / 2)
+        phi = phi + corr
+        c, s = np.cos(phi), np.sin(phi)
+        out[p, 0], out[p, 1] = a * c - b * s, b * c + a * s
+    return out

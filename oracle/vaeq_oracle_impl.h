@@ -870,6 +870,87 @@ void FN(vaeq_oracle_nnbn_forward_eval)(int B, int sps, int n, int k1, int k2, co
 #undef NNBN_NP
 #undef NN_NP
 
+/* ============================================================== row f4: constant-modulus baselines (shared_funcs.py:341-488)
+ * CMA (:341-383), CMAbatch (:385-433), CMAflex (:435-488) on one frame Rx[2][2][N]:
+ *   y = zero-padded Rx divided by the mean of |y_pol|^2 over the PADDED length (:350-351, a power -- not an amplitude -- scaling);
+ *   symbol j (sample i = mh + sps j) is written to index k = i / sps - mh, which is NEGATIVE for the first symbols and then wraps to
+ *   the end of the arrays exactly like the reference's tensor indexing does (:357);
+ *   mode 0: tap update after every symbol (:371-381); mode 1: the increments of the last `batchlen` symbols are applied when
+ *   k % symb_step == 0 and k >= batchlen (CMAflex :475; CMAbatch = the same with symb_step = batchlen, :421).
+ * h[2][2][2][M] = [out pol][in pol][re/im][tap], updated in place; out[2][2][K], e[K][2], K = N / sps. */
+void FN(vaeq_oracle_cma)(int N, int sps, int M, int mode, int batchlen, int symb_step, const REAL *rx, REAL R, REAL *h, double lr,
+                         REAL *out, REAL *e)
+{
+    const int mh = M / 2, Lp = N + 2 * mh, K = N / sps;
+    REAL *y = (REAL *)calloc((size_t)4 * Lp, sizeof(REAL));
+    REAL *gbuf = (REAL *)calloc((size_t)K * 4 + 1, sizeof(REAL));      /* per symbol: out[0][0], out[0][1], out[1][0], out[1][1] at update time */
+    int *jof = (int *)malloc(sizeof(int) * (K + 1));                   /* symbol number j stored at index k (to find its window again) */
+    REAL pw = 0;
+    for (int p = 0; p < 2; p++)
+        for (int c = 0; c < 2; c++)
+            for (int i = 0; i < N; i++) {
+                const REAL v = rx[(p * 2 + c) * N + i];
+                y[(p * 2 + c) * Lp + mh + i] = v;
+                pw += v * v;
+            }
+    pw /= (REAL)(2 * Lp);                                              /* torch.mean over [2, Lp] */
+    for (int i = 0; i < 4 * Lp; i++) y[i] /= pw;
+    for (int i = 0; i < 4 * K; i++) out[i] = 0;
+    const REAL two_lr = (REAL)(2.0 * lr);
+    for (int j = 0; mh + sps * j < N + mh; j++) {
+        const int i0 = sps * j;                                        /* first padded sample of the window: i - mh */
+        int k = (mh + sps * j) / sps - mh;
+        const int kraw = k;
+        if (k < 0) k += K;
+        REAL o[2][2];
+        for (int op = 0; op < 2; op++) {
+            REAL re = 0, im = 0;
+            for (int p = 0; p < 2; p++) {
+                REAL s0 = 0, s1 = 0, s2 = 0, s3 = 0;                   /* torch.matmul dot products, accumulated per filter row */
+                for (int t = 0; t < M; t++) {
+                    const REAL yr = y[(p * 2 + 0) * Lp + i0 + t], yi = y[(p * 2 + 1) * Lp + i0 + t];
+                    const REAL hr = h[((op * 2 + p) * 2 + 0) * M + t], hi = h[((op * 2 + p) * 2 + 1) * M + t];
+                    s0 += yr * hr; s1 += yi * hi; s2 += yr * hi; s3 += yi * hr;
+                }
+                re += s0 - s1;
+                im += s2 + s3;
+            }
+            o[op][0] = re; o[op][1] = im;
+            out[(op * 2 + 0) * K + k] = re;
+            out[(op * 2 + 1) * K + k] = im;
+            e[k * 2 + op] = R - re * re - im * im;
+        }
+        if (mode == 0) {
+            for (int op = 0; op < 2; op++)
+                for (int p = 0; p < 2; p++)
+                    for (int t = 0; t < M; t++) {
+                        const REAL yr = y[(p * 2 + 0) * Lp + i0 + t], yi = y[(p * 2 + 1) * Lp + i0 + t], ee = e[k * 2 + op];
+                        h[((op * 2 + p) * 2 + 0) * M + t] += two_lr * ee * (o[op][0] * yr + o[op][1] * yi);
+                        h[((op * 2 + p) * 2 + 1) * M + t] += two_lr * ee * (o[op][1] * yr - o[op][0] * yi);
+                    }
+        } else {
+            gbuf[k * 4 + 0] = o[0][0]; gbuf[k * 4 + 1] = o[0][1]; gbuf[k * 4 + 2] = o[1][0]; gbuf[k * 4 + 3] = o[1][1];
+            jof[k] = j;
+            if (kraw >= batchlen && kraw % symb_step == 0) {
+                for (int op = 0; op < 2; op++)
+                    for (int p = 0; p < 2; p++)
+                        for (int t = 0; t < M; t++) {
+                            REAL a0 = 0, a1 = 0;
+                            for (int kk = kraw - batchlen; kk < kraw; kk++) {
+                                const int w0 = sps * jof[kk];
+                                const REAL yr = y[(p * 2 + 0) * Lp + w0 + t], yi = y[(p * 2 + 1) * Lp + w0 + t], ee = e[kk * 2 + op];
+                                a0 += (gbuf[kk * 4 + op * 2] * yr + gbuf[kk * 4 + op * 2 + 1] * yi) * ee;
+                                a1 += (gbuf[kk * 4 + op * 2 + 1] * yr - gbuf[kk * 4 + op * 2] * yi) * ee;
+                            }
+                            h[((op * 2 + p) * 2 + 0) * M + t] += two_lr * a0;
+                            h[((op * 2 + p) * 2 + 1) * M + t] += two_lr * a1;
+                        }
+            }
+        }
+    }
+    free(y); free(gbuf); free(jof);
+}
+
 #undef FN
 #undef CAT
 #undef CAT_

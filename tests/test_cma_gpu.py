@@ -1,0 +1,83 @@
+"""GPU parity of the constant-modulus baselines (vaeq_cma, vaeq_cpe) against vectors captured from the reference
+(G12) and the run-level behaviour of the three drop-in processing() modules."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+PHI = np.array([0.0314, 0.0314], dtype=np.complex64)
+TAU_PMD = 0.1e-12 * np.sqrt(1000)
+
+
+@pytest.mark.parametrize("tag,mode", [("cma", "CMA"), ("cmabatch", "CMAbatch"), ("cmaflex", "CMAflex")])
+def test_cma_kernel_against_reference(tag, mode):
+    from vae_equalizer_amd.engine import cma
+    g = load_golden("G12_cma")
+    R = 3
+    rx = torch.from_numpy(g["rx"])[None].expand(R, -1, -1, -1).contiguous().to(DEV)
+    h = torch.from_numpy(g["h0"])[None].expand(R, -1, -1, -1, -1).contiguous().to(DEV)
+    out, e = cma(rx, h, float(g[f"lr_{tag}"]), int(g["sps"]), mode, int(g["batchlen"]), int(g["symb_step"]))
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], out[1]) and torch.equal(h[0], h[2])            # deterministic, run-independent
+    assert relerr(out[0].cpu().numpy(), g[f"{tag}_out"]) < 5e-5
+    assert relerr(e[0].cpu().numpy(), g[f"{tag}_e"]) < 5e-5
+    assert relerr(h[0].cpu().numpy(), g[f"{tag}_h"]) < 5e-5
+
+
+def test_cma_mirrors_keep_reference_signatures():
+    from vae_equalizer_amd import shared_funcs as sfun
+    g = load_golden("G12_cma")
+    rx = torch.from_numpy(g["rx"]).to(DEV)
+    h = torch.from_numpy(g["h0"]).to(DEV)
+    out, h2, e = sfun.CMAflex(rx, 1, h, float(g["lr_cmaflex"]), 100, 10, 2, True)
+    assert h2 is h and relerr(out.cpu().numpy(), g["cmaflex_out"]) < 5e-5 and relerr(h.cpu().numpy(), g["cmaflex_h"]) < 5e-5
+    h = torch.from_numpy(g["h0"]).to(DEV)
+    out, _, e = sfun.CMA(rx, 1, h, 1e-3, 2, False)                             # eval=False: no update
+    assert torch.equal(h.cpu(), torch.from_numpy(g["h0"])) and out.shape == (2, 2, 700) and e.shape == (700, 2)
+    out, _, _ = sfun.CMAbatch(rx, 1, h, float(g["lr_cmabatch"]), 100, 2, True)
+    assert relerr(out.cpu().numpy(), g["cmabatch_out"]) < 5e-5
+
+
+def test_cpe_kernel_against_reference():
+    from vae_equalizer_amd.shared_funcs import CPE
+    g = load_golden("G12_cma")
+    y = torch.from_numpy(g["cpe_in"]).to(DEV)
+    got = CPE(y).cpu().numpy()
+    assert relerr(got, g["cpe_out"]) < 2e-5
+    yb = torch.stack([y, torch.flip(y, dims=[-1])])                            # batched, a second run with the drift reversed
+    gb = CPE(yb).cpu().numpy()
+    assert relerr(gb[0], g["cpe_out"]) < 2e-5 and relerr(gb[1], oracle.cpe(yb[1].cpu().numpy())) < 2e-5
+
+
+@pytest.mark.parametrize("tag,module", [("cma", "func_CMA_DP_MQAM_shaping"), ("cmabatch", "func_CMAbatch_DP_MQAM_shaping"),
+                                        ("cmaflex", "func_CMAflex_DP_MQAM_shaping")])
+def test_cma_processing_vs_reference_trajectory(tag, module):
+    """processing() of the three baseline modules on the frames the reference saw (4-QAM, 18 dB, 24 frames x 1500 symbols).  The
+    constant-modulus updates are plain stochastic-gradient steps (no Adam normalisation), so the per-frame SER follows the reference's
+    closely, frame by frame."""
+    import importlib
+    mod = importlib.import_module("vae_equalizer_amd." + module)
+    g = load_golden("G12_cma_runs")
+    SER, Var_est, var = mod.processing("4-QAM", 2, 18, 0.0, 25, 0.006 * np.pi, np.pi / 10, float(g[f"{tag}_lr"]), 100, 1500, 24, 10, "h0", 90e9,
+                                       -26e-24, TAU_PMD, PHI, 170, seed=int(g[f"{tag}_seed"]), verbose=False)
+    ours, ref = SER.numpy(), g[f"{tag}_SER"]
+    assert ours.shape == ref.shape == (4, 24) and Var_est.shape == (2, 24) and float(Var_est.abs().max()) == 0.0
+    assert np.mean(np.abs(ours - ref)) < 0.02, np.round(np.abs(ours - ref).max(0), 3)
+    assert np.max(np.abs(ours[:, -5:] - ref[:, -5:])) < 0.03
+
+
+def test_eval_run_dp_serves_the_cma_loss_types(tmp_path, monkeypatch):
+    import scipy.io as io
+    from vae_equalizer_amd import Eval_run_DP as ev
+    monkeypatch.setattr(ev, "loss_type", "CMAflex"); monkeypatch.setattr(ev, "mod", "4-QAM"); monkeypatch.setattr(ev, "SNR_vec", [18])
+    monkeypatch.setattr(ev, "lr_optim_vec", [1e-5, 2e-5]); monkeypatch.setattr(ev, "iter", 2); monkeypatch.setattr(ev, "num_frames", 6)
+    monkeypatch.setattr(ev, "N_frame_max", 1500); monkeypatch.setattr(ev, "savePATH", str(tmp_path) + "/"); monkeypatch.setattr(ev, "generator", "hip")
+    monkeypatch.setattr(ev, "base_seed", 9)
+    name, d = ev.main()
+    assert "SERvsSNR_CMAflex_DP_4-QAM_" in name and np.isfinite(d["SER"]).all()
+    assert d["SER"][..., -1].mean() < 0.01 < d["SER"][..., 0].mean()              # converging already inside the first frame, clean at the end
+    assert set(io.loadmat(name)["dict"].dtype.names) >= {"SER", "Var_est", "var_real", "symb_step"}

@@ -260,3 +260,22 @@ def test_vaennbn_step_and_running_statistics(name):
     Ne = B * min(ns, 3)
     qe = oracle.nnbn_forward_eval(g["rx"][:, :Ne * sps], g[f"theta{ns}"], g[f"bn{ns}"], n, k1, k2, sps, np.float64)
     assert np.max(np.abs(qe - g["q_eval"])) < 5e-6
+
+
+# ------------------------------------------------------------------ row f4: constant-modulus baselines + CPE (G12)
+@pytest.mark.parametrize("tag,mode", [("cma", "CMA"), ("cmabatch", "CMAbatch"), ("cmaflex", "CMAflex")])
+def test_cma_variants(tag, mode):
+    """CMA / CMAbatch / CMAflex on one 700-symbol frame: outputs (incl. the wrapped first symbols), errors and updated taps."""
+    g = load_golden("G12_cma")
+    for dt, tol in ((np.float32, 2e-5), (np.float64, 5e-6)):
+        h = g["h0"].astype(dt).copy()
+        out, e = oracle.cma(g["rx"], h, float(g[f"lr_{tag}"]), int(g["sps"]), mode, int(g["batchlen"]), int(g["symb_step"]), 1.0, dt)
+        assert np.isfinite(g[f"{tag}_out"]).all()
+        assert relerr(out, g[f"{tag}_out"]) < tol and relerr(e, g[f"{tag}_e"]) < tol and relerr(h, g[f"{tag}_h"]) < tol
+    assert np.abs(g[f"{tag}_h"] - g["h0"]).max() > 1e-3                       # the taps did move
+
+
+def test_cpe_against_reference():
+    g = load_golden("G12_cma")
+    assert relerr(oracle.cpe(g["cpe_in"]), g["cpe_out"]) < 2e-6
+    assert np.abs(g["cpe_out"] - g["cpe_in"]).max() > 0.3                      # a real de-rotation with unwrapped drift

@@ -634,6 +634,52 @@ def capture_G11(sfun, awgn):
     save("G11_vaennbn_run", SER=t2n(SER), theta0=theta0.astype(np.float32), seed=np.int64(114), seconds=np.float64(time.time() - t0))
 
 
+# --------------------------------------------------------------------------
+# G12: row f4, constant-modulus baselines CMA / CMAbatch / CMAflex + CPE (shared_funcs.py:139-186, 341-488)
+# --------------------------------------------------------------------------
+def capture_G12(sfun, awgn):
+    import contextlib
+    import io
+    import func_CMA_DP_MQAM_shaping as ref_cma
+    import func_CMAbatch_DP_MQAM_shaping as ref_cmab
+    import func_CMAflex_DP_MQAM_shaping as ref_cmaf
+
+    sps, M_est, N = 2, 25, 700
+    h_est, h_channel, P, amp_levels, amps, pol, nu_sc, var, pow_mean = sfun.init("h0", "64-QAM", "cpu", 0.0, sps, M_est, 23)
+    with SeededRng(121):
+        rx, data, _ = sfun.generate_data_shaping(N, amps, 23, h_channel, P, pol, DP_DEFAULTS["symb_rate"], sps, DP_DEFAULTS["tau_cd"],
+                                                 DP_DEFAULTS["tau_pmd"], DP_DEFAULTS["phiIQ"], DP_DEFAULTS["theta"], "cpu")
+    res = dict(rx=t2n(rx), data=t2n(data), h0=t2n(h_est), lr_cma=np.float64(1e-3), lr_cmabatch=np.float64(5e-5), lr_cmaflex=np.float64(5e-6),
+               sps=np.int64(sps), M_est=np.int64(M_est), batchlen=np.int64(100),
+               symb_step=np.int64(10), amp_levels=t2n(amp_levels), var=t2n(var), nu_sc=np.float64(nu_sc))
+    with torch.no_grad():
+        for tag, fn in (("cma", lambda h: sfun.CMA(rx.clone(), 1, h, 1e-3, sps, True)),
+                        ("cmabatch", lambda h: sfun.CMAbatch(rx.clone(), 1, h, 5e-5, 100, sps, True)),
+                        ("cmaflex", lambda h: sfun.CMAflex(rx.clone(), 1, h, 5e-6, 100, 10, sps, True))):
+            out, h, e = fn(h_est.detach().clone())
+            res[f"{tag}_out"], res[f"{tag}_h"], res[f"{tag}_e"] = t2n(out), t2n(h), t2n(e)
+        # CPE on a phase-rotated noisy constellation with a slow drift (so that the unwrapping matters)
+        g = torch.Generator().manual_seed(5)
+        n = 3000
+        lev = amp_levels[torch.randint(0, 8, (2, 2, n), generator=g)]
+        phi = 0.9 + 2.2 * torch.arange(n) / n
+        y = torch.stack([torch.stack([lev[p, 0] * torch.cos(phi) - lev[p, 1] * torch.sin(phi), lev[p, 1] * torch.cos(phi) + lev[p, 0] * torch.sin(phi)])
+                         for p in range(2)]) + 0.02 * torch.randn(2, 2, n, generator=g)
+        res["cpe_in"], res["cpe_out"] = t2n(y), t2n(sfun.CPE(y.clone()))
+    save("G12_cma", **res)
+    runs = {}
+    # 4-QAM at 18 dB: the constant-modulus criterion converges within ~12 frames of 1500 symbols; step sizes per variant (the batch
+    # forms sum the increments of 100 symbols, CMAflex applies such a sum every 10 symbols)
+    for tag, mod_, seed, lr in (("cma", ref_cma, 122, 1e-3), ("cmabatch", ref_cmab, 123, 1e-4), ("cmaflex", ref_cmaf, 124, 1e-5)):
+        t0 = time.time()
+        with SeededRng(seed), contextlib.redirect_stdout(io.StringIO()):
+            SER, Var_est, var_ = mod_.processing("4-QAM", 2, 18, 0.0, 25, 0.006 * np.pi, np.pi / 10, lr, 100, 1500, 24, 10, "h0", 90e9, -26e-24,
+                                                 0.1e-12 * np.sqrt(1000), np.array([0.0314, 0.0314], dtype=np.complex64), 170)
+        print(f"   G12 {tag}: {time.time() - t0:.0f}s  SER last {SER[:, -1].tolist()}")
+        runs[f"{tag}_SER"], runs[f"{tag}_seed"], runs[f"{tag}_lr"] = t2n(SER), np.int64(seed), np.float64(lr)
+    save("G12_cma_runs", **runs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -642,7 +688,7 @@ def main():
     torch.set_num_threads(1)
     os.makedirs(OUT, exist_ok=True)
     sfun, awgn = _import_reference()
-    todo = [s for s in args.only.split(",") if s] or ["G0", "G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11"]
+    todo = [s for s in args.only.split(",") if s] or ["G0", "G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12"]
     for g in todo:
         print(f"[{g}]")
         if g == "G7":

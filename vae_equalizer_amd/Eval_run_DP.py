@@ -13,7 +13,7 @@ import torch
 mod = '64-QAM'  # modulation format:  {4,16,64}-QAM
 sps = 2         # oversampling factor in samples per symbol
 
-loss_type = 'VAE'  # 'VAE' 'VAEflex'   (the CMA baselines of the reference are out of scope here)
+loss_type = 'VAE'  # 'VAE' 'VAEflex' 'CMA' 'CMAbatch' 'CMAflex'
 channel = 'h0'     # optical channel with PMD and ISI caused by CD
 
 nu_vec = [0]  # [0] [0.0270955] [0.0872449] [0.1222578]: PCS entropies 6, 5.72, 4.6, 4.125 bit (PCS-64-QAM)
@@ -77,8 +77,15 @@ def main():
         runs = [DPRun(points[mine[k]][1]["SNR"], points[mine[k]][1]["nu"], points[mine[k]][1]["theta_diff"], points[mine[k]][1]["theta"],
                       points[mine[k]][1]["lr_optim"], points[mine[k]][1]["symb_rate"],
                       None if base_seed is None else base_seed + 1000 * mine[k]) for k in sel]
-        r = run_dp_batch(runs, mod, sps, M, batch_len, N_frame_max, num_frames, fs, channel, tau_cd, tau_pmd, phiIQ, N_lrhalf,
-                         flex=(loss_type == 'VAEflex'), device=device, generator=generator, verbose=False)
+        if loss_type in ('CMA', 'CMAbatch', 'CMAflex'):         # the constant-modulus baselines (:58-65)
+            from .cma_runs import run_cma_batch
+            r = run_cma_batch(runs, loss_type, mod, sps, M, batch_len, N_frame_max, num_frames, fs, channel, tau_cd, tau_pmd, phiIQ, N_lrhalf,
+                              device=device, generator=generator if generator in ("numpy", "hip") else "hip", verbose=False)
+        elif loss_type in ('VAE', 'VAEflex'):
+            r = run_dp_batch(runs, mod, sps, M, batch_len, N_frame_max, num_frames, fs, channel, tau_cd, tau_pmd, phiIQ, N_lrhalf,
+                             flex=(loss_type == 'VAEflex'), device=device, generator=generator, verbose=False)
+        else:
+            raise NameError(f"loss_type {loss_type!r}: the reference leaves `process` undefined (:56-65)")
         local[sel, 0:4] = r["SER"]
         local[sel, 4:6] = r["Var_est"]
         local[sel, 6:8] = r["var"].unsqueeze(-1).expand(-1, -1, num_frames)

@@ -13,7 +13,7 @@ import torch
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("VAEQ_LIB") or os.path.join(_PKG, "libvaeq_hip.so")   # VAEQ_LIB: A/B builds of the kernels (tools/build_variant.sh)
-SOURCES = ["vaeq_dp.hip", "vaeq_dp_wave.hip", "vaeq_awgn.hip", "vaeq_awgn_wave.hip", "vaeq_misc.hip", "vaeq_nn.hip", "vaeq_epilogue.hip", "vaeq_gen.hip"]
+SOURCES = ["vaeq_dp.hip", "vaeq_dp_wave.hip", "vaeq_awgn.hip", "vaeq_awgn_wave.hip", "vaeq_misc.hip", "vaeq_nn.hip", "vaeq_cma.hip", "vaeq_epilogue.hip", "vaeq_gen.hip"]
 HEADERS = ["vaeq_common.h", "vaeq_wave.h", "vaeq_validate.h"]
 _LIB = None
 
@@ -84,7 +84,7 @@ class NNArgs(C.Structure):
 
 # every symbol include/vaeq.h declares; tests check the library exports all of them
 EXPORTS = ["vaeq_dp_train", "vaeq_dp_lds_bytes", "vaeq_dp_resident_runs", "vaeq_soft_demap", "vaeq_dp_forward", "vaeq_dp_loss", "vaeq_dp_loss_bwd", "vaeq_dp_forward_bwd", "vaeq_dp_epilogue", "vaeq_dp_epilogue_ws_bytes", "vaeq_dp_epilogue_compact", "vaeq_gen_dp_tx", "vaeq_gen_dp_disperse", "vaeq_gen_dp_finish", "vaeq_gen_dp_frame", "vaeq_awgn_train",
-           "vaeq_awgn_lds_bytes", "vaeq_awgn_forward", "vaeq_awgn_validate", "vaeq_awgn_loss", "vaeq_gen_awgn", "vaeq_nn_train", "vaeq_nn_param_count", "vaeq_nn_lds_bytes", "vaeq_nn_forward", "vaeq_nn_validate", "vaeq_version", "vaeq_strerror"]
+           "vaeq_awgn_lds_bytes", "vaeq_awgn_forward", "vaeq_awgn_validate", "vaeq_awgn_loss", "vaeq_gen_awgn", "vaeq_nn_train", "vaeq_nn_param_count", "vaeq_nn_lds_bytes", "vaeq_nn_forward", "vaeq_nn_validate", "vaeq_cma", "vaeq_cpe", "vaeq_version", "vaeq_strerror"]
 
 
 def lib():
@@ -141,6 +141,10 @@ def lib():
         L.vaeq_nn_lds_bytes.argtypes = [C.c_int32] * 7
         L.vaeq_nn_forward.restype = C.c_int
         L.vaeq_nn_forward.argtypes = [C.c_int32, C.c_int64] + [C.c_int32] * 5 + [C.c_void_p] * 5
+        L.vaeq_cma.restype = C.c_int
+        L.vaeq_cma.argtypes = [C.c_int32, C.c_int64] + [C.c_int32] * 5 + [C.c_void_p, C.c_float] + [C.c_void_p] * 5
+        L.vaeq_cpe.restype = C.c_int
+        L.vaeq_cpe.argtypes = [C.c_int32, C.c_int64, C.c_int32] + [C.c_void_p] * 3
         L.vaeq_awgn_loss.restype = C.c_int
         L.vaeq_awgn_loss.argtypes = [C.c_int32] * 5 + [C.c_void_p] * 7
         L.vaeq_nn_validate.restype = C.c_int

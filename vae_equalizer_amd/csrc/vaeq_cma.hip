@@ -1,0 +1,210 @@
+// vaeq_cma.hip -- SURVEY row f4: the constant-modulus baselines of the DP scripts and their carrier phase estimation.
+//
+//   CMA (shared_funcs.py:341-383), CMAbatch (:385-433), CMAflex (:435-488): 2x2 real-coefficient butterfly FIR at 1 sample per
+//   symbol output, error e = R - |out|^2, stochastic-gradient tap update after every symbol (CMA) or, with the increments of the
+//   last `batchlen` symbols, whenever k % symb_step == 0 and k >= batchlen (CMAflex; CMAbatch = symb_step = batchlen).
+//   The algorithms are sequential in the symbol index by construction; the parallelism is over taps (lanes) and runs (waves):
+//   one 64-lane wave per run, lane t owns tap t of all 8 real filter rows h[out pol][in pol][re/im][t] (M <= 64).
+//   Reference quirks kept: the frame is scaled by 1 / mean|y|^2 over the ZERO-PADDED length (a power, :350-351), and symbol j lands
+//   at index k = (mh + sps j) / sps - mh, negative for the first symbols, i.e. wrapped to the end of out / e (:357).
+//   CPE (:139-186): Viterbi-Viterbi 4th-power estimate, 501-symbol zero-padded moving average, atan2 / 4, unwrapping of the pi/2
+//   jumps (the correction of sample n is the signed count of jumps before it), de-rotation; one workgroup per run.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vaeq.h"
+#include "vaeq_common.h"
+
+namespace vaeq {
+
+__global__ __launch_bounds__(64) void cma_kernel(int N, int sps, int M, int mode, int batchlen, int symb_step, const float *__restrict__ rx,
+                                                 float Rc, float *__restrict__ h, const float *__restrict__ lr, float *__restrict__ out,
+                                                 float *__restrict__ eout)
+{
+    extern __shared__ float ring[];                            // mode 1: [batchlen][8] = out[2][2], e[2], window start, unused
+    const int run = blockIdx.x, lane = threadIdx.x;
+    const int mh = M / 2, Lp = N + 2 * mh, K = N / sps;
+    const float *x = rx + (size_t)run * 4 * N;                 // [pol][re/im][N]
+    float pw = 0.f;
+    for (int i = lane; i < 4 * N; i += 64) pw = fmaf(x[i], x[i], pw);
+    const float inv = 1.0f / (wave_sum(pw) / (float)(2 * Lp));
+    const bool tap = lane < M;
+    float hr[2][2], hi[2][2];                                  // [out pol][in pol] at tap = lane
+    float *hrun = h + (size_t)run * 8 * M;
+#pragma unroll
+    for (int o = 0; o < 2; o++)
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            hr[o][p] = tap ? hrun[((o * 2 + p) * 2 + 0) * M + lane] : 0.f;
+            hi[o][p] = tap ? hrun[((o * 2 + p) * 2 + 1) * M + lane] : 0.f;
+        }
+    const float two_lr = 2.0f * lr[run];
+    float *orun = out + (size_t)run * 4 * K, *erun = eout ? eout + (size_t)run * 2 * K : nullptr;
+    auto window = [&](int i0, float (&yr)[2], float (&yi)[2]) { // padded sample i0 + lane of both polarisations, scaled
+        const int sx = i0 + lane - mh;
+        const bool ok = tap && sx >= 0 && sx < N;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            yr[p] = ok ? x[(p * 2 + 0) * N + sx] * inv : 0.f;
+            yi[p] = ok ? x[(p * 2 + 1) * N + sx] * inv : 0.f;
+        }
+    };
+    for (int j = 0; mh + sps * j < N + mh; j++) {
+        const int i0 = sps * j, kraw = (mh + sps * j) / sps - mh, k = kraw < 0 ? kraw + K : kraw;
+        float yr[2], yi[2];
+        window(i0, yr, yi);
+        float o_[2][2], e_[2];
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+            float re = 0.f, im = 0.f;
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                re = fmaf(yr[p], hr[o][p], re); re = fmaf(-yi[p], hi[o][p], re);
+                im = fmaf(yr[p], hi[o][p], im); im = fmaf(yi[p], hr[o][p], im);
+            }
+            o_[o][0] = wave_sum(re);
+            o_[o][1] = wave_sum(im);
+            e_[o] = Rc - o_[o][0] * o_[o][0] - o_[o][1] * o_[o][1];
+        }
+        if (lane == 0) {
+            orun[0 * K + k] = o_[0][0]; orun[1 * K + k] = o_[0][1]; orun[2 * K + k] = o_[1][0]; orun[3 * K + k] = o_[1][1];
+            if (erun) { erun[k * 2 + 0] = e_[0]; erun[k * 2 + 1] = e_[1]; }
+        }
+        if (mode == 0) {                                       // :371-381
+#pragma unroll
+            for (int o = 0; o < 2; o++)
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    hr[o][p] += two_lr * e_[o] * (o_[o][0] * yr[p] + o_[o][1] * yi[p]);
+                    hi[o][p] += two_lr * e_[o] * (o_[o][1] * yr[p] - o_[o][0] * yi[p]);
+                }
+        } else if (kraw >= 0) {
+            if (kraw >= batchlen && kraw % symb_step == 0) {   // :421 / :475: the last `batchlen` symbols, kraw itself excluded
+                float ar[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, ai[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+                for (int kk = kraw - batchlen; kk < kraw; kk++) {
+                    const float *s = ring + (size_t)(kk % batchlen) * 8;
+                    float wr[2], wi[2];
+                    window(__float_as_int(s[6]), wr, wi);
+#pragma unroll
+                    for (int o = 0; o < 2; o++)
+#pragma unroll
+                        for (int p = 0; p < 2; p++) {
+                            ar[o][p] = fmaf(s[o * 2] * wr[p] + s[o * 2 + 1] * wi[p], s[4 + o], ar[o][p]);
+                            ai[o][p] = fmaf(s[o * 2 + 1] * wr[p] - s[o * 2] * wi[p], s[4 + o], ai[o][p]);
+                        }
+                }
+#pragma unroll
+                for (int o = 0; o < 2; o++)
+#pragma unroll
+                    for (int p = 0; p < 2; p++) {
+                        hr[o][p] = fmaf(two_lr, ar[o][p], hr[o][p]);
+                        hi[o][p] = fmaf(two_lr, ai[o][p], hi[o][p]);
+                    }
+            }
+            __syncthreads();                                   // one wave per workgroup: every read of the ring is done ...
+            float *slot = ring + (size_t)(kraw % batchlen) * 8; // ... before symbol kraw replaces symbol kraw - batchlen in it
+            if (lane < 4) slot[lane] = o_[lane >> 1][lane & 1];
+            if (lane == 4) { slot[4] = e_[0]; slot[5] = e_[1]; slot[6] = __int_as_float(i0); }
+            __syncthreads();
+        }
+    }
+    if (tap) {
+#pragma unroll
+        for (int o = 0; o < 2; o++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                hrun[((o * 2 + p) * 2 + 0) * M + lane] = hr[o][p];
+                hrun[((o * 2 + p) * 2 + 1) * M + lane] = hi[o][p];
+            }
+    }
+}
+
+constexpr int CPE_NT = 256;
+
+__global__ __launch_bounds__(CPE_NT) void cpe_kernel(int N, int M_ma, const float *__restrict__ y, float *__restrict__ yout)
+{
+    extern __shared__ float phi[];                             // [N] phase estimate of one polarisation
+    __shared__ int cnt[CPE_NT + 1];
+    const int run = blockIdx.x, tid = threadIdx.x;
+    const int chunk = (N + CPE_NT - 1) / CPE_NT, n0 = tid * chunk, n1 = min(N, n0 + chunk), half = M_ma / 2;
+    for (int p = 0; p < 2; p++) {
+        const float *a = y + ((size_t)run * 2 + p) * 2 * N, *b = a + N;
+        auto pow4 = [&](int n, float &r4, float &i4) {        // (a + jb)^4 = a^4 - 6 a^2 b^2 + b^4 + j 4 (a^3 b - a b^3), zero outside
+            if (n < 0 || n >= N) { r4 = 0.f; i4 = 0.f; return; }
+            const float av = a[n], bv = b[n], a2 = av * av, b2 = bv * bv;
+            r4 = a2 * a2 - 6.0f * a2 * b2 + b2 * b2;
+            i4 = 4.0f * (a2 * av * bv - av * b2 * bv);
+        };
+        if (n0 < n1) {                                         // moving average over [n - half, n + half]: direct sum, then slide
+            float sr = 0.f, si = 0.f;
+            for (int m = n0 - half; m <= n0 + half; m++) { float r4, i4; pow4(m, r4, i4); sr += r4; si += i4; }
+            for (int n = n0; n < n1; n++) {
+                phi[n] = atan2f(si / (float)M_ma, -sr / (float)M_ma) * 0.25f;
+                float r4, i4, r5, i5;
+                pow4(n - half, r4, i4);
+                pow4(n + half + 1, r5, i5);
+                sr += r5 - r4; si += i5 - i4;
+            }
+        }
+        __syncthreads();
+        // unwrapping (:165-170): sample n is corrected by -pi/2 per upward jump (> pi/4) and +pi/2 per downward jump before it
+        int local = 0;
+        for (int n = max(n0, 1); n < n1; n++) {
+            const float d = phi[n] - phi[n - 1];
+            local += (d < -0.78539816339744831f) - (d > 0.78539816339744831f);
+        }
+        cnt[tid + 1] = local;
+        __syncthreads();
+        if (tid == 0) {
+            cnt[0] = 0;
+            for (int i = 1; i <= CPE_NT; i++) cnt[i] += cnt[i - 1];
+        }
+        __syncthreads();
+        int acc = cnt[tid];                                    // jumps before this thread's chunk
+        float prev = n0 > 0 && n0 < N ? phi[n0 - 1] : 0.f;
+        float *oa = yout + ((size_t)run * 2 + p) * 2 * N, *ob = oa + N;
+        for (int n = n0; n < n1; n++) {
+            const float ph = phi[n];
+            if (n > 0) {
+                const float d = ph - prev;
+                acc += (d < -0.78539816339744831f) - (d > 0.78539816339744831f);
+            }
+            prev = ph;
+            float sn, cs;
+            sincosf(ph + 1.5707963267948966f * (float)acc, &sn, &cs);
+            const float av = a[n], bv = b[n];
+            oa[n] = av * cs - bv * sn;
+            ob[n] = bv * cs + av * sn;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace vaeq
+
+extern "C" int vaeq_cma(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t mode, int32_t batchlen, int32_t symb_step, const float *rx,
+                        float R_mod, float *h, const float *lr, float *out, float *e, void *stream)
+{
+    if (R == 0) return VAEQ_OK;                                // an empty batch owns no memory: its pointers may be NULL
+    if (!rx || !h || !lr || !out) return VAEQ_ERR_NULL;
+    if (R < 0 || N <= 0 || N > 0x3fffffff || sps <= 0 || M <= 0 || (M & 1) == 0 || M > 63 || N / sps < 2 * M) return VAEQ_ERR_SHAPE;
+    if (!(mode == 0 || mode == 1) || (mode == 1 && (batchlen <= 0 || symb_step <= 0 || batchlen > 4096))) return VAEQ_ERR_SHAPE;
+    const size_t lds = mode == 1 ? (size_t)batchlen * 8 * sizeof(float) : 0;
+    hipLaunchKernelGGL(vaeq::cma_kernel, dim3(R), dim3(64), lds, reinterpret_cast<hipStream_t>(stream), (int)N, sps, M, mode, batchlen, symb_step, rx,
+                       R_mod, h, lr, out, e);
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}
+
+extern "C" int vaeq_cpe(int32_t R, int64_t N, int32_t M_ma, const float *y, float *y_out, void *stream)
+{
+    if (R == 0 || N == 0) return VAEQ_OK;
+    if (!y || !y_out) return VAEQ_ERR_NULL;
+    if (R < 0 || N < 0 || N > 32768 || M_ma <= 0 || (M_ma & 1) == 0) return VAEQ_ERR_SHAPE;   // the phase track of one polarisation lives in LDS
+    const size_t lds = (size_t)N * sizeof(float);
+    auto k = vaeq::cpe_kernel;
+    if (lds > 32 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return VAEQ_ERR_LDS;
+    hipLaunchKernelGGL(k, dim3(R), dim3(vaeq::CPE_NT), lds, reinterpret_cast<hipStream_t>(stream), (int)N, M_ma, y, y_out);
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}

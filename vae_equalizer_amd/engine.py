@@ -402,3 +402,34 @@ def awgn_loss(q, x, h, amp_levels, P=None):
         nat.check(nat.lib().vaeq_awgn_loss(R, B, x.shape[-1] // B, h.shape[-1], n, nat.ptr(q), nat.ptr(x), nat.ptr(h), nat.ptr(amp),
                                            nat.ptr(Pt), nat.ptr(loss), nat.current_stream(dev)), "vaeq_awgn_loss")
     return loss[0] if single else loss
+
+
+def cma(rx, h, lr, sps=2, mode="CMA", batch_len=100, symb_step=10, R_mod=1.0, want_e=True):
+    """CMA / CMAbatch / CMAflex (shared_funcs.py:341-488, vaeq_cma) for R runs: rx[R,2,2,N], h[R,2,2,2,M] (updated IN PLACE),
+    lr scalar or [R] -> (out[R,2,2,N//sps], e[R,N//sps,2] or None)."""
+    dev, R, N = rx.device, rx.shape[0], rx.shape[-1]
+    if tuple(rx.shape[1:3]) != (2, 2) or tuple(h.shape[:4]) != (R, 2, 2, 2) or not h.is_contiguous():
+        raise ValueError(f"rx must be [R,2,2,N] and h a contiguous [R,2,2,2,M], got {tuple(rx.shape)}, {tuple(h.shape)}")
+    m = {"CMA": 0, "CMAbatch": 1, "CMAflex": 1}[mode]
+    step = batch_len if mode == "CMAbatch" else symb_step
+    rx = rx.contiguous()
+    lr_t = _f32(lr, dev).expand(R).contiguous()
+    K = N // sps
+    out = torch.empty(R, 2, 2, K, dtype=torch.float32, device=dev)
+    e = torch.empty(R, K, 2, dtype=torch.float32, device=dev) if want_e else None
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().vaeq_cma(R, N, sps, h.shape[-1], m, int(batch_len), int(step), nat.ptr(rx), float(R_mod), nat.ptr(h),
+                                     nat.ptr(lr_t), nat.ptr(out), nat.ptr(e), nat.current_stream(dev)), "vaeq_cma")
+    return out, e
+
+
+def cpe(y, M_ma=501):
+    """Viterbi-Viterbi carrier phase estimation (shared_funcs.py:139-186, vaeq_cpe): y[R,2,2,N] (or [2,2,N]) -> corrected y."""
+    squeeze = y.dim() == 3
+    if squeeze:
+        y = y.unsqueeze(0)
+    y = y.contiguous().float()
+    out = torch.empty_like(y)
+    with torch.cuda.device(y.device):
+        nat.check(nat.lib().vaeq_cpe(y.shape[0], y.shape[-1], int(M_ma), nat.ptr(y), nat.ptr(out), nat.current_stream(y.device)), "vaeq_cpe")
+    return out[0] if squeeze else out

@@ -1,5 +1,5 @@
 """Host-side mirror of optical_DP_channel/shared_funcs.py for the VAE path (same names, argument order and
-return shapes), backed by the HIP library.  CMA / CPE baselines of that file are out of scope.
+return shapes), backed by the HIP library.
 
 What runs where:
   * ``init``, ``generate_data_shaping``            -- host (numpy), like the reference;
@@ -97,6 +97,37 @@ def loss_function_shaping(q, rx, h_est, amp_levels, P):
         from .autograd_ops import elbo_loss
         return elbo_loss(q, rx, h_est, amp_levels, P)
     return _engine.dp_loss(q, rx, h_est.detach(), amp_levels, P)
+
+
+# ------------------------------------------------------------------ row f4: constant-modulus baselines, reference signatures
+def _cma(mode, Rx, R, h, lr, batchlen, symb_step, sps, eval):
+    if not eval:
+        lr = 0.0                                                # the reference skips the update (:370); outputs are the same
+    hh = h.detach().reshape(1, 2, 2, 2, -1).contiguous().clone()
+    out, e = _engine.cma(Rx.reshape(1, 2, 2, -1), hh, lr, sps, mode, batchlen, symb_step, float(R))
+    with torch.no_grad():
+        h.copy_(hh[0])                                          # the reference updates h in place, too
+    return out[0], h, e[0]
+
+
+def CMA(Rx, R, h, lr, sps, eval):
+    """shared_funcs.py:341-383 on the device (vaeq_cma) -> (out[2,2,N//sps], h, e[N//sps,2])."""
+    return _cma("CMA", Rx, R, h, lr, 100, 10, sps, eval)
+
+
+def CMAbatch(Rx, R, h, lr, batchlen, sps, eval):
+    """shared_funcs.py:385-433."""
+    return _cma("CMAbatch", Rx, R, h, lr, batchlen, batchlen, sps, eval)
+
+
+def CMAflex(Rx, R, h, lr, batchlen, symb_step, sps, eval):
+    """shared_funcs.py:435-488."""
+    return _cma("CMAflex", Rx, R, h, lr, batchlen, symb_step, sps, eval)
+
+
+def CPE(y):
+    """Viterbi-Viterbi carrier phase estimation (shared_funcs.py:139-186) on the device (vaeq_cpe)."""
+    return _engine.cpe(y)
 
 
 # ------------------------------------------------------------------ per-frame epilogue, reference signatures
