@@ -123,27 +123,28 @@ constexpr int CPE_NT = 256;
 
 __global__ __launch_bounds__(CPE_NT) void cpe_kernel(int N, int M_ma, const float *__restrict__ y, float *__restrict__ yout)
 {
-    extern __shared__ float phi[];                             // [N] phase estimate of one polarisation
+    extern __shared__ float cpe_lds[];                         // [3][N]: 4th power (re, im) and the phase estimate of one polarisation
     __shared__ int cnt[CPE_NT + 1];
+    float *p4r = cpe_lds, *p4i = cpe_lds + N, *phi = cpe_lds + 2 * N;
     const int run = blockIdx.x, tid = threadIdx.x;
-    const int chunk = (N + CPE_NT - 1) / CPE_NT, n0 = tid * chunk, n1 = min(N, n0 + chunk), half = M_ma / 2;
+    // a thread owns one chunk of consecutive symbols; an ODD chunk length keeps the lanes' LDS accesses on different banks
+    const int chunk = ((N + CPE_NT - 1) / CPE_NT) | 1, n0 = min(N, tid * chunk), n1 = min(N, n0 + chunk), half = M_ma / 2;
     for (int p = 0; p < 2; p++) {
         const float *a = y + ((size_t)run * 2 + p) * 2 * N, *b = a + N;
-        auto pow4 = [&](int n, float &r4, float &i4) {        // (a + jb)^4 = a^4 - 6 a^2 b^2 + b^4 + j 4 (a^3 b - a b^3), zero outside
-            if (n < 0 || n >= N) { r4 = 0.f; i4 = 0.f; return; }
+        for (int n = tid; n < N; n += CPE_NT) {               // (a + jb)^4 = a^4 - 6 a^2 b^2 + b^4 + j 4 (a^3 b - a b^3), coalesced
             const float av = a[n], bv = b[n], a2 = av * av, b2 = bv * bv;
-            r4 = a2 * a2 - 6.0f * a2 * b2 + b2 * b2;
-            i4 = 4.0f * (a2 * av * bv - av * b2 * bv);
-        };
-        if (n0 < n1) {                                         // moving average over [n - half, n + half]: direct sum, then slide
+            p4r[n] = a2 * a2 - 6.0f * a2 * b2 + b2 * b2;
+            p4i[n] = 4.0f * (a2 * av * bv - av * b2 * bv);
+        }
+        __syncthreads();
+        if (n0 < n1) {                                         // moving average over [n - half, n + half] (zero outside): direct sum, then slide
             float sr = 0.f, si = 0.f;
-            for (int m = n0 - half; m <= n0 + half; m++) { float r4, i4; pow4(m, r4, i4); sr += r4; si += i4; }
+            for (int m = max(0, n0 - half); m <= min(N - 1, n0 + half); m++) { sr += p4r[m]; si += p4i[m]; }
             for (int n = n0; n < n1; n++) {
                 phi[n] = atan2f(si / (float)M_ma, -sr / (float)M_ma) * 0.25f;
-                float r4, i4, r5, i5;
-                pow4(n - half, r4, i4);
-                pow4(n + half + 1, r5, i5);
-                sr += r5 - r4; si += i5 - i4;
+                const int lo = n - half, hi_ = n + half + 1;
+                if (hi_ < N) { sr += p4r[hi_]; si += p4i[hi_]; }
+                if (lo >= 0) { sr -= p4r[lo]; si -= p4i[lo]; }
             }
         }
         __syncthreads();
@@ -162,16 +163,20 @@ __global__ __launch_bounds__(CPE_NT) void cpe_kernel(int N, int M_ma, const floa
         __syncthreads();
         int acc = cnt[tid];                                    // jumps before this thread's chunk
         float prev = n0 > 0 && n0 < N ? phi[n0 - 1] : 0.f;
-        float *oa = yout + ((size_t)run * 2 + p) * 2 * N, *ob = oa + N;
-        for (int n = n0; n < n1; n++) {
+        for (int n = n0; n < n1; n++) {                        // phi <- unwrapped phase (only this thread touches its chunk now)
             const float ph = phi[n];
             if (n > 0) {
                 const float d = ph - prev;
                 acc += (d < -0.78539816339744831f) - (d > 0.78539816339744831f);
             }
             prev = ph;
+            p4r[n] = ph + 1.5707963267948966f * (float)acc;    // the 4th-power buffer is spent: reuse it for the unwrapped phase
+        }
+        __syncthreads();
+        float *oa = yout + ((size_t)run * 2 + p) * 2 * N, *ob = oa + N;
+        for (int n = tid; n < N; n += CPE_NT) {               // de-rotation, coalesced
             float sn, cs;
-            sincosf(ph + 1.5707963267948966f * (float)acc, &sn, &cs);
+            sincosf(p4r[n], &sn, &cs);
             const float av = a[n], bv = b[n];
             oa[n] = av * cs - bv * sn;
             ob[n] = bv * cs + av * sn;
@@ -199,8 +204,8 @@ extern "C" int vaeq_cpe(int32_t R, int64_t N, int32_t M_ma, const float *y, floa
 {
     if (R == 0 || N == 0) return VAEQ_OK;
     if (!y || !y_out) return VAEQ_ERR_NULL;
-    if (R < 0 || N < 0 || N > 32768 || M_ma <= 0 || (M_ma & 1) == 0) return VAEQ_ERR_SHAPE;   // the phase track of one polarisation lives in LDS
-    const size_t lds = (size_t)N * sizeof(float);
+    if (R < 0 || N < 0 || N > 12800 || M_ma <= 0 || (M_ma & 1) == 0) return VAEQ_ERR_SHAPE;   // three N-float tracks of one polarisation live in LDS
+    const size_t lds = (size_t)3 * N * sizeof(float);
     auto k = vaeq::cpe_kernel;
     if (lds > 32 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
