@@ -188,6 +188,15 @@ int64_t vaeq_awgn_lds_bytes(int32_t B, int32_t sps, int32_t M, int32_t n_lev);
 int vaeq_awgn_loss(int32_t R, int32_t B, int32_t sps, int32_t M, int32_t n_lev, const float *q, const float *x, const float *h,
                    const float *amp, const float *P, float *loss, void *stream);
 
+/* Backward passes of the two stand-alone AWGN operators (for autograd wrappers, like vaeq_dp_loss_bwd / vaeq_dp_forward_bwd):
+ *   vaeq_awgn_loss_bwd   : g_up[R] -> gq[R][2*n_lev][B] = dL/dq, gh[R][2][M] = dL/dh   (P nullable as in vaeq_awgn_loss)
+ *   vaeq_awgn_forward_bwd: twoFIR.forward (:214-231): gq[R][2*n_lev][N] (+ nullable gy[R][2][N] on the un-normalised output)
+ *                          -> gW[R][2][M]; the forward is recomputed from x and W. */
+int vaeq_awgn_loss_bwd(int32_t R, int32_t B, int32_t sps, int32_t M, int32_t n_lev, const float *q, const float *x, const float *h,
+                       const float *amp, const float *P, const float *g_up, float *gq, float *gh, void *stream);
+int vaeq_awgn_forward_bwd(int32_t R, int32_t N, int32_t sps, int32_t M, int32_t n_lev, const float *x, const float *W, const float *amp,
+                          const float *amp_mean, const float *var, const float *gq, const float *gy, float *gW, void *stream);
+
 /* twoFIR.forward in eval mode (validation pass, func_VAELE_MQAM_shaping.py:311-313) on N symbols per run:
  * x[R][2][N*sps], W[R][2][M] -> q[R][2*n_lev][N] (nullable), y[R][2][N] (un-normalised). */
 int vaeq_awgn_forward(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, const float *x, const float *W,

@@ -73,3 +73,61 @@ def test_eval_mode_builds_no_graph():
     with torch.no_grad():
         q, out = net(torch.from_numpy(g["rx"][:, :, :200]).to(DEV), torch.from_numpy(g["amp_levels"]).to(DEV), torch.from_numpy(g["var"]).to(DEV), 0.0)
     assert not q.requires_grad and not out.requires_grad
+
+
+# ------------------------------------------------------------------ the AWGN pair (twoFIR / loss_function) and the VAE-NN loss
+@pytest.mark.parametrize("name", ["G4_awgn_16qam_cfg1", "G4_awgn_64qam_pcs_free10", "G4_awgn_4qam_small"])
+def test_awgn_operator_level_loop_matches_reference(name):
+    """The reference's AWGN loop (func_VAELE_MQAM_shaping.py:297-306) written against the mirrors: twoFIR -> loss_function -> backward ->
+    Adam(amsgrad).step with HIP forward/backward kernels reproduces the reference's gradients and first update."""
+    from vae_equalizer_amd import func_VAELE_MQAM_shaping as aw
+    g = load_golden(name)
+    B, sps, M = int(g["B"]), int(g["sps"]), int(g["M_est"])
+    x = torch.from_numpy(g["rx"][:, :B * sps]).to(DEV)
+    amp, P = torch.from_numpy(g["amp_levels"]).to(DEV), torch.from_numpy(g["P"]).to(DEV)
+    net = aw.twoFIR(M, sps).to(DEV)
+    with torch.no_grad():
+        net.conv_w.weight.copy_(torch.from_numpy(g["W0"]).reshape(1, 2, M))
+    h = torch.tensor(g["h0"], device=DEV, requires_grad=True)
+    opt = torch.optim.Adam(net.parameters(), lr=float(g["lr"]), amsgrad=True)
+    opt.add_param_group({"params": h})
+    opt.zero_grad()
+    q, out = net(x, amp, float(g["amp_mean"]), float(g["var"]))
+    loss = aw.loss_function(q, x, h, DEV, amp, P)
+    loss.backward()
+    assert abs(float(loss.detach()) - g["loss"][0]) / abs(g["loss"][0]) < 1e-5
+    assert relerr(net.conv_w.weight.grad.cpu().numpy().reshape(2, -1), g["gW0"].reshape(2, -1)) < 2e-4
+    assert relerr(h.grad.cpu().numpy(), g["gh0"]) < 2e-5
+    opt.step()
+    ok = np.abs(g["gW0"].reshape(2, -1)) > 1e-6 * np.abs(g["gW0"]).max()
+    assert np.max(np.abs(net.conv_w.weight.detach().cpu().numpy().reshape(2, -1) - g["W1"].reshape(2, -1))[ok]) < 1e-5
+    assert np.max(np.abs(h.detach().cpu().numpy() - g["h1"])) < 1e-5
+
+
+def test_vaenn_reference_loop_with_torch_net_and_hip_loss():
+    """func_VAENN_MQAM's loop with the reference's own kind of torch Net (Conv1d / ELU / softmax on the GPU) and the HIP loss_function
+    with autograd: the gradient of every parameter equals the reference's (G8)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from vae_equalizer_amd import func_VAENN_MQAM as nn_
+    g = load_golden("G8_vaenn_16qam_small")
+    B, sps, k1, k2, M = int(g["B"]), int(g["sps"]), int(g["k1"]), int(g["k2"]), int(g["M_est"])
+    n = len(g["amp_levels"])
+    C_ = 2 * n
+    o = np.cumsum([0, C_ * 2 * k1, C_, C_ * C_ * k2, C_, 2 * M])
+    th = torch.from_numpy(g["theta0"]).to(DEV)
+    fc1 = nn.Conv1d(2, C_, k1, padding=k1 // 2).to(DEV)
+    fc2 = nn.Conv1d(C_, C_, k2, padding=k2 // 2, stride=sps).to(DEV)
+    with torch.no_grad():
+        fc1.weight.copy_(th[o[0]:o[1]].reshape(C_, 2, k1)); fc1.bias.copy_(th[o[1]:o[2]])
+        fc2.weight.copy_(th[o[2]:o[3]].reshape(C_, C_, k2)); fc2.bias.copy_(th[o[3]:o[4]])
+    h = th[o[4]:o[5]].reshape(2, M).clone().requires_grad_(True)
+    x = torch.from_numpy(g["rx"][:, :B * sps]).to(DEV)
+    a2 = fc2(F.elu(fc1(x[None])))[0]
+    q = torch.cat([torch.softmax(a2[:n], 0), torch.softmax(a2[n:], 0)])
+    loss = nn_.loss_function(q, x, h, DEV, torch.from_numpy(g["amp_levels"]).to(DEV))
+    loss.backward()
+    assert abs(float(loss.detach()) - g["loss"][0]) / abs(g["loss"][0]) < 1e-5
+    got = torch.cat([fc1.weight.grad.reshape(-1), fc1.bias.grad, fc2.weight.grad.reshape(-1), fc2.bias.grad, h.grad.reshape(-1)]).cpu().numpy()
+    for a, b in zip(o[:-1], o[1:]):
+        assert relerr(got[a:b], g["g0"][a:b]) < 5e-4, (a, b)

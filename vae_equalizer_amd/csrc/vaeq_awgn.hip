@@ -556,6 +556,181 @@ __global__ __launch_bounds__(256) void awgn_loss_kernel(int B, int sps, int M, c
     }
 }
 
+
+// Backward of the stand-alone AWGN ELBO (for the autograd wrappers; the fused training kernels do not use it):
+// g_up[R] = upstream d/dloss -> gq[R][2n][B] = dL/dq, gh[R][2][M] = dL/dh.  P == nullptr: the VAE-NN form (entropy).
+template <int NLEV>
+__global__ __launch_bounds__(256) void awgn_loss_bwd_kernel(int B, int sps, int M, const float *__restrict__ q, const float *__restrict__ x,
+                                                            const float *__restrict__ h, const float *__restrict__ amp_g,
+                                                            const float *__restrict__ P, const float *__restrict__ g_up, float *__restrict__ gq,
+                                                            float *__restrict__ gh)
+{
+    extern __shared__ float4 smem4[];
+    float *sm = reinterpret_cast<float *>(smem4);
+    __shared__ float red[64];
+    __shared__ float hs[2 * 64], VS[64];
+    const int run = blockIdx.x, tid = threadIdx.x;
+    const int L = B * sps, mh = M / 2, Mh = 2 * mh, nm = L - Mh;
+    float *mu = sm, *vr = sm + 2 * B, *es = sm + 4 * B;       // es[2][nm]
+    float amp[NLEV], invP[NLEV];
+#pragma unroll
+    for (int i = 0; i < NLEV; i++) { amp[i] = amp_g[i]; invP[i] = P ? 1.0f / P[(size_t)run * NLEV + i] : 1.0f; }
+    for (int i = tid; i < 2 * M; i += 256) hs[i] = h[(size_t)run * 2 * M + i];
+    const float *qr = q + (size_t)run * 2 * NLEV * B, *x0 = x + (size_t)run * 2 * L, *x1 = x0 + L;
+    for (int it = tid; it < 2 * B; it += 256) {
+        const int c = it / B, n = it - c * B;
+        float e1 = 0.f, e2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NLEV; i++) e1 = fmaf(amp[i], qr[(size_t)(c * NLEV + i) * B + n], e1);
+#pragma unroll
+        for (int i = 0; i < NLEV; i++) { const float d = amp[i] - e1; e2 = fmaf(qr[(size_t)(c * NLEV + i) * B + n] * d, d, e2); }
+        mu[it] = e1; vr[it] = e2;
+    }
+    __syncthreads();
+    float se = 0.f;
+    for (int t = tid; t < nm; t += 256) {
+        float dr = 0.f, di = 0.f;
+        for (int j = (t + Mh) % sps; j <= Mh; j += sps) {
+            const int np = (t + Mh - j) / sps;
+            const float a_ = mu[np], b_ = mu[B + np], c_ = hs[j], d_ = hs[M + j];
+            dr = fmaf(c_, a_, dr); dr = fmaf(-d_, b_, dr);
+            di = fmaf(c_, b_, di); di = fmaf(d_, a_, di);
+        }
+        const float er = x0[mh + t] - dr, ei = x1[mh + t] - di;
+        es[t] = er; es[nm + t] = ei;
+        se += er * er + ei * ei;
+    }
+    for (int j = tid; j < M; j += 256) {
+        const int lo = (Mh - j + sps - 1) / sps, hi_ = (nm - 1 + Mh - j) / sps;
+        float acc = 0.f;
+        for (int np = lo; np <= hi_; np++) acc += vr[np] + vr[B + np];
+        VS[j] = acc;
+    }
+    block_reduce3<256>(se, 0.f, 0.f, red);
+    float C = red[0];
+    for (int j = 0; j < M; j++) C = fmaf(hs[j] * hs[j] + hs[M + j] * hs[M + j], VS[j], C);
+    const float up = g_up[run], gC = up * (float)nm / C;
+    for (int j = tid; j < M; j += 256) {
+        const int lo = (Mh - j + sps - 1) / sps, hi_ = (nm - 1 + Mh - j) / sps;
+        float ar = 0.f, ai = 0.f;
+        for (int np = lo; np <= hi_; np++) {
+            const int t = np * sps - Mh + j;
+            const float a_ = es[t], b_ = es[nm + t], c_ = mu[np], d_ = mu[B + np];
+            ar = fmaf(a_, c_, ar); ar = fmaf(b_, d_, ar);
+            ai = fmaf(b_, c_, ai); ai = fmaf(-a_, d_, ai);
+        }
+        gh[(size_t)run * 2 * M + j] = gC * (-2.0f * ar + 2.0f * hs[j] * VS[j]);
+        gh[(size_t)run * 2 * M + M + j] = gC * (-2.0f * ai + 2.0f * hs[M + j] * VS[j]);
+    }
+    float *gqr = gq + (size_t)run * 2 * NLEV * B;
+    for (int n = tid; n < B; n += 256) {
+        const int sx = n * sps;
+        const int jlo = max(0, Mh - sx), jhi = min(Mh, nm - 1 + Mh - sx);
+        const float *er = es + (sx - Mh), *ei = er + nm;
+        float pr = 0.f, pi = 0.f, ph = 0.f;
+        for (int j = jlo; j <= jhi; j++) {
+            const float a_ = er[j], b_ = ei[j], c_ = hs[j], d_ = hs[M + j];
+            pr = fmaf(a_, c_, pr); pr = fmaf(b_, d_, pr);
+            pi = fmaf(b_, c_, pi); pi = fmaf(-a_, d_, pi);
+            ph = fmaf(c_, c_, ph); ph = fmaf(d_, d_, ph);
+        }
+        const float gv = gC * ph;
+        const bool inr = (n >= mh) && (n < B - mh);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const float gmu = -2.0f * gC * (c ? pi : pr) - 2.0f * mu[c * B + n] * gv;
+#pragma unroll
+            for (int i = 0; i < NLEV; i++) {
+                const float qq = qr[(size_t)(c * NLEV + i) * B + n];
+                float g = amp[i] * gmu + amp[i] * amp[i] * gv;
+                if (inr) { const float r = qq * invP[i], re = r + 1e-12f; g += up * (__logf(re) + r / re); }
+                gqr[(size_t)(c * NLEV + i) * B + n] = g;
+            }
+        }
+    }
+}
+
+// Backward of twoFIR.forward (func_VAELE_MQAM_shaping.py:214-231): upstream gq[R][2n][N] (and optionally gy on the un-normalised
+// output) -> gW[R][2][M].  Recomputes the forward (y, mean |y|, yhat, q), then softmax backward with dz_i/dyhat = -2 (yhat - a_i) / var,
+// the normalisation's Jacobian and the tap correlation.  One workgroup per run, y and dL/dy in LDS.
+template <int NLEV>
+__global__ __launch_bounds__(256) void awgn_forward_bwd_kernel(int N, int sps, int M, const float *__restrict__ x, const float *__restrict__ W,
+                                                               const float *__restrict__ amp_g, const float *__restrict__ amp_mean,
+                                                               const float *__restrict__ var, const float *__restrict__ gq,
+                                                               const float *__restrict__ gy_up, float *__restrict__ gW)
+{
+    extern __shared__ float4 smem4[];
+    float *ys = reinterpret_cast<float *>(smem4), *gys = ys + 2 * N;
+    __shared__ float Ws[2 * 64];
+    __shared__ float red[64];
+    const int run = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < 2 * M; i += 256) Ws[i] = W[(size_t)run * 2 * M + i];
+    __syncthreads();
+    const int L = N * sps, pad = (M - 1) / 2;
+    const float *x0 = x + (size_t)run * 2 * L, *x1 = x0 + L;
+    float sa0 = 0.f, sa1 = 0.f;
+    for (int n = tid; n < N; n += 256) {
+        float yI = 0.f, yQ = 0.f;
+        for (int k = 0; k < M; k++) {
+            const int sx = n * sps + k - pad;
+            if (sx < 0 || sx >= L) continue;
+            const float a_ = x0[sx], b_ = x1[sx];
+            yI = fmaf(Ws[k], a_, yI); yI = fmaf(Ws[M + k], b_, yI);
+            yQ = fmaf(Ws[k], b_, yQ); yQ = fmaf(-Ws[M + k], a_, yQ);
+        }
+        ys[n] = yI; ys[N + n] = yQ;
+        sa0 += fabsf(yI); sa1 += fabsf(yQ);
+    }
+    block_reduce3<256>(sa0, sa1, 0.f, red);
+    float amp[NLEV];
+#pragma unroll
+    for (int i = 0; i < NLEV; i++) amp[i] = amp_g[i];
+    const float A = amp_mean[run], ivar = 1.0f / var[run];
+    const float m0 = red[0] / (float)N, m1 = red[1] / (float)N;
+    __syncthreads();
+    const float *gqr = gq + (size_t)run * 2 * NLEV * N;
+    float dt0 = 0.f, dt1 = 0.f;
+    for (int it = tid; it < 2 * N; it += 256) {
+        const int c = it / N, n = it - c * N;
+        const float yh = ys[it] / (c ? m1 : m0) * A;
+        float z[NLEV], zmax = -3.0e38f, ssum = 0.f, dot = 0.f, g = 0.f;
+#pragma unroll
+        for (int i = 0; i < NLEV; i++) { const float d = yh - amp[i]; z[i] = -(d * d * ivar); zmax = fmaxf(zmax, z[i]); }
+#pragma unroll
+        for (int i = 0; i < NLEV; i++) { z[i] = __expf(z[i] - zmax); ssum += z[i]; }
+#pragma unroll
+        for (int i = 0; i < NLEV; i++) { z[i] /= ssum; dot = fmaf(z[i], gqr[(size_t)(c * NLEV + i) * N + n], dot); }
+#pragma unroll
+        for (int i = 0; i < NLEV; i++) g = fmaf(z[i] * (gqr[(size_t)(c * NLEV + i) * N + n] - dot), -2.0f * (yh - amp[i]) * ivar, g);
+        gys[it] = g;                                           // dL/dyhat
+        if (c) dt1 = fmaf(g, ys[it], dt1); else dt0 = fmaf(g, ys[it], dt0);
+    }
+    block_reduce3<256>(dt0, dt1, 0.f, red);
+    {
+        const float s0_ = A / m0, s1_ = A / m1, k0_ = red[0] * A / (m0 * m0) / (float)N, k1_ = red[1] * A / (m1 * m1) / (float)N;
+        __syncthreads();
+        for (int n = tid; n < N; n += 256) {                   // normalisation backward (:228) + the upstream gradient on `out`
+            const float yI = ys[n], yQ = ys[N + n];
+            const float sgI = (float)(yI > 0.f) - (float)(yI < 0.f), sgQ = (float)(yQ > 0.f) - (float)(yQ < 0.f);
+            gys[n] = gys[n] * s0_ - k0_ * sgI + (gy_up ? gy_up[(size_t)run * 2 * N + n] : 0.f);
+            gys[N + n] = gys[N + n] * s1_ - k1_ * sgQ + (gy_up ? gy_up[(size_t)run * 2 * N + N + n] : 0.f);
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < M; k += 256) {                       // dL/dW0[k] = sum gI x0 + gQ x1, dL/dW1[k] = sum gI x1 - gQ x0
+        float g0 = 0.f, g1 = 0.f;
+        for (int n = 0; n < N; n++) {
+            const int sx = n * sps + k - pad;
+            if (sx < 0 || sx >= L) continue;
+            const float a_ = gys[n], b_ = gys[N + n], c_ = x0[sx], d_ = x1[sx];
+            g0 = fmaf(a_, c_, g0); g0 = fmaf(b_, d_, g0);
+            g1 = fmaf(a_, d_, g1); g1 = fmaf(-b_, c_, g1);
+        }
+        gW[(size_t)run * 2 * M + k] = g0;
+        gW[(size_t)run * 2 * M + M + k] = g1;
+    }
+}
+
 template <int NT, int NLEV>
 static int launch_awgn(const vaeq_awgn_args &a, size_t lds, hipStream_t st)
 {
@@ -672,5 +847,59 @@ extern "C" int vaeq_awgn_loss(int32_t R, int32_t B, int32_t sps, int32_t M, int3
     default: return VAEQ_ERR_SHAPE;
     }
 #undef VAEQ_AL
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}
+
+extern "C" int vaeq_awgn_loss_bwd(int32_t R, int32_t B, int32_t sps, int32_t M, int32_t n_lev, const float *q, const float *x, const float *h,
+                                  const float *amp, const float *P, const float *g_up, float *gq, float *gh, void *stream)
+{
+    if (R == 0) return VAEQ_OK;                                // an empty batch owns no memory: its pointers may be NULL
+    if (!q || !x || !h || !amp || !g_up || !gq || !gh) return VAEQ_ERR_NULL;
+    if (R < 0 || B <= 0 || sps <= 0 || M <= 0 || (M & 1) == 0 || M > 63 || (int64_t)B * sps - 2 * (M / 2) <= 0 || B <= 2 * (M / 2)) return VAEQ_ERR_SHAPE;
+    const size_t lds = ((size_t)4 * B + 2 * ((size_t)B * sps - 2 * (M / 2))) * sizeof(float);
+    if (lds > 150 * 1024) return VAEQ_ERR_LDS;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define VAEQ_ALB(NL)                                                                                                                    \
+    {                                                                                                                                   \
+        auto k = vaeq::awgn_loss_bwd_kernel<NL>;                                                                                        \
+        if (lds > 32 * 1024 &&                                                                                                          \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
+            return VAEQ_ERR_LDS;                                                                                                        \
+        hipLaunchKernelGGL(k, dim3(R), dim3(256), lds, st, B, sps, M, q, x, h, amp, P, g_up, gq, gh);                                   \
+    }
+    switch (n_lev) {
+    case 2: VAEQ_ALB(2) break;
+    case 4: VAEQ_ALB(4) break;
+    case 8: VAEQ_ALB(8) break;
+    default: return VAEQ_ERR_SHAPE;
+    }
+#undef VAEQ_ALB
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}
+
+extern "C" int vaeq_awgn_forward_bwd(int32_t R, int32_t N, int32_t sps, int32_t M, int32_t n_lev, const float *x, const float *W, const float *amp,
+                                     const float *amp_mean, const float *var, const float *gq, const float *gy, float *gW, void *stream)
+{
+    if (R == 0) return VAEQ_OK;                                // an empty batch owns no memory: its pointers may be NULL
+    if (!x || !W || !amp || !amp_mean || !var || !gq || !gW) return VAEQ_ERR_NULL;
+    if (R < 0 || N <= 0 || sps <= 0 || M <= 0 || (M & 1) == 0 || M > 63) return VAEQ_ERR_SHAPE;
+    const size_t lds = (size_t)4 * N * sizeof(float);
+    if (lds > 150 * 1024) return VAEQ_ERR_LDS;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define VAEQ_AFB(NL)                                                                                                                    \
+    {                                                                                                                                   \
+        auto k = vaeq::awgn_forward_bwd_kernel<NL>;                                                                                     \
+        if (lds > 32 * 1024 &&                                                                                                          \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
+            return VAEQ_ERR_LDS;                                                                                                        \
+        hipLaunchKernelGGL(k, dim3(R), dim3(256), lds, st, N, sps, M, x, W, amp, amp_mean, var, gq, gy, gW);                            \
+    }
+    switch (n_lev) {
+    case 2: VAEQ_AFB(2) break;
+    case 4: VAEQ_AFB(4) break;
+    case 8: VAEQ_AFB(8) break;
+    default: return VAEQ_ERR_SHAPE;
+    }
+#undef VAEQ_AFB
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }

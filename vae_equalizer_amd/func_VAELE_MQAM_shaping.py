@@ -30,7 +30,8 @@ generate_data = ch.generate_data                       # (:39-61) host restateme
 
 class twoFIR(torch.nn.Module):
     """Complex FIR + output normalisation + per-axis soft demapper (:206-231); ``conv_w.weight`` keeps the reference's
-    Conv1d(2, 1, M) layout.  forward() runs vaeq_awgn_forward (inference; training goes through engine.AWGNEngine)."""
+    Conv1d(2, 1, M) layout.  forward() runs vaeq_awgn_forward; with autograd enabled its backward is the HIP kernel vaeq_awgn_forward_bwd (the fused
+    engine.AWGNEngine is how processing() trains)."""
 
     def __init__(self, M_est, sps):
         super().__init__()
@@ -39,6 +40,9 @@ class twoFIR(torch.nn.Module):
         torch.nn.init.dirac_(self.conv_w.weight)
 
     def forward(self, x, amp_levels, amp_mean, var):
+        if torch.is_grad_enabled() and self.conv_w.weight.requires_grad:
+            from .autograd_ops import awgn_fir_demap              # HIP forward + HIP backward (vaeq_awgn_forward / _bwd)
+            return awgn_fir_demap(x, self.conv_w.weight, amp_levels, amp_mean, var, self.sps)
         W = self.conv_w.weight.detach()
         eng = AWGNEngine(1, W.shape[-1], amp_levels, np.full(len(amp_levels), 1.0 / len(amp_levels)), float(amp_mean), float(var), x.device,
                          self.sps)
@@ -48,7 +52,10 @@ class twoFIR(torch.nn.Module):
 
 
 def loss_function(q, rx, h, device, amp_levels, P):
-    """ELBO of one minibatch (:63-95), value only: q[2n,B], rx[2,B*sps], h[2,M] (HIP: vaeq_awgn_loss)."""
+    """ELBO of one minibatch (:63-95): q[2n,B], rx[2,B*sps], h[2,M] (HIP: vaeq_awgn_loss; with autograd also vaeq_awgn_loss_bwd)."""
+    if torch.is_grad_enabled() and (q.requires_grad or h.requires_grad):
+        from .autograd_ops import awgn_elbo_loss
+        return awgn_elbo_loss(q, rx, h, amp_levels, P)
     from .engine import awgn_loss
     return awgn_loss(q, rx, h.detach(), amp_levels, P)
 

@@ -49,7 +49,10 @@ def generate_data(N, M, constellation, SNR, h_channel, sps, device, rng=None):
 
 
 def loss_function(q, rx, h, device, amp_levels):
-    """ELBO of one minibatch (:63-95), value only: q[2n,B], rx[2,B*sps], h[2,M] (HIP: vaeq_awgn_loss with the entropy term)."""
+    """ELBO of one minibatch (:63-95): q[2n,B], rx[2,B*sps], h[2,M] (HIP: vaeq_awgn_loss with the entropy term; differentiable)."""
+    if torch.is_grad_enabled() and (q.requires_grad or h.requires_grad):
+        from .autograd_ops import awgn_elbo_loss
+        return awgn_elbo_loss(q, rx, h, amp_levels, None)
     from .engine import awgn_loss
     return awgn_loss(q, rx, h.detach(), amp_levels, None)
 
