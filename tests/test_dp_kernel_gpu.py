@@ -195,9 +195,11 @@ def test_error_codes():
         eng.train(torch.zeros(1, 1, 2, 2, 400), 100, 1, 1e-3)
 
 
-@pytest.mark.parametrize("B,M,n", [(100, 25, 8), (64, 25, 4), (128, 13, 2), (50, 9, 8), (26, 25, 8), (100, 31, 8), (80, 17, 4), (60, 21, 2)])
+@pytest.mark.parametrize("B,M,n", [(100, 25, 8), (64, 25, 4), (128, 13, 2), (50, 9, 8), (26, 25, 8), (100, 31, 8), (80, 17, 4), (60, 21, 2),
+                                   (130, 25, 8), (200, 25, 8), (256, 13, 2), (258, 31, 4), (300, 9, 8), (384, 21, 2), (512, 25, 8), (154, 17, 4)])
 def test_wave_kernel_equals_generic_kernel(B, M, n):
-    """The wave-per-run fast path (threads=1) and the generic kernel (threads=256) agree on ragged shapes, 5 free steps, R=9."""
+    """The wave-per-run fast path (threads=1; one wavefront per run up to B = 128, two up to 256, four up to 512) and the generic
+    kernel (threads=256) agree on ragged shapes, 5 free steps, R=9."""
     from vae_equalizer_amd.engine import DPEngine
     rng = np.random.default_rng(B + M)
     R, sps, steps = 9, 2, 5

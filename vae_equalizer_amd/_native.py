@@ -13,8 +13,8 @@ import torch
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("VAEQ_LIB") or os.path.join(_PKG, "libvaeq_hip.so")   # VAEQ_LIB: A/B builds of the kernels (tools/build_variant.sh)
-SOURCES = ["vaeq_dp.hip", "vaeq_dp_wave.hip", "vaeq_awgn.hip", "vaeq_awgn_wave.hip", "vaeq_misc.hip", "vaeq_nn.hip", "vaeq_cma.hip", "vaeq_epilogue.hip", "vaeq_gen.hip"]
-HEADERS = ["vaeq_common.h", "vaeq_wave.h", "vaeq_validate.h"]
+SOURCES = ["vaeq_dp.hip", "vaeq_dp_wave.hip", "vaeq_dp_wave_mw.hip", "vaeq_awgn.hip", "vaeq_awgn_wave.hip", "vaeq_misc.hip", "vaeq_nn.hip", "vaeq_cma.hip", "vaeq_epilogue.hip", "vaeq_gen.hip"]
+HEADERS = ["vaeq_common.h", "vaeq_wave.h", "vaeq_validate.h", "vaeq_dp_wave_kernel.h"]
 _LIB = None
 
 
@@ -30,8 +30,28 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(_ROOT, "include"),
-           "-I", csrc, *srcs, "-lhipfft", "-o", LIB_PATH]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(_ROOT, "include"), "-I", csrc]
+    obj_dir = os.path.join(_PKG, "_obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    hdr_time = max(os.path.getmtime(d) for d in deps[len(srcs):])
+
+    def compile_one(src):                                      # one translation unit -> one object, rebuilt only when stale
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            cmd = [hipcc, *flags, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        return obj
+
+    from concurrent.futures import ThreadPoolExecutor
+    try:
+        jobs = len(os.sched_getaffinity(0))
+    except AttributeError:
+        jobs = os.cpu_count() or 1
+    with ThreadPoolExecutor(max(1, min(jobs, len(srcs)))) as pool:  # the translation units compile side by side
+        objs = list(pool.map(compile_one, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-lhipfft", "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1,0 +1,792 @@
+// vaeq_dp_wave_kernel.h -- wave-per-run fast path of the DP VAE-LE / VAEflex training loop (gfx950).
+//
+// One 64-lane wavefront = one run (B <= 128); no workgroup barriers, everything between HBM and the taps lives in LDS/VGPRs.
+// Same math as vaeq_dp.hip (see the derivation there and in DESIGN.md); what changes is the mapping:
+//
+//   * lane l owns the symbol pair (2l, 2l+1) of the minibatch (B <= 128): FIR, soft demap, the per-symbol moments
+//     (kept in registers until the backward pass) and dL/dy are all done by the owning lane; q and y leave as one
+//     8-byte store per lane and row (400 contiguous bytes per row and step at B = 100).
+//   * every convolution-shaped phase is register-blocked over that pair and over both outputs: a tap quad is read once
+//     (LDS broadcast) and feeds 16 FMAs
+//     (FIR:  y[n]      = sum_k w[k] x[2n+k],
+//      dL/dU[n]        = sum_j e[2n+j] conj(h[j])    -- the same shape on the residual e,
+//      D[t], t=4l..4l+3: the zero-stuffed convolution, written as two polyphase symbol-rate FIRs on mu).
+//   * sample-rate arrays (x, e) are stored 4-way polyphase in LDS (index c -> [c & 3][c >> 2]) and the symbol-rate mu
+//     2-way, so that the stride-4 / stride-2 accesses of consecutive lanes hit consecutive 8-byte LDS words.
+//   * the two correlation-shaped gradients (dL/dh: 100 outputs x 88 terms, dL/dw: 100 x 100) are laid out as
+//     lane = (tap, half of the sum range); halves are combined with one cross-half shuffle; the lane that ends up
+//     with a gradient also owns that parameter's Adam moments (registers) and writes the updated tap to LDS.
+//   * reductions (sum |e|^2, KL) are fixed-order xor butterflies: bitwise reproducible.
+//
+// Supported here: sps == 2, B even, 2*(M/2)+2 <= B <= 512, M in {9, 13, 17, 21, 25, 31}; everything else takes the
+// generic kernel of vaeq_dp.hip.  BT > 0 bakes the minibatch length into the kernel (all LDS offsets immediate).
+// B <= 128 runs as ONE wavefront per run (NW = 1, described above); 128 < B <= 256 as two and B <= 512 as four wavefronts
+// per run (NW = 2, 4: same code, thread 64 wv + lane owns the pair, see dp_wave_kernel).  Instantiated in vaeq_dp_wave.hip
+// (NW = 1) and vaeq_dp_wave_mw.hip (NW = 2, 4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vaeq.h"
+#include "vaeq_common.h"
+#include "vaeq_wave.h"
+
+namespace vaeq {
+
+struct WaveLayout {
+    int Lph, Uph;                                      // float2 per polyphase component of x/e and of mu
+    int X, E, U, PSv, W, H, PSh, VS, RED, XG, total;   // byte offsets (the dL/dy buffer aliases U)
+};
+
+__host__ __device__ inline WaveLayout wave_layout(int B, int M, int NW = 1)
+{
+    WaveLayout l;
+    const int len = 2 * B + M - 1;                     // L + 2*mh samples incl. zero halo
+    const int lph = wave_lph(len);
+    l.Lph = lph;
+    l.Uph = B / 2 + 1;
+    int o = 0;
+    auto take = [&](int bytes) { int r = o; o += (bytes + 15) & ~15; return r; };
+    l.X = take(2 * 4 * lph * 8);
+    l.E = take(2 * 4 * lph * 8);
+    const int ubytes = 2 * 2 * l.Uph * 8, gbytes = 2 * B * 8;
+    l.U = take(ubytes > gbytes ? ubytes : gbytes);
+    l.PSv = take(2 * (B + 1) * 4);
+    l.W = take(2 * M * 16);
+    l.H = take(2 * 2 * (M + 1) * 8);                   // one zero pad tap per (chi, nu): j = M
+    l.PSh = take(2 * (M + 1) * 4);
+    l.VS = take(2 * M * 4);
+    l.RED = take(NW > 1 ? 64 * 4 : 0);                 // NW > 1: cross-wave scan offsets and sums
+    l.XG = take((NW - 1) * 4 * 64 * 4);                // ... and the tap-gradient partial sums of waves 1..NW-1
+    l.total = o;
+    return l;
+}
+
+// y[sym] += sum_k taps[k] * x[4l + 2*sym + k] for the lane's symbol pair, one input polarisation (FIR) -- or the same
+// shape on the residual with conjugated channel taps (dL/dU).  xp = phase-0 pointer of the lane (slot = lane).
+//   FIR : T = float4 tap quads (o0.re, o0.im, o1.re, o1.im), acc[sym][o]  += w * x
+//   DU  : two float2 tap arrays (nu = 0, 1),                   acc[sym][nu] += e * conj(h)
+template <int M, bool CONJ>
+__device__ __forceinline__ void pair_fir(cacc (&acc)[2][2], const float2 *xp, int Lph, const float4 *wq, const float2 *ha,
+                                         const float2 *hb)
+{
+    auto tap = [&](int k, float &ar, float &ai, float &br, float &bi) {
+        if (CONJ) {
+            const float2 a_ = ha[k], b_ = hb[k];
+            ar = a_.x; ai = a_.y; br = b_.x; bi = b_.y;
+        } else {
+            const float4 w = wq[k];
+            ar = w.x; ai = w.y; br = w.z; bi = w.w;
+        }
+    };
+    auto mac = [&](int sy, float2 x, float ar, float ai, float br, float bi) {
+        cmac(acc[sy][0], ar, ai, x);                   // FIR: w * x;  dL/dU: e * conj(h) -- same accumulation, different final combine
+        cmac(acc[sy][1], br, bi, x);
+    };
+    constexpr int G = M / 4;
+#pragma unroll 1
+    for (int g = 0; g < G; g++) {                      // taps 4g..4g+3, samples c' = 4g..4g+5
+        const float2 *xg = xp + g;
+        const float2 x0 = xg[0], x1 = xg[Lph], x2 = xg[2 * Lph], x3 = xg[3 * Lph], x4 = xg[1], x5 = xg[Lph + 1];
+        float ar, ai, br, bi;
+        tap(4 * g + 0, ar, ai, br, bi); mac(0, x0, ar, ai, br, bi); mac(1, x2, ar, ai, br, bi);
+        tap(4 * g + 1, ar, ai, br, bi); mac(0, x1, ar, ai, br, bi); mac(1, x3, ar, ai, br, bi);
+        tap(4 * g + 2, ar, ai, br, bi); mac(0, x2, ar, ai, br, bi); mac(1, x4, ar, ai, br, bi);
+        tap(4 * g + 3, ar, ai, br, bi); mac(0, x3, ar, ai, br, bi); mac(1, x5, ar, ai, br, bi);
+    }
+#pragma unroll
+    for (int k = 4 * G; k < M; k++) {                  // remaining 1 or 3 taps
+        float ar, ai, br, bi;
+        tap(k, ar, ai, br, bi);
+        mac(0, xp[(k & 3) * Lph + (k >> 2)], ar, ai, br, bi);
+        mac(1, xp[((k + 2) & 3) * Lph + ((k + 2) >> 2)], ar, ai, br, bi);
+    }
+}
+
+// OUT: 0 = every output nullable at run time; 1 = no compact outputs (eq_out / dec_out ignored); 2 = compact outputs, q not written.
+// The specialisations only drop dead code: fewer live scalars, fewer SGPR spills in the step loop.
+// NW = wavefronts per run: 1 (B <= 128, no barriers at all) or 2 / 4 (B <= 256 / 512): thread gl = 64 wv + lane owns the symbol pair
+// (2 gl, 2 gl + 1), the tap-gradient sums are split 2 NW ways, wave 0 owns the taps and their Adam moments; phases are separated
+// by s_barrier after an LDS-only wait (sync_lds), so the in-flight q / y stores still never stall a phase.
+template <int NW>
+__device__ __forceinline__ void sync_lds()
+{
+    if constexpr (NW == 1) wave_lds_sync();
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int M, int NLEV, int BT, bool PAIR, int OUT, int NW = 1>
+__global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args a)
+{
+    constexpr int mh = M / 2, Mh = 2 * mh, MP = M + 1;
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    extern __shared__ float4 smem4[];
+    char *sm = reinterpret_cast<char *>(smem4);
+    const int gl = threadIdx.x, lane = NW > 1 ? (gl & 63) : gl, wv = NW > 1 ? (gl >> 6) : 0, run = blockIdx.x;
+    constexpr int NT = 64 * NW, NP = 2 * NW;              // threads per run; parts a tap-gradient sum is split into
+    const int B = BT ? BT : a.B;
+    const int L = 2 * B, nm = L - Mh, P2 = B / 2;
+    const WaveLayout lay = wave_layout(B, M, NW);
+    const int Lph = lay.Lph, Uph = lay.Uph;
+    float2 *Xs = reinterpret_cast<float2 *>(sm + lay.X), *Es = reinterpret_cast<float2 *>(sm + lay.E);
+    float2 *Us = reinterpret_cast<float2 *>(sm + lay.U), *GY = Us;
+    float4 *Wt = reinterpret_cast<float4 *>(sm + lay.W);       // [p][k] = (wr[o0], wi[o0], wr[o1], wi[o1])
+    float2 *Ht = reinterpret_cast<float2 *>(sm + lay.H);       // [chi][nu][j] = (re, im), j = 0..M (j = M: zero pad)
+    float *PSv = reinterpret_cast<float *>(sm + lay.PSv);      // [nu][B+1] exclusive prefix sums of v_I + v_Q
+    float *PSh = reinterpret_cast<float *>(sm + lay.PSh);      // [nu][M+1] exclusive prefix sums of sum_chi gC |h|^2
+    float *VS = reinterpret_cast<float *>(sm + lay.VS);        // [nu][M]
+    float *RED = reinterpret_cast<float *>(sm + lay.RED), *XG = reinterpret_cast<float *>(sm + lay.XG);   // NW > 1 only
+
+    // ---- per-run constants (uniform)
+    float amp[NLEV], b2[NLEV], nlogP[NLEV];
+    const float nusc = a.nu_sc[run];
+#pragma unroll
+    for (int i = 0; i < NLEV; i++) {
+        amp[i] = a.amp[i];
+        b2[i] = nusc * amp[i] * amp[i] * LOG2E;
+        nlogP[i] = -logf(a.P[(size_t)run * NLEV + i]);
+    }
+    const float var0 = a.var[run * 2 + 0], var1 = a.var[run * 2 + 1];
+    const float lrW = a.lr_W[run], lrH = a.lr_h[run];
+
+    // ---- zero the halo'd buffers once; load taps; owner lanes load their Adam moments
+    for (int i = gl; i < (lay.W - lay.X) / 8; i += NT) Xs[i] = make_float2(0.f, 0.f);     // X, E, U, PSv
+    for (int i = gl; i < (lay.PSh - lay.H) / 8; i += NT) Ht[i] = make_float2(0.f, 0.f);   // incl. the pad taps
+    __syncthreads();
+    const int tk = lane & 31, half = lane >> 5;                // tap index / which half this lane owns (o resp. chi)
+    const bool worker = tk < M, owner = worker && wv == 0;     // worker: sums a part of a tap's gradient; owner: holds the tap
+    const int part = wv * 2 + half;
+    const size_t gbase = (size_t)run * 8 * M;
+    float mWr[2] = {0, 0}, mWi[2] = {0, 0}, vWr[2] = {0, 0}, vWi[2] = {0, 0};   // [p]  moments of W[o=half][p][k=tk]
+    float mHr[2] = {0, 0}, mHi[2] = {0, 0}, vHr[2] = {0, 0}, vHi[2] = {0, 0};   // [nu] moments of h[chi=half][nu][.][j=tk]
+    if (owner) {
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const size_t ir = gbase + (half * 4 + p) * M + tk, ii = gbase + (half * 4 + 2 + p) * M + tk;
+            float *wq = reinterpret_cast<float *>(&Wt[p * M + tk]);
+            wq[half * 2 + 0] = a.W[ir];
+            wq[half * 2 + 1] = a.W[ii];
+            mWr[p] = a.adam_mW[ir]; mWi[p] = a.adam_mW[ii];
+            vWr[p] = a.adam_vW[ir]; vWi[p] = a.adam_vW[ii];
+            const size_t hr = gbase + ((half * 2 + p) * 2 + 0) * M + tk, hi = hr + M;
+            Ht[(half * 2 + p) * MP + tk] = make_float2(a.h[hr], a.h[hi]);
+            mHr[p] = a.adam_mh[hr]; mHi[p] = a.adam_mh[hi];
+            vHr[p] = a.adam_vh[hr]; vHi[p] = a.adam_vh[hi];
+        }
+    }
+    int step = a.step[run];
+    double b1t = pow(0.9, (double)step), b2t = pow(0.999, (double)step);
+    __syncthreads();
+
+    const int klen = a.keep_len, k0 = a.keep_off;
+    const size_t No = (size_t)a.steps * klen;
+    constexpr bool pairst = PAIR;                              // keep_off, keep_len even: both symbols of a lane kept together -> 8-byte stores
+    const bool act = gl < P2;                                  // thread owns symbols 2*gl, 2*gl+1
+    const int nq = (nm + 3) / 4;                               // residual quads t = 4l' .. 4l'+3
+    const int n0 = 2 * gl;
+    const float2 *Xl = Xs + gl, *El = Es + gl, *Ul = Us + gl;
+
+    // The window of the NEXT step is fetched into registers while the current step computes (one 16-byte load per lane and
+    // row: B <= 128 means L/4 <= 64 lanes), so a step never waits for HBM after the first.
+    const bool ldl = gl < L / 4;
+    float4 pf[4];
+    auto fetch = [&](int f, int s) {
+        const float *src = a.rx + ((size_t)run * a.n_frames + f) * 4 * (size_t)a.S + (size_t)s * a.stride_sym * 2 + 4 * gl;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            pf[r] = ldl ? *reinterpret_cast<const float4 *>(src + (size_t)r * a.S) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    fetch(0, 0);
+    for (int f = 0; f < a.n_frames; f++) {
+        float *qf = (OUT != 2 && a.q_out) ? a.q_out + ((size_t)run * a.n_frames + f) * (4 * NLEV) * No : nullptr;
+        float *yf = a.y_out ? a.y_out + ((size_t)run * a.n_frames + f) * 4 * No : nullptr;
+        float *ef = (OUT != 1 && a.eq_out) ? a.eq_out + ((size_t)run * a.n_frames + f) * 2 * No : nullptr;
+        int8_t *df = (OUT != 1 && a.dec_out) ? a.dec_out + ((size_t)run * a.n_frames + f) * 4 * No : nullptr;
+#pragma unroll 1
+        for (int s = 0; s < a.steps; s++) {
+            // ============ P0: prefetched window -> LDS (polyphase scatter; halo stays zero)
+            if (ldl) {
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const float4 I4 = pf[p * 2 + 0], Q4 = pf[p * 2 + 1];
+                    const float xi[4] = {I4.x, I4.y, I4.z, I4.w}, xq[4] = {Q4.x, Q4.y, Q4.z, Q4.w};
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int c = mh + i;                  // + 4*lane: phase (c & 3) is lane independent
+                        Xs[(p * 4 + (c & 3)) * Lph + gl + (c >> 2)] = make_float2(xi[i], xq[i]);
+                    }
+                }
+            }
+            sync_lds<NW>();
+
+            // ============ P1: FIR for the lane's symbol pair, both output polarisations
+            float2 y[2][2];                                    // [sym][o]
+            {
+                cacc ya[2][2];
+                ya[0][0] = ya[0][1] = ya[1][0] = ya[1][1] = cacc0();
+                if (act) {
+                    pair_fir<M, false>(ya, Xl, Lph, Wt, nullptr, nullptr);
+                    pair_fir<M, false>(ya, Xl + 4 * Lph, Lph, Wt + M, nullptr, nullptr);
+                }
+#pragma unroll
+                for (int sy = 0; sy < 2; sy++)
+#pragma unroll
+                    for (int o = 0; o < 2; o++) y[sy][o] = cfin(ya[sy][o]);
+            }
+            // pin: hipcc otherwise sinks whole FMA chains to their (much later) use and keeps their inputs alive instead
+            asm volatile("" : "+v"(y[0][0].x), "+v"(y[0][0].y), "+v"(y[0][1].x), "+v"(y[0][1].y), "+v"(y[1][0].x), "+v"(y[1][0].y),
+                         "+v"(y[1][1].x), "+v"(y[1][1].y));
+            const bool kept0 = act && (n0 >= k0) && (n0 < k0 + klen), kept1 = act && (n0 + 1 >= k0) && (n0 + 1 < k0 + klen);
+            const size_t col = (size_t)s * klen + (n0 - k0);
+            if (yf) {
+#pragma unroll
+                for (int o = 0; o < 2; o++) {
+                    float *rI = yf + (size_t)(o * 2 + 0) * No + col, *rQ = yf + (size_t)(o * 2 + 1) * No + col;
+                    if (pairst) {
+                        if (kept0) {
+                            *reinterpret_cast<float2 *>(rI) = make_float2(y[0][o].x, y[1][o].x);
+                            *reinterpret_cast<float2 *>(rQ) = make_float2(y[0][o].y, y[1][o].y);
+                        }
+                    } else {
+                        if (kept0) { rI[0] = y[0][o].x; rQ[0] = y[0][o].y; }
+                        if (kept1) { rI[1] = y[1][o].x; rQ[1] = y[1][o].y; }
+                    }
+                }
+            }
+
+            // ============ P2: soft demap + moments (registers), mu -> LDS, prefix sums of the variances
+            float mv[2][2][2], mt3[2][2][2], mkc[2][2][2];     // [sym][o][c]: Var_q, 3rd central moment, KL-gradient moment
+            float klsum = 0.f, vv[2][2];                       // vv[o][sym] = v_I + v_Q
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                const float c2 = 0.5f / (o ? var1 : var0) * LOG2E;
+                float2 muv[2];                                 // per sym: (mu_I, mu_Q)
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    // both symbols of the lane at once: every add/mul/fma below is one packed instruction (v_pk_*_f32)
+                    const v2f yy = c ? v2f{y[0][o].y, y[1][o].y} : v2f{y[0][o].x, y[1][o].x};
+                    v2f z[NLEV], q[NLEV];
+                    float zm0 = -3.0e38f, zm1 = -3.0e38f;
+#pragma unroll
+                    for (int i = 0; i < NLEV; i++) {
+                        const v2f d = yy - amp[i];
+                        z[i] = -(d * d * c2 + b2[i]);
+                        zm0 = fmaxf(zm0, z[i].x);
+                        zm1 = fmaxf(zm1, z[i].y);
+                    }
+                    const v2f zmax = {zm0, zm1};
+                    v2f ssum = {0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < NLEV; i++) {
+                        z[i] -= zmax;
+                        q[i] = v2f{__builtin_amdgcn_exp2f(z[i].x), __builtin_amdgcn_exp2f(z[i].y)};
+                        ssum += q[i];
+                    }
+                    const v2f rs = {__builtin_amdgcn_rcpf(ssum.x), __builtin_amdgcn_rcpf(ssum.y)};
+                    v2f m1 = {0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < NLEV; i++) {
+                        q[i] *= rs;
+                        m1 += q[i] * amp[i];
+                    }
+                    // compact stand-ins for q in the epilogue: E_q[x_I] and the first maximum of q, exactly as it would derive them
+                    if (ef && c == 0) {
+                        float *r = ef + (size_t)o * No + col;
+                        if (pairst) {
+                            if (kept0) *reinterpret_cast<v2f *>(r) = m1;
+                        } else {
+                            if (kept0) r[0] = m1.x;
+                            if (kept1) r[1] = m1.y;
+                        }
+                    }
+                    if (df) {
+                        float v0 = q[0].x, v1 = q[0].y;
+                        int b0 = 0, b1 = 0;
+#pragma unroll
+                        for (int i = 1; i < NLEV; i++) {
+                            if (q[i].x > v0) { v0 = q[i].x; b0 = i; }
+                            if (q[i].y > v1) { v1 = q[i].y; b1 = i; }
+                        }
+                        int8_t *r = df + (size_t)(o * 2 + c) * No + col;
+                        if (pairst) {
+                            if (kept0) *reinterpret_cast<uint16_t *>(r) = (uint16_t)(b0 | (b1 << 8));
+                        } else {
+                            if (kept0) r[0] = (int8_t)b0;
+                            if (kept1) r[1] = (int8_t)b1;
+                        }
+                    }
+                    // log(q_i/P_i) = z_i ln2 - log(ssum) - log P_i: the softmax's own logits; the +1e-12 inside the reference's
+                    // log and the q/(q+eps P) factor of its derivative change q*log(.) by < 1e-12, and the terms
+                    // common to all levels cancel in the centred sum
+                    v2f m2 = {0.f, 0.f}, m3 = {0.f, 0.f}, kk = {0.f, 0.f}, kl = {0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < NLEV; i++) {
+                        const v2f d = amp[i] - m1, qd = q[i] * d, g = z[i] * LN2 + nlogP[i];
+                        m2 += qd * d;
+                        m3 += qd * d * d;
+                        kk += qd * g;
+                        kl += q[i] * g;
+                    }
+                    const bool inr0 = (n0 >= mh) && (n0 < B - mh) && act;             // KL slice, symbol index (:132)
+                    const bool inr1 = (n0 + 1 >= mh) && (n0 + 1 < B - mh) && act;
+                    if (inr0) klsum += kl.x - __builtin_amdgcn_logf(ssum.x) * LN2;
+                    if (inr1) klsum += kl.y - __builtin_amdgcn_logf(ssum.y) * LN2;
+                    asm volatile("" : "+v"(m2), "+v"(m3), "+v"(kk), "+v"(klsum));   // pin (see P1)
+                    mv[0][o][c] = m2.x; mv[1][o][c] = m2.y;
+                    mt3[0][o][c] = m3.x; mt3[1][o][c] = m3.y;
+                    mkc[0][o][c] = inr0 ? kk.x : 0.f;
+                    mkc[1][o][c] = inr1 ? kk.y : 0.f;
+                    if (c) { muv[0].y = m1.x; muv[1].y = m1.y; } else { muv[0].x = m1.x; muv[1].x = m1.y; }
+                    if (qf) {
+#pragma unroll
+                        for (int i = 0; i < NLEV; i++) {
+                            float *r = qf + (size_t)(o * 2 * NLEV + c * NLEV + i) * No + col;
+                            if (pairst) {
+                                if (kept0) *reinterpret_cast<v2f *>(r) = q[i];
+                            } else {
+                                if (kept0) r[0] = q[i].x;
+                                if (kept1) r[1] = q[i].y;
+                            }
+                        }
+                    }
+                }
+                vv[o][0] = act ? mv[0][o][0] + mv[0][o][1] : 0.f;
+                vv[o][1] = act ? mv[1][o][0] + mv[1][o][1] : 0.f;
+                if (act) {                                     // U[nu=o][n]: even symbols in phase 0, odd in phase 1
+                    Us[(o * 2 + 0) * Uph + gl] = muv[0];
+                    Us[(o * 2 + 1) * Uph + gl] = muv[1];
+                }
+            }
+            // exclusive prefix sums PSv[nu][n], n = 0..B  (VS[nu][j] = PSv[hi+1] - PSv[lo])
+            {
+                float inc[2];
+#pragma unroll
+                for (int o = 0; o < 2; o++) inc[o] = wave_incl_scan(vv[o][0] + vv[o][1], lane);
+                if constexpr (NW > 1) {                        // add the totals of the waves below (fixed order)
+                    if (lane == 63) { RED[wv] = inc[0]; RED[NW + wv] = inc[1]; }
+                    sync_lds<NW>();
+#pragma unroll
+                    for (int w = 0; w < NW - 1; w++)
+                        if (w < wv) { inc[0] += RED[w]; inc[1] += RED[NW + w]; }
+                }
+#pragma unroll
+                for (int o = 0; o < 2; o++) {
+                    if (act) {
+                        PSv[o * (B + 1) + n0 + 1] = inc[o] - vv[o][1];
+                        PSv[o * (B + 1) + n0 + 2] = inc[o];
+                    }
+                    if (gl == 0) PSv[o * (B + 1)] = 0.f;
+                }
+            }
+            sync_lds<NW>();
+            if (owner) {                                       // VS[nu][j]: lane = (j = tk, nu = half)
+                const int lo = (Mh - tk + 1) >> 1, hi_ = (nm - 1 + Mh - tk) >> 1;
+                VS[half * M + tk] = PSv[half * (B + 1) + hi_ + 1] - PSv[half * (B + 1) + lo];
+            }
+            sync_lds<NW>();
+
+            // ============ P3: residual e = x - D for the quad t = 4l'..4l'+3, both chi.
+            //   D[chi, 2 tau + par] = sum_nu sum_a h[chi,nu,2a+par] U[nu, tau + mh - a],   tau in {2l', 2l'+1}, a = 0..mh
+            float se0 = 0.f, se1 = 0.f;
+            if (gl < nq) {
+                cacc D[2][4];                                  // [chi][i], i = 2*dl + par
+#pragma unroll
+                for (int chi = 0; chi < 2; chi++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) D[chi][i] = cacc0();
+#pragma unroll
+                for (int v = 0; v < 2; v++) {
+                    const float2 *h0 = Ht + (0 * 2 + v) * MP, *h1 = Ht + (1 * 2 + v) * MP;
+                    const float2 *up = Ul + v * 2 * Uph;       // U[nu][2l' + d] = up[(d & 1) * Uph + (d >> 1)]
+                    auto step_a = [&](int aa, float2 ulo, float2 uhi) {   // ulo = U[2l' + mh - a], uhi = U[2l' + mh - a + 1]
+                        const float2 e0 = h0[2 * aa], o0 = h0[2 * aa + 1], e1 = h1[2 * aa], o1 = h1[2 * aa + 1];
+                        cmac(D[0][0], e0.x, e0.y, ulo); cmac(D[0][1], o0.x, o0.y, ulo);
+                        cmac(D[0][2], e0.x, e0.y, uhi); cmac(D[0][3], o0.x, o0.y, uhi);
+                        cmac(D[1][0], e1.x, e1.y, ulo); cmac(D[1][1], o1.x, o1.y, ulo);
+                        cmac(D[1][2], e1.x, e1.y, uhi); cmac(D[1][3], o1.x, o1.y, uhi);
+                    };
+                    constexpr int NA = mh + 1, NB = NA / 2;    // a = 0..mh; pairs (2b, 2b+1)
+#pragma unroll 1
+                    for (int b = 0; b < NB; b++) {             // d = mh - 2b: samples d+1, d, d-1
+                        constexpr int ph = mh & 1;             // phase of d (d and mh have equal parity)
+                        const int sl = (mh >> 1) - b;          // slot of d   (d >> 1)
+                        const float2 ud = up[ph * Uph + sl];
+                        const float2 udp = up[(ph ^ 1) * Uph + sl + ph];            // d + 1
+                        const float2 udm = up[(ph ^ 1) * Uph + sl + ph - 1];        // d - 1
+                        step_a(2 * b, ud, udp);
+                        step_a(2 * b + 1, udm, ud);
+                    }
+                    if (NA & 1) {                              // a = mh: d = 0 -> U[2l'], U[2l'+1]
+                        step_a(mh, up[0], up[Uph]);
+                    }
+                }
+#pragma unroll
+                for (int chi = 0; chi < 2; chi++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int ce = Mh + i;                 // + 4*lane: same (phase, slot) arithmetic as x
+                        const float2 x = Xl[(chi * 4 + (ce & 3)) * Lph + (ce >> 2)];
+                        const float2 Dv = cfin(D[chi][i]);
+                        float2 e = make_float2(x.x - Dv.x, x.y - Dv.y);
+                        if (4 * gl + i >= nm) e = make_float2(0.f, 0.f);
+                        Es[(chi * 4 + (ce & 3)) * Lph + gl + (ce >> 2)] = e;
+                        const float e2 = e.x * e.x + e.y * e.y;
+                        if (chi) se1 += e2; else se0 += e2;
+                    }
+            }
+            se0 = wave_sum(se0);
+            se1 = wave_sum(se1);
+            klsum = wave_sum(klsum);
+            if constexpr (NW > 1) {                            // totals over the run's waves, same order in every wave
+                if (lane == 0) { RED[16 + wv] = se0; RED[16 + NW + wv] = se1; RED[16 + 2 * NW + wv] = klsum; }
+                sync_lds<NW>();
+                se0 = RED[16]; se1 = RED[16 + NW]; klsum = RED[16 + 2 * NW];
+#pragma unroll
+                for (int w = 1; w < NW; w++) { se0 += RED[16 + w]; se1 += RED[16 + NW + w]; klsum += RED[16 + 2 * NW + w]; }
+            }
+            // C[chi] = sum|e|^2 + sum_{nu,j} |h|^2 VS   (lanes (j, nu) hold one term each for both chi)
+            float hq0 = 0.f, hq1 = 0.f;
+            if (worker) {
+                const float2 h0 = Ht[(0 * 2 + half) * MP + tk], h1 = Ht[(1 * 2 + half) * MP + tk];
+                hq0 = h0.x * h0.x + h0.y * h0.y;
+                hq1 = h1.x * h1.x + h1.y * h1.y;
+            }
+            const float vsl = worker ? VS[half * M + tk] : 0.f;
+            const float C0 = se0 + wave_sum(hq0 * vsl), C1 = se1 + wave_sum(hq1 * vsl);
+            const float gC0 = (float)nm / C0, gC1 = (float)nm / C1;
+            if (gl == 0) {
+                const size_t li = ((size_t)run * a.n_frames + f) * a.steps + s;
+                if (a.loss) a.loss[li] = (float)nm * (logf(C0) + logf(C1)) + klsum;
+                if (a.var_est) {
+                    const size_t vi = ((size_t)run * a.n_frames + f) * 2 * a.steps + s;
+                    a.var_est[vi] = C0 / (float)nm;
+                    a.var_est[vi + a.steps] = C1 / (float)nm;
+                }
+            }
+            // prefix sums over j of H2[nu][j] = sum_chi gC[chi] |h[chi,nu,j]|^2  -> G_V by two lookups per symbol
+            {
+                float inc = gC0 * hq0 + gC1 * hq1;             // inclusive scan within each 32-lane half
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) {
+                    const float t = __shfl_up(inc, d, 32);
+                    if (tk >= d) inc += t;
+                }
+                if (owner) PSh[half * MP + tk + 1] = inc;
+                if (tk == 0) PSh[half * MP] = 0.f;
+            }
+            sync_lds<NW>();
+
+            // ============ P4a: dL/dh partial sums, lane = (j = tk, half of the tau range); acc[chi][nu]
+            step += 1;
+            b1t *= 0.9;
+            b2t *= 0.999;
+            const float rbc1 = __builtin_amdgcn_rcpf((float)(1.0 - b1t));                 // bias corrections: beta^t in double,
+            const float bc2s = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf((float)(1.0 - b2t)));   // the rest in float
+            const float ssW = lrW * rbc1, ssH = lrH * rbc1;
+            float2 hnew[2];
+            hnew[0] = hnew[1] = make_float2(0.f, 0.f);
+            float ghr[2] = {0, 0}, ghi[2] = {0, 0};
+            float2 hacc[2];                                    // NW > 1: this wave's part of sum e conj(U) for (chi = half, nu)
+            {
+                cacc ca[2][2];
+                ca[0][0] = ca[0][1] = ca[1][0] = ca[1][1] = cacc0();
+                if (worker) {
+                    // sum over tau of e[chi, 2 tau + par] conj(U[nu, tau + mh - a]); tau runs in pairs (2m, 2m+1) so that the
+                    // polyphase component of every operand is a per-lane constant and only the slot advances (by one per m).
+                    // Past the last valid tau the residual cells are zero (pad), so the pair loop may overrun by one.
+                    const int par = tk & 1, aa = tk >> 1;
+                    const int T = (nm - par + 1) >> 1, Th = ((T + 2 * NP - 1) / (2 * NP)) << 1;   // even split points
+                    const int ma = (part * Th) >> 1, mb = (min(T, part * Th + Th) + 1) >> 1;
+                    const int ceA = par + Mh, ceB = par + Mh + 2, npA = mh - aa, npB = mh - aa + 1;
+                    const float2 *eA = Es + (ceA & 3) * Lph + (ceA >> 2), *eB = Es + (ceB & 3) * Lph + (ceB >> 2);
+                    const float2 *uA = Us + (npA & 1) * Uph + (npA >> 1), *uB = Us + (npB & 1) * Uph + (npB >> 1);
+#pragma unroll 2
+                    for (int m = ma; m < mb; m++) {
+                        const float2 e0 = eA[m], e1 = eA[4 * Lph + m], u0 = uA[m], u1 = uA[2 * Uph + m];
+                        const float2 f0 = eB[m], f1 = eB[4 * Lph + m], w0 = uB[m], w1 = uB[2 * Uph + m];
+                        cmac(ca[0][0], u0.x, u0.y, e0);
+                        cmac(ca[0][1], u1.x, u1.y, e0);
+                        cmac(ca[1][0], u0.x, u0.y, e1);
+                        cmac(ca[1][1], u1.x, u1.y, e1);
+                        cmac(ca[0][0], w0.x, w0.y, f0);
+                        cmac(ca[0][1], w1.x, w1.y, f0);
+                        cmac(ca[1][0], w0.x, w0.y, f1);
+                        cmac(ca[1][1], w1.x, w1.y, f1);
+                    }
+                }
+                float2 acc[2][2];
+#pragma unroll
+                for (int chi = 0; chi < 2; chi++)
+#pragma unroll
+                    for (int v = 0; v < 2; v++) acc[chi][v] = cfinc(ca[chi][v]);             // e * conj(U)
+                // combine the two halves; lane (j, half) keeps chi = half
+#pragma unroll
+                for (int chi = 0; chi < 2; chi++)
+#pragma unroll
+                    for (int v = 0; v < 2; v++) {
+                        acc[chi][v].x += __shfl_xor(acc[chi][v].x, 32, 64);
+                        acc[chi][v].y += __shfl_xor(acc[chi][v].y, 32, 64);
+                    }
+                if constexpr (NW > 1) {                        // waves 1.. hand their partial sums to wave 0 (read after the next barrier)
+#pragma unroll
+                    for (int v = 0; v < 2; v++) {
+                        hacc[v] = half ? acc[1][v] : acc[0][v];
+                        if (wv > 0) {
+                            XG[((wv - 1) * 4 + 2 * v + 0) * 64 + lane] = hacc[v].x;
+                            XG[((wv - 1) * 4 + 2 * v + 1) * 64 + lane] = hacc[v].y;
+                        }
+                    }
+                }
+                if (NW == 1 && owner) {
+                    const float g = half ? gC1 : gC0;
+#pragma unroll
+                    for (int v = 0; v < 2; v++) {
+                        const float2 ac = half ? acc[1][v] : acc[0][v];
+                        const float2 hh = Ht[(half * 2 + v) * MP + tk];
+                        const float vs = VS[v * M + tk];
+                        ghr[v] = g * (-2.0f * ac.x + 2.0f * hh.x * vs);
+                        ghi[v] = g * (-2.0f * ac.y + 2.0f * hh.y * vs);
+                        hnew[v] = hh;
+                        if (!a.no_update) {
+                            adam_update_fast(hnew[v].x, mHr[v], vHr[v], ghr[v], ssH, bc2s);
+                            adam_update_fast(hnew[v].y, mHi[v], vHi[v], ghi[v], ssH, bc2s);
+                        }
+                    }
+                }
+            }
+
+            asm volatile("" : "+v"(hnew[0].x), "+v"(hnew[0].y), "+v"(hnew[1].x), "+v"(hnew[1].y), "+v"(ghr[0]), "+v"(ghr[1]), "+v"(ghi[0]),
+                         "+v"(ghi[1]));                        // pin (see P1)
+            // prefetch the next window now: the q/y stores of this step were issued half a step ago and have drained, so the wait
+            // for these loads at the top of the next step does not also wait for fresh stores (vmcnt retires in order)
+            {
+                const bool last_s = s + 1 == a.steps;
+                if (!(last_s && f + 1 == a.n_frames)) fetch(last_s ? f + 1 : f, last_s ? 0 : s + 1);
+            }
+            // ============ P4b: dL/dU for the lane's symbol pair (same shape as the FIR, on e with conj(h)), then dL/dy
+            float2 gy[2][2];                                   // [sym][nu]
+            {
+                float2 au0[2][2], au1[2][2];                   // chi = 0 / 1: [sym][nu]
+                {
+                    cacc c0[2][2], c1[2][2];
+                    c0[0][0] = c0[0][1] = c0[1][0] = c0[1][1] = cacc0();
+                    c1[0][0] = c1[0][1] = c1[1][0] = c1[1][1] = cacc0();
+                    if (act) {
+                        pair_fir<M, true>(c0, El, Lph, nullptr, Ht + 0 * MP, Ht + 1 * MP);
+                        pair_fir<M, true>(c1, El + 4 * Lph, Lph, nullptr, Ht + 2 * MP, Ht + 3 * MP);
+                    }
+#pragma unroll
+                    for (int sy = 0; sy < 2; sy++)
+#pragma unroll
+                        for (int v = 0; v < 2; v++) { au0[sy][v] = cfinc(c0[sy][v]); au1[sy][v] = cfinc(c1[sy][v]); }   // e * conj(h)
+                }
+#pragma unroll
+                for (int sy = 0; sy < 2; sy++) {
+                    const int sx = 2 * (n0 + sy);
+                    const int jlo = max(0, Mh - sx), jhi = max(jlo - 1, min(Mh, nm - 1 + Mh - sx));
+#pragma unroll
+                    for (int v = 0; v < 2; v++) {
+                        const float ur = -2.0f * (gC0 * au0[sy][v].x + gC1 * au1[sy][v].x);
+                        const float ui = -2.0f * (gC0 * au0[sy][v].y + gC1 * au1[sy][v].y);
+                        const float gv = PSh[v * MP + jhi + 1] - PSh[v * MP + jlo];
+                        const float iv = 1.0f / (v ? var1 : var0);
+                        gy[sy][v].x = iv * (ur * mv[sy][v][0] + gv * mt3[sy][v][0] + mkc[sy][v][0]);
+                        gy[sy][v].y = iv * (ui * mv[sy][v][1] + gv * mt3[sy][v][1] + mkc[sy][v][1]);
+                    }
+                }
+            }
+            sync_lds<NW>();                                   // every read of U / old h is done (GY aliases U)
+            if constexpr (NW > 1) {
+                if (owner) {
+                    const float g = half ? gC1 : gC0;
+#pragma unroll
+                    for (int v = 0; v < 2; v++) {
+                        float2 ac = hacc[v];
+#pragma unroll
+                        for (int w = 0; w < NW - 1; w++) {
+                            ac.x += XG[(w * 4 + 2 * v + 0) * 64 + lane];
+                            ac.y += XG[(w * 4 + 2 * v + 1) * 64 + lane];
+                        }
+                        const float2 hh = Ht[(half * 2 + v) * MP + tk];
+                        const float vs = VS[v * M + tk];
+                        ghr[v] = g * (-2.0f * ac.x + 2.0f * hh.x * vs);
+                        ghi[v] = g * (-2.0f * ac.y + 2.0f * hh.y * vs);
+                        hnew[v] = hh;
+                        if (!a.no_update) {
+                            adam_update_fast(hnew[v].x, mHr[v], vHr[v], ghr[v], ssH, bc2s);
+                            adam_update_fast(hnew[v].y, mHi[v], vHi[v], ghi[v], ssH, bc2s);
+                        }
+                    }
+                }
+            }
+            if (act) {
+#pragma unroll
+                for (int v = 0; v < 2; v++) {
+                    GY[v * B + n0] = gy[0][v];
+                    GY[v * B + n0 + 1] = gy[1][v];
+                }
+            }
+            if (owner && !a.no_update) {
+                Ht[(half * 2 + 0) * MP + tk] = hnew[0];
+                Ht[(half * 2 + 1) * MP + tk] = hnew[1];
+            }
+            sync_lds<NW>();
+
+            // ============ P5: dL/dw partial sums, lane = (k = tk, half of the symbol range); acc[o][p]
+            float gwr[2] = {0, 0}, gwi[2] = {0, 0};
+            {
+                cacc ca[2][2];
+                ca[0][0] = ca[0][1] = ca[1][0] = ca[1][1] = cacc0();
+                if (worker) {
+                    // sum over n of gy[o, n] conj(x[p, 2n + k]); n runs in pairs (2m, 2m+1): x phase fixed per lane, gy pair = 16 bytes
+                    const int Bq = ((B + 2 * NP - 1) / (2 * NP)) << 1;                   // even split points (B is even)
+                    const int ma = (part * Bq) >> 1, mb = min(B, part * Bq + Bq) >> 1;
+                    const int cA = tk, cB = tk + 2;
+                    const float2 *xA = Xs + (cA & 3) * Lph + (cA >> 2), *xB = Xs + (cB & 3) * Lph + (cB >> 2);
+                    const float4 *G0 = reinterpret_cast<const float4 *>(GY), *G1 = reinterpret_cast<const float4 *>(GY + B);
+#pragma unroll 2
+                    for (int m = ma; m < mb; m++) {
+                        const float4 ga = G0[m], gb = G1[m];                             // (gy[o][2m], gy[o][2m+1])
+                        const float2 x0 = xA[m], x1 = xA[4 * Lph + m], z0 = xB[m], z1 = xB[4 * Lph + m];
+                        cmac(ca[0][0], x0.x, x0.y, make_float2(ga.x, ga.y));
+                        cmac(ca[0][1], x1.x, x1.y, make_float2(ga.x, ga.y));
+                        cmac(ca[1][0], x0.x, x0.y, make_float2(gb.x, gb.y));
+                        cmac(ca[1][1], x1.x, x1.y, make_float2(gb.x, gb.y));
+                        cmac(ca[0][0], z0.x, z0.y, make_float2(ga.z, ga.w));
+                        cmac(ca[0][1], z1.x, z1.y, make_float2(ga.z, ga.w));
+                        cmac(ca[1][0], z0.x, z0.y, make_float2(gb.z, gb.w));
+                        cmac(ca[1][1], z1.x, z1.y, make_float2(gb.z, gb.w));
+                    }
+                }
+                float2 acc[2][2];
+#pragma unroll
+                for (int o = 0; o < 2; o++)
+#pragma unroll
+                    for (int pp = 0; pp < 2; pp++) acc[o][pp] = cfinc(ca[o][pp]);            // gy * conj(x)
+#pragma unroll
+                for (int o = 0; o < 2; o++)
+#pragma unroll
+                    for (int p = 0; p < 2; p++) {
+                        acc[o][p].x += __shfl_xor(acc[o][p].x, 32, 64);
+                        acc[o][p].y += __shfl_xor(acc[o][p].y, 32, 64);
+                    }
+                if constexpr (NW > 1) {                        // as for dL/dh: wave 0 adds the other waves' parts after the barrier
+#pragma unroll
+                    for (int p = 0; p < 2; p++) {
+                        const float2 ac = half ? acc[1][p] : acc[0][p];
+                        if (wv > 0) {
+                            XG[((wv - 1) * 4 + 2 * p + 0) * 64 + lane] = ac.x;
+                            XG[((wv - 1) * 4 + 2 * p + 1) * 64 + lane] = ac.y;
+                        }
+                    }
+                    sync_lds<NW>();
+                }
+                if (owner) {
+#pragma unroll
+                    for (int p = 0; p < 2; p++) {
+                        float2 ac = half ? acc[1][p] : acc[0][p];
+                        if constexpr (NW > 1) {
+#pragma unroll
+                            for (int w = 0; w < NW - 1; w++) {
+                                ac.x += XG[(w * 4 + 2 * p + 0) * 64 + lane];
+                                ac.y += XG[(w * 4 + 2 * p + 1) * 64 + lane];
+                            }
+                        }
+                        gwr[p] = ac.x;
+                        gwi[p] = ac.y;
+                        if (!a.no_update) {
+                            float *wq = reinterpret_cast<float *>(&Wt[p * M + tk]) + half * 2;
+                            float wr = wq[0], wi = wq[1];
+                            adam_update_fast(wr, mWr[p], vWr[p], gwr[p], ssW, bc2s);
+                            adam_update_fast(wi, mWi[p], vWi[p], gwi[p], ssW, bc2s);
+                            wq[0] = wr;
+                            wq[1] = wi;
+                        }
+                    }
+                }
+            }
+            if (a.dbg_gW && owner && f == a.n_frames - 1 && s == a.steps - 1) {
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    a.dbg_gW[gbase + (half * 4 + p) * M + tk] = gwr[p];
+                    a.dbg_gW[gbase + (half * 4 + 2 + p) * M + tk] = gwi[p];
+                    a.dbg_gh[gbase + ((half * 2 + p) * 2 + 0) * M + tk] = ghr[p];
+                    a.dbg_gh[gbase + ((half * 2 + p) * 2 + 1) * M + tk] = ghi[p];
+                }
+            }
+            sync_lds<NW>();
+        }
+    }
+
+    // ---- state out
+    if (owner && !a.no_update) {
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const size_t ir = gbase + (half * 4 + p) * M + tk, ii = gbase + (half * 4 + 2 + p) * M + tk;
+            const float *wq = reinterpret_cast<const float *>(&Wt[p * M + tk]) + half * 2;
+            a.W[ir] = wq[0]; a.W[ii] = wq[1];
+            a.adam_mW[ir] = mWr[p]; a.adam_mW[ii] = mWi[p];
+            a.adam_vW[ir] = vWr[p]; a.adam_vW[ii] = vWi[p];
+            const size_t hr = gbase + ((half * 2 + p) * 2 + 0) * M + tk, hi = hr + M;
+            const float2 hh = Ht[(half * 2 + p) * MP + tk];
+            a.h[hr] = hh.x; a.h[hi] = hh.y;
+            a.adam_mh[hr] = mHr[p]; a.adam_mh[hi] = mHi[p];
+            a.adam_vh[hr] = vHr[p]; a.adam_vh[hi] = vHi[p];
+        }
+    }
+    if (gl == 0 && !a.no_update) a.step[run] = step;
+}
+
+
+template <int M, int NLEV, int BT, int NW>
+static int launch_wave(const vaeq_dp_args &a, hipStream_t st)
+{
+    const size_t lds = (size_t)wave_layout(a.B, M, NW).total;
+    const bool pair = ((a.keep_len | a.keep_off) & 1) == 0;
+    void (*k)(const vaeq_dp_args) = pair ? dp_wave_kernel<M, NLEV, BT, true, 0, NW> : dp_wave_kernel<M, NLEV, BT, false, 0, NW>;
+    if (BT) {                                                  // the tuned shape also gets the output-mode specialisations
+        if (!a.eq_out && !a.dec_out) k = pair ? dp_wave_kernel<M, NLEV, BT, true, BT ? 1 : 0, NW> : dp_wave_kernel<M, NLEV, BT, false, BT ? 1 : 0, NW>;
+        else if (!a.q_out) k = pair ? dp_wave_kernel<M, NLEV, BT, true, BT ? 2 : 0, NW> : dp_wave_kernel<M, NLEV, BT, false, BT ? 2 : 0, NW>;
+    }
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return VAEQ_ERR_LDS;
+    hipLaunchKernelGGL(k, dim3(a.R), dim3(64 * NW), lds, st, a);
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}
+
+template <int M, int BT, int NW>
+static int launch_wave_lev(const vaeq_dp_args &a, hipStream_t st)
+{
+    switch (a.n_lev) {
+    case 2: return launch_wave<M, 2, BT, NW>(a, st);
+    case 4: return launch_wave<M, 4, BT, NW>(a, st);
+    case 8: return launch_wave<M, 8, BT, NW>(a, st);
+    }
+    return VAEQ_ERR_SHAPE;
+}
+
+template <int M, int NLEV, int BT, int NW>
+static int64_t wave_resident(int B)
+{
+    int nb = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return VAEQ_ERR_DEVICE;
+    const size_t lds = (size_t)wave_layout(B, M, NW).total;
+    auto k = dp_wave_kernel<M, NLEV, BT, true, 0, NW>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64 * NW, lds) != hipSuccess) return VAEQ_ERR_DEVICE;
+    return (int64_t)nb * prop.multiProcessorCount;
+}
+
+template <int M, int BT, int NW>
+static int64_t wave_resident_lev(int B, int n_lev)
+{
+    switch (n_lev) {
+    case 2: return wave_resident<M, 2, BT, NW>(B);
+    case 4: return wave_resident<M, 4, BT, NW>(B);
+    case 8: return wave_resident<M, 8, BT, NW>(B);
+    }
+    return VAEQ_ERR_SHAPE;
+}
+
+}  // namespace vaeq
