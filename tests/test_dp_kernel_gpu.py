@@ -229,6 +229,32 @@ def test_wave_kernel_equals_generic_kernel(B, M, n):
     assert torch.equal(ea.step, eb.step)
 
 
+@pytest.mark.parametrize("B,k0,klen", [(200, 95, 11), (200, 90, 20), (300, 145, 10), (140, 65, 11)])
+def test_multiwave_flex_windows_equal_generic_kernel(B, k0, klen):
+    """VAEflex windows (stride 10, centre slice kept; odd offsets take the scalar-store variant) on the two- / four-wave kernels,
+    with the compact epilogue outputs, against the generic kernel: 12 free steps, R = 5."""
+    from vae_equalizer_amd.engine import DPEngine
+    rng = np.random.default_rng(B + k0)
+    R, sps, M, n, stride, steps = 5, 2, 25, 8, 10, 12
+    lev = np.arange(-(n - 1), n, 2).astype(np.float32)
+    amp = lev / np.sqrt(np.mean(lev ** 2) * 2).astype(np.float32)
+    P = rng.dirichlet(np.ones(n) * 5, R).astype(np.float32)
+    var = rng.uniform(0.002, 0.02, (R, 2)).astype(np.float32)
+    rx = torch.from_numpy((0.4 * rng.standard_normal((R, 2, 2, ((steps - 1) * stride + B) * sps + 8))).astype(np.float32)).to(DEV)
+    outs = []
+    for th in (1, 256):
+        eng = DPEngine(R, M, amp, P, var, rng.uniform(0, 1, R).astype(np.float32) * 0 + 0.3, DEV, sps, th)
+        r = eng.train(rx, B, steps, 2e-3, stride=stride, keep_off=k0, keep_len=klen, want_compact=True)
+        torch.cuda.synchronize()
+        outs.append((r, eng))
+    (ra, ea), (rb, eb) = outs
+    assert ra["y"].shape == rb["y"].shape and ra["y"].shape[-1] == steps * klen
+    assert relerr(_np(ra["loss"]), _np(rb["loss"])) < 2e-6 and relerr(_np(ra["y"]), _np(rb["y"])) < 1e-5
+    assert np.max(np.abs(_np(ra["q"]) - _np(rb["q"]))) < 2e-4 and relerr(_np(ra["eq"]), _np(rb["eq"])) < 1e-4
+    assert np.mean(_np(ra["dec"]) != _np(rb["dec"])) < 2e-3                     # argmax ties at decision boundaries only
+    assert np.max(np.abs(_np(ea.W) - _np(eb.W))) < 2e-5 and np.max(np.abs(_np(ea.h) - _np(eb.h))) < 2e-5
+
+
 def test_wave_kernel_refused_for_unsupported_shape():
     from vae_equalizer_amd import _native as nat
     from vae_equalizer_amd.engine import DPEngine
