@@ -199,7 +199,7 @@ def main():
                        "kernel_choice": args.threads,
                        "distinct_frames": n_distinct, "parallelism": f"sweep-sharded x{world}, one all_gather of result rows"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "vaeq::dp_wave_kernel<25,8,100,true,1>" if args.threads in (0, 1) else "vaeq::dp_train_kernel", "kernel_ms": kern_ms,
+                         "traffic": traffic, "kernel": "vaeq::dp_wave_kernel<25,8,100,true,1,1>" if args.threads in (0, 1) else "vaeq::dp_train_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_DP_SYMBOL * sym_per_launch},
         }
         if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only

@@ -196,9 +196,9 @@ def test_error_codes():
 
 
 @pytest.mark.parametrize("B,M,n", [(100, 25, 8), (64, 25, 4), (128, 13, 2), (50, 9, 8), (26, 25, 8), (100, 31, 8), (80, 17, 4), (60, 21, 2),
-                                   (130, 25, 8), (200, 25, 8), (256, 13, 2), (258, 31, 4), (300, 9, 8), (384, 21, 2), (512, 25, 8), (154, 17, 4)])
+                                   (130, 25, 8), (200, 25, 8), (256, 13, 2), (258, 31, 4), (300, 9, 8), (384, 21, 2), (512, 25, 8), (154, 17, 4), (600, 13, 4), (1000, 31, 2), (1024, 25, 8)])
 def test_wave_kernel_equals_generic_kernel(B, M, n):
-    """The wave-per-run fast path (threads=1; one wavefront per run up to B = 128, two up to 256, four up to 512) and the generic
+    """The wave-per-run fast path (threads=1; one wavefront per run up to B = 128, two up to 256, four up to 512, eight up to 1024) and the generic
     kernel (threads=256) agree on ragged shapes, 5 free steps, R=9."""
     from vae_equalizer_amd.engine import DPEngine
     rng = np.random.default_rng(B + M)
@@ -229,7 +229,7 @@ def test_wave_kernel_equals_generic_kernel(B, M, n):
     assert torch.equal(ea.step, eb.step)
 
 
-@pytest.mark.parametrize("B,k0,klen", [(200, 95, 11), (200, 90, 20), (300, 145, 10), (140, 65, 11)])
+@pytest.mark.parametrize("B,k0,klen", [(200, 95, 11), (200, 90, 20), (300, 145, 10), (140, 65, 11), (700, 345, 11)])
 def test_multiwave_flex_windows_equal_generic_kernel(B, k0, klen):
     """VAEflex windows (stride 10, centre slice kept; odd offsets take the scalar-store variant) on the two- / four-wave kernels,
     with the compact epilogue outputs, against the generic kernel: 12 free steps, R = 5."""

@@ -1,5 +1,5 @@
 // vaeq_dp_wave.hip -- dispatch of the wave-per-run DP kernel (vaeq_dp_wave_kernel.h): one wavefront per run for B <= 128; the
-// two- and four-wave variants for 128 < B <= 512 are instantiated in vaeq_dp_wave_mw.hip.
+// multi-wave variants for 128 < B <= 1024 are instantiated in vaeq_dp_wave_mw.hip / vaeq_dp_wave_mw8.hip.
 #include "vaeq_dp_wave_kernel.h"
 
 namespace vaeq {
@@ -10,7 +10,7 @@ int64_t dp_wave_mw_resident(int B, int M, int n_lev);
 // Whether the wave-per-run kernel covers this call (else the generic kernel runs).
 bool dp_wave_supported(const vaeq_dp_args &a)
 {
-    if (a.sps != 2 || (a.B & 1) || a.B > 512 || a.B < 2 * (a.M / 2) + 2) return false;
+    if (a.sps != 2 || (a.B & 1) || a.B > 1024 || a.B < 2 * (a.M / 2) + 2) return false;
     if (!(a.M == 25 || a.M == 31 || a.M == 21 || a.M == 17 || a.M == 13 || a.M == 9)) return false;
     if ((a.S & 3) || ((a.stride_sym * 2) & 3) || (reinterpret_cast<uintptr_t>(a.rx) & 15)) return false;   // 16-byte window loads
     if (a.q_out && (reinterpret_cast<uintptr_t>(a.q_out) & 7)) return false;

@@ -18,11 +18,11 @@
 //     with a gradient also owns that parameter's Adam moments (registers) and writes the updated tap to LDS.
 //   * reductions (sum |e|^2, KL) are fixed-order xor butterflies: bitwise reproducible.
 //
-// Supported here: sps == 2, B even, 2*(M/2)+2 <= B <= 512, M in {9, 13, 17, 21, 25, 31}; everything else takes the
+// Supported here: sps == 2, B even, 2*(M/2)+2 <= B <= 1024, M in {9, 13, 17, 21, 25, 31}; everything else takes the
 // generic kernel of vaeq_dp.hip.  BT > 0 bakes the minibatch length into the kernel (all LDS offsets immediate).
-// B <= 128 runs as ONE wavefront per run (NW = 1, described above); 128 < B <= 256 as two and B <= 512 as four wavefronts
-// per run (NW = 2, 4: same code, thread 64 wv + lane owns the pair, see dp_wave_kernel).  Instantiated in vaeq_dp_wave.hip
-// (NW = 1) and vaeq_dp_wave_mw.hip (NW = 2, 4).
+// B <= 128 runs as ONE wavefront per run (NW = 1, described above); 128 < B <= 256 as two, B <= 512 as four and B <= 1024 as
+// eight wavefronts per run (NW = 2, 4, 8: same code, thread 64 wv + lane owns the pair, see dp_wave_kernel).  Instantiated in
+// vaeq_dp_wave.hip (NW = 1), vaeq_dp_wave_mw.hip (NW = 2, 4) and vaeq_dp_wave_mw8.hip (NW = 8).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -105,7 +105,7 @@ __device__ __forceinline__ void pair_fir(cacc (&acc)[2][2], const float2 *xp, in
 
 // OUT: 0 = every output nullable at run time; 1 = no compact outputs (eq_out / dec_out ignored); 2 = compact outputs, q not written.
 // The specialisations only drop dead code: fewer live scalars, fewer SGPR spills in the step loop.
-// NW = wavefronts per run: 1 (B <= 128, no barriers at all) or 2 / 4 (B <= 256 / 512): thread gl = 64 wv + lane owns the symbol pair
+// NW = wavefronts per run: 1 (B <= 128, no barriers at all) or 2 / 4 / 8 (B <= 256 / 512 / 1024): thread gl = 64 wv + lane owns the symbol pair
 // (2 gl, 2 gl + 1), the tap-gradient sums are split 2 NW ways, wave 0 owns the taps and their Adam moments; phases are separated
 // by s_barrier after an LDS-only wait (sync_lds), so the in-flight q / y stores still never stall a phase.
 template <int NW>
@@ -785,6 +785,35 @@ static int64_t wave_resident_lev(int B, int n_lev)
     case 2: return wave_resident<M, 2, BT, NW>(B);
     case 4: return wave_resident<M, 4, BT, NW>(B);
     case 8: return wave_resident<M, 8, BT, NW>(B);
+    }
+    return VAEQ_ERR_SHAPE;
+}
+
+// every supported M for a given NW (the per-NW translation units instantiate these)
+template <int NW>
+static int launch_wave_any(const vaeq_dp_args &a, hipStream_t st)
+{
+    switch (a.M) {
+    case 25: return launch_wave_lev<25, 0, NW>(a, st);
+    case 31: return launch_wave_lev<31, 0, NW>(a, st);
+    case 21: return launch_wave_lev<21, 0, NW>(a, st);
+    case 17: return launch_wave_lev<17, 0, NW>(a, st);
+    case 13: return launch_wave_lev<13, 0, NW>(a, st);
+    case 9: return launch_wave_lev<9, 0, NW>(a, st);
+    }
+    return VAEQ_ERR_SHAPE;
+}
+
+template <int NW>
+static int64_t wave_resident_any(int B, int M, int n_lev)
+{
+    switch (M) {
+    case 25: return wave_resident_lev<25, 0, NW>(B, n_lev);
+    case 31: return wave_resident_lev<31, 0, NW>(B, n_lev);
+    case 21: return wave_resident_lev<21, 0, NW>(B, n_lev);
+    case 17: return wave_resident_lev<17, 0, NW>(B, n_lev);
+    case 13: return wave_resident_lev<13, 0, NW>(B, n_lev);
+    case 9: return wave_resident_lev<9, 0, NW>(B, n_lev);
     }
     return VAEQ_ERR_SHAPE;
 }
