@@ -100,9 +100,11 @@ def test_awgn_wave_refuses_unsupported_shape():
 
 
 @pytest.mark.parametrize("B,M,nlev", [(26, 25, 8), (100, 25, 4), (128, 25, 8), (130, 17, 2), (254, 9, 8), (256, 25, 2), (258, 25, 8),
-                                      (350, 25, 8), (384, 17, 4), (10, 9, 4)])
+                                      (350, 25, 8), (384, 17, 4), (10, 9, 4), (386, 25, 8), (512, 17, 4), (514, 9, 2), (700, 25, 8),
+                                      (768, 25, 2), (770, 17, 8), (1000, 25, 4), (1024, 25, 8)])
 def test_awgn_wave_matches_generic(B, M, nlev):
-    """Every round count (1..3), partial last rounds, all supported tap counts: 4 free steps, 3 runs, wave vs generic kernel."""
+    """Every round count (1..3), partial last rounds, all supported tap counts, and the two- / three- / four-wave variants
+    (B > 384): 4 free steps, 3 runs, wave vs generic kernel."""
     from vae_equalizer_amd.engine import AWGNEngine
     rng = np.random.default_rng(B * 100 + M)
     R, steps, sps = 3, 4, 2

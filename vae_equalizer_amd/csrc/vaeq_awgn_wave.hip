@@ -9,7 +9,8 @@
 // Lane (tap k, half) computes one half of the sum of dL/dw[k] and dL/dh[k]; after the cross-half shuffle, half 0 owns w[k] and
 // half 1 owns h[k]: parameter, Adam first/second moment and AMSGrad maximum all live in that lane's registers.
 //
-// Supported here: sps == 2, B even, 2*(M/2)+2 <= B <= 384, M in {9, 17, 25}; everything else takes the generic kernel.
+// Supported here: sps == 2, B even, 2*(M/2)+2 <= B <= 1024, M in {9, 17, 25}; everything else takes the generic kernel.
+// B <= 384: one wavefront per run (NR <= 3 rounds; more rounds spill); 384 < B <= 1024: two to four wavefronts x two rounds.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -21,10 +22,10 @@ namespace vaeq {
 
 struct AwgnWaveLayout {
     int Lph, Uph;
-    int X, E, U, PSv, W, H, PSh, VS, total;            // byte offsets (the dL/dy buffer aliases U)
+    int X, E, U, PSv, W, H, PSh, VS, RED, XG, total;   // byte offsets (the dL/dy buffer aliases U)
 };
 
-__host__ __device__ inline AwgnWaveLayout awgn_wave_layout(int B, int M)
+__host__ __device__ inline AwgnWaveLayout awgn_wave_layout(int B, int M, int NW = 1)
 {
     AwgnWaveLayout l;
     l.Lph = wave_lph(2 * B + M - 1);
@@ -40,6 +41,8 @@ __host__ __device__ inline AwgnWaveLayout awgn_wave_layout(int B, int M)
     l.H = take((M + 1) * 8);                           // one zero pad tap: j = M
     l.PSh = take((M + 1) * 4);
     l.VS = take(M * 4);
+    l.RED = take(NW > 1 ? 64 * 4 : 0);                 // NW > 1: cross-wave sums and scan offsets
+    l.XG = take((NW - 1) * 2 * 64 * 4);                // ... and the tap-gradient partial sums of waves 1..NW-1
     l.total = o;
     return l;
 }
@@ -83,16 +86,19 @@ __device__ __forceinline__ void amsgrad_fast(float &p, float &m, float &v, float
     p = fmaf(-step_size * m, __builtin_amdgcn_rcpf(denom), p);
 }
 
-template <int M, int NLEV, int NR>
-__global__ __launch_bounds__(64, 2) void awgn_wave_kernel(const vaeq_awgn_args a)
+// NW = wavefronts per run (1: no barriers; 2..4 for B > 384, see vaeq_dp_wave_kernel.h): wave wv owns the pairs 64 NR wv + 64 r + lane.
+template <int M, int NLEV, int NR, int NW = 1>
+__global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_args a)
 {
     constexpr int mh = M / 2, Mh = 2 * mh;
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
     extern __shared__ float4 smem4[];
     char *sm = reinterpret_cast<char *>(smem4);
-    const int lane = threadIdx.x, run = blockIdx.x;
+    const int gl = threadIdx.x, lane = NW > 1 ? (gl & 63) : gl, wv = NW > 1 ? (gl >> 6) : 0, run = blockIdx.x;
+    const int l0 = lane + 64 * NR * wv;                       // first pair of this lane
+    constexpr int NT = 64 * NW, NP = 2 * NW;
     const int B = a.B, L = 2 * B, nm = L - Mh, P2 = B / 2, nq = (nm + 3) / 4;
-    const AwgnWaveLayout lay = awgn_wave_layout(B, M);
+    const AwgnWaveLayout lay = awgn_wave_layout(B, M, NW);
     const int Lph = lay.Lph, Uph = lay.Uph;
     float2 *Xs = reinterpret_cast<float2 *>(sm + lay.X), *Es = reinterpret_cast<float2 *>(sm + lay.E);
     float2 *Us = reinterpret_cast<float2 *>(sm + lay.U), *GY = Us;
@@ -101,6 +107,7 @@ __global__ __launch_bounds__(64, 2) void awgn_wave_kernel(const vaeq_awgn_args a
     float *PSv = reinterpret_cast<float *>(sm + lay.PSv);      // [B+1] exclusive prefix sums of v_I + v_Q
     float *PSh = reinterpret_cast<float *>(sm + lay.PSh);      // [M+1] exclusive prefix sums of gC |h_j|^2
     float *VS = reinterpret_cast<float *>(sm + lay.VS);        // [M]
+    float *RED = reinterpret_cast<float *>(sm + lay.RED), *XG = reinterpret_cast<float *>(sm + lay.XG);   // NW > 1 only
 
     float amp[NLEV], nlogP[NLEV];
 #pragma unroll
@@ -112,11 +119,12 @@ __global__ __launch_bounds__(64, 2) void awgn_wave_kernel(const vaeq_awgn_args a
     const float c2 = LOG2E / var, ivar2 = 2.0f / var;          // z_i = -(yhat - a_i)^2 / var: no 1/2, no PCS term (:229)
     const float lr = a.lr[run];
 
-    for (int i = lane; i < (lay.W - lay.X) / 8; i += 64) Xs[i] = make_float2(0.f, 0.f);     // X, E, U, PSv
-    for (int i = lane; i < (lay.PSh - lay.H) / 8; i += 64) Ht[i] = make_float2(0.f, 0.f);   // incl. the pad tap
+    for (int i = gl; i < (lay.W - lay.X) / 8; i += NT) Xs[i] = make_float2(0.f, 0.f);     // X, E, U, PSv
+    for (int i = gl; i < (lay.PSh - lay.H) / 8; i += NT) Ht[i] = make_float2(0.f, 0.f);   // incl. the pad tap
     __syncthreads();
     const int tk = lane & 31, half = lane >> 5;
-    const bool owner = tk < M, wown = owner && half == 0, hown = owner && half == 1;
+    const bool worker = tk < M, owner = worker && wv == 0, wown = owner && half == 0, hown = owner && half == 1;
+    const int part = wv * 2 + half;
     const size_t g0 = (size_t)run * 2 * M + tk, g1 = g0 + M;
     float p0 = 0.f, p1 = 0.f, am0 = 0.f, am1 = 0.f, av0 = 0.f, av1 = 0.f, ax0 = 0.f, ax1 = 0.f;   // parameter pair + Adam state
     {
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(64, 2) void awgn_wave_kernel(const vaeq_awgn_args a
     const float2 *xp[NR], *ep[NR], *up[NR], *xq[NR];
 #pragma unroll
     for (int r = 0; r < NR; r++) {
-        const int pr = lane + 64 * r;
+        const int pr = l0 + 64 * r;
         act[r] = pr < P2;                                      // lane owns symbols 2 pr, 2 pr + 1 in round r
         qa[r] = pr < nq;                                       // ... and the residual quad t = 4 pr .. 4 pr + 3
         xp[r] = Xs + (act[r] ? pr : 0);                        // idle lanes shadow lane 0 (reads stay inside the arrays)
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(64, 2) void awgn_wave_kernel(const vaeq_awgn_args a
     // the window of the NEXT step is fetched into registers while the current step computes
     float4 pf[NR][2];
     auto fetch = [&](int s) {
-        const float *src = a.rx + (size_t)run * 2 * (size_t)a.S + (size_t)s * L + 4 * lane;
+        const float *src = a.rx + (size_t)run * 2 * (size_t)a.S + (size_t)s * L + 4 * l0;
 #pragma unroll
         for (int r = 0; r < NR; r++)
 #pragma unroll
@@ -172,11 +180,11 @@ __global__ __launch_bounds__(64, 2) void awgn_wave_kernel(const vaeq_awgn_args a
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int c = mh + i;                      // + 4*pr: phase (c & 3) is lane independent
-                    Xs[(c & 3) * Lph + lane + 64 * r + (c >> 2)] = make_float2(xi[i], xq_[i]);
+                    Xs[(c & 3) * Lph + l0 + 64 * r + (c >> 2)] = make_float2(xi[i], xq_[i]);
                 }
             }
         }
-        wave_lds_sync();
+        sync_lds<NW>();
 
         // ============ P1: FIR for the lane's symbol pairs; mean |y| per axis (:228)
         float2 y[NR][2];
@@ -200,12 +208,14 @@ __global__ __launch_bounds__(64, 2) void awgn_wave_kernel(const vaeq_awgn_args a
             sa0 += fabsf(y[r][0].x) + fabsf(y[r][1].x);
             sa1 += fabsf(y[r][0].y) + fabsf(y[r][1].y);
             if (yf && act[r]) {                                // un-normalised output (:227,231)
-                float *rI = yf + (size_t)s * B + 2 * (lane + 64 * r);
+                float *rI = yf + (size_t)s * B + 2 * (l0 + 64 * r);
                 *reinterpret_cast<float2 *>(rI) = make_float2(y[r][0].x, y[r][1].x);
                 *reinterpret_cast<float2 *>(rI + No) = make_float2(y[r][0].y, y[r][1].y);
             }
         }
-        const float m0 = wave_sum(sa0) / (float)B, m1 = wave_sum(sa1) / (float)B;
+        float sav[2] = {wave_sum(sa0), wave_sum(sa1)};
+        waves_sum<NW, 2>(sav, RED, lane, wv);
+        const float m0 = sav[0] / (float)B, m1 = sav[1] / (float)B;
         const float sc0 = A / m0, sc1 = A / m1;
 
         // ============ P2: soft demap + moments (registers), mu -> LDS, prefix sums of the variances
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(64, 2) void awgn_wave_kernel(const vaeq_awgn_args a
         float klsum = 0.f, vv[NR][2];
 #pragma unroll
         for (int r = 0; r < NR; r++) {
-            const int n0 = 2 * (lane + 64 * r);
+            const int n0 = 2 * (l0 + 64 * r);
             const bool inr0 = (n0 >= mh) && (n0 < B - mh) && act[r];                  // KL slice (:91)
             const bool inr1 = (n0 + 1 >= mh) && (n0 + 1 < B - mh) && act[r];
             float2 muv[2];
@@ -271,30 +281,41 @@ __global__ __launch_bounds__(64, 2) void awgn_wave_kernel(const vaeq_awgn_args a
             vv[r][0] = act[r] ? mv[r][0][0] + mv[r][0][1] : 0.f;
             vv[r][1] = act[r] ? mv[r][1][0] + mv[r][1][1] : 0.f;
             if (act[r]) {                                      // U[n]: even symbols in phase 0, odd in phase 1
-                Us[lane + 64 * r] = muv[0];
-                Us[Uph + lane + 64 * r] = muv[1];
+                Us[l0 + 64 * r] = muv[0];
+                Us[Uph + l0 + 64 * r] = muv[1];
             }
         }
         {
-            float carry = 0.f;
+            float carry = 0.f, inc[NR];
 #pragma unroll
             for (int r = 0; r < NR; r++) {
-                const int n0 = 2 * (lane + 64 * r);
-                const float inc = wave_incl_scan(vv[r][0] + vv[r][1], lane) + carry;
-                if (act[r]) {
-                    PSv[n0 + 1] = inc - vv[r][1];
-                    PSv[n0 + 2] = inc;
-                }
-                carry = __shfl(inc, 63, 64);
+                inc[r] = wave_incl_scan(vv[r][0] + vv[r][1], lane) + carry;
+                carry = __shfl(inc[r], 63, 64);
             }
-            if (lane == 0) PSv[0] = 0.f;
+            float base = 0.f;
+            if constexpr (NW > 1) {                            // totals of the waves below (fixed order)
+                if (lane == 0) RED[8 + wv] = carry;
+                sync_lds<NW>();
+#pragma unroll
+                for (int w = 0; w < NW - 1; w++)
+                    if (w < wv) base += RED[8 + w];
+            }
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const int n0 = 2 * (l0 + 64 * r);
+                if (act[r]) {
+                    PSv[n0 + 1] = inc[r] + base - vv[r][1];
+                    PSv[n0 + 2] = inc[r] + base;
+                }
+            }
+            if (gl == 0) PSv[0] = 0.f;
         }
-        wave_lds_sync();
+        sync_lds<NW>();
         if (wown) {
             const int lo = (Mh - tk + 1) >> 1, hi_ = (nm - 1 + Mh - tk) >> 1;
             VS[tk] = PSv[hi_ + 1] - PSv[lo];
         }
-        wave_lds_sync();
+        sync_lds<NW>();
 
         // ============ P3: residual e = x - D for the quads t = 4 pr .. 4 pr + 3
         //   D[2 tau + par] = sum_a h[2a + par] U[tau + mh - a],   tau in {2 pr, 2 pr + 1}, a = 0..mh
@@ -337,22 +358,25 @@ __global__ __launch_bounds__(64, 2) void awgn_wave_kernel(const vaeq_awgn_args a
                     const float2 x = xq[r][(ce & 3) * Lph + (ce >> 2)];
                     const float2 Dv = cfin(D[r][i]);
                     float2 e = make_float2(x.x - Dv.x, x.y - Dv.y);
-                    if (!qa[r] || 4 * (lane + 64 * r) + i >= nm) e = make_float2(0.f, 0.f);
-                    if (qa[r]) Es[(ce & 3) * Lph + lane + 64 * r + (ce >> 2)] = e;
+                    if (!qa[r] || 4 * (l0 + 64 * r) + i >= nm) e = make_float2(0.f, 0.f);
+                    if (qa[r]) Es[(ce & 3) * Lph + l0 + 64 * r + (ce >> 2)] = e;
                     se += e.x * e.x + e.y * e.y;
                 }
         }
-        se = wave_sum(se);
-        klsum = wave_sum(klsum);
+        {
+            float sk[2] = {wave_sum(se), wave_sum(klsum)};
+            waves_sum<NW, 2>(sk, RED + 16, lane, wv);
+            se = sk[0]; klsum = sk[1];
+        }
         float hq = 0.f;
-        if (owner) {
+        if (worker) {
             const float2 hc = Ht[tk];
             hq = hc.x * hc.x + hc.y * hc.y;
         }
-        const float vsl = owner ? VS[tk] : 0.f;
+        const float vsl = worker ? VS[tk] : 0.f;
         const float C = se + wave_sum(half ? 0.f : hq * vsl);
         const float gC = (float)nm / C;
-        if (lane == 0 && a.loss) a.loss[(size_t)run * a.steps + s] = (float)nm * logf(C) + klsum;
+        if (gl == 0 && a.loss) a.loss[(size_t)run * a.steps + s] = (float)nm * logf(C) + klsum;
         {
             float inc = gC * hq;                               // inclusive scan within each 32-lane half
 #pragma unroll
@@ -361,9 +385,9 @@ __global__ __launch_bounds__(64, 2) void awgn_wave_kernel(const vaeq_awgn_args a
                 if (tk >= d) inc += t;
             }
             if (wown) PSh[tk + 1] = inc;
-            if (lane == 0) PSh[0] = 0.f;
+            if (gl == 0) PSh[0] = 0.f;
         }
-        wave_lds_sync();
+        sync_lds<NW>();
 
         // ============ P4a: dL/dh, lane = (j = tk, half of the tau range)
         step += 1;
@@ -372,12 +396,13 @@ __global__ __launch_bounds__(64, 2) void awgn_wave_kernel(const vaeq_awgn_args a
         const float ss = lr * __builtin_amdgcn_rcpf((float)(1.0 - b1t));
         const float rbc2s = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf((float)(1.0 - b2t)));
         float gh0 = 0.f, gh1 = 0.f;
+        float2 hacc;                                           // NW > 1: this wave's part of sum e conj(U)
         {
             cacc ca = cacc0();
-            if (owner) {
+            if (worker) {
                 const int par = tk & 1, aa = tk >> 1;
-                const int T = (nm - par + 1) >> 1, Th = ((T + 3) >> 2) << 1;
-                const int ma = (half * Th) >> 1, mb = (min(T, half * Th + Th) + 1) >> 1;
+                const int T = (nm - par + 1) >> 1, Th = ((T + 2 * NP - 1) / (2 * NP)) << 1;
+                const int ma = (part * Th) >> 1, mb = (min(T, part * Th + Th) + 1) >> 1;
                 const int ceA = par + Mh, ceB = par + Mh + 2, npA = mh - aa, npB = mh - aa + 1;
                 const float2 *eA = Es + (ceA & 3) * Lph + (ceA >> 2), *eB = Es + (ceB & 3) * Lph + (ceB >> 2);
                 const float2 *uA = Us + (npA & 1) * Uph + (npA >> 1), *uB = Us + (npB & 1) * Uph + (npB >> 1);
@@ -391,7 +416,11 @@ __global__ __launch_bounds__(64, 2) void awgn_wave_kernel(const vaeq_awgn_args a
             float2 acc = cfinc(ca);                            // e * conj(U)
             acc.x += __shfl_xor(acc.x, 32, 64);
             acc.y += __shfl_xor(acc.y, 32, 64);
-            if (hown) {
+            hacc = acc;
+            if constexpr (NW > 1) {                            // waves 1.. hand their parts to wave 0 (read after the next barrier)
+                if (wv > 0) { XG[((wv - 1) * 2 + 0) * 64 + lane] = acc.x; XG[((wv - 1) * 2 + 1) * 64 + lane] = acc.y; }
+            }
+            if (NW == 1 && hown) {
                 gh0 = gC * (-2.0f * acc.x + 2.0f * p0 * vsl);
                 gh1 = gC * (-2.0f * acc.y + 2.0f * p1 * vsl);
                 if (!a.no_update) {
@@ -417,7 +446,7 @@ __global__ __launch_bounds__(64, 2) void awgn_wave_kernel(const vaeq_awgn_args a
 #pragma unroll
                     for (int sy = 0; sy < 2; sy++) {
                         const float2 au = cfinc(cu[r][sy]);    // e * conj(h)
-                        const int sx = 2 * (2 * (lane + 64 * r) + sy);
+                        const int sx = 2 * (2 * (l0 + 64 * r) + sy);
                         const int jlo = max(0, Mh - sx), jhi = max(jlo - 1, min(Mh, nm - 1 + Mh - sx));
                         const float gv = PSh[jhi + 1] - PSh[jlo];
                         const float ur = -2.0f * gC * au.x, ui = -2.0f * gC * au.y;
@@ -429,8 +458,11 @@ __global__ __launch_bounds__(64, 2) void awgn_wave_kernel(const vaeq_awgn_args a
                         dt1 = fmaf(gQ, y[r][sy].y, dt1);
                     }
             }
-            dt0 = wave_sum(dt0);
-            dt1 = wave_sum(dt1);
+            {
+                float dv[2] = {wave_sum(dt0), wave_sum(dt1)};
+                waves_sum<NW, 2>(dv, RED + 24, lane, wv);
+                dt0 = dv[0]; dt1 = dv[1];
+            }
             const float k0_ = dt0 * A / (m0 * m0) / (float)B, k1_ = dt1 * A / (m1 * m1) / (float)B;
 #pragma unroll
             for (int r = 0; r < NR; r++)
@@ -442,23 +474,36 @@ __global__ __launch_bounds__(64, 2) void awgn_wave_kernel(const vaeq_awgn_args a
                     gy[r][sy].y = gy[r][sy].y * sc1 - k1_ * sgQ;
                 }
         }
-        wave_lds_sync();                                       // every read of U / old h is done (GY aliases U)
+        sync_lds<NW>();                                       // every read of U / old h is done (GY aliases U)
+        if constexpr (NW > 1) {
+            if (hown) {
+                float2 acc = hacc;
+#pragma unroll
+                for (int w = 0; w < NW - 1; w++) { acc.x += XG[(w * 2 + 0) * 64 + lane]; acc.y += XG[(w * 2 + 1) * 64 + lane]; }
+                gh0 = gC * (-2.0f * acc.x + 2.0f * p0 * vsl);
+                gh1 = gC * (-2.0f * acc.y + 2.0f * p1 * vsl);
+                if (!a.no_update) {
+                    amsgrad_fast(p0, am0, av0, ax0, gh0, ss, rbc2s);
+                    amsgrad_fast(p1, am1, av1, ax1, gh1, ss, rbc2s);
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < NR; r++)
             if (act[r]) {
-                GY[2 * (lane + 64 * r)] = gy[r][0];
-                GY[2 * (lane + 64 * r) + 1] = gy[r][1];
+                GY[2 * (l0 + 64 * r)] = gy[r][0];
+                GY[2 * (l0 + 64 * r) + 1] = gy[r][1];
             }
         if (hown && !a.no_update) Ht[tk] = make_float2(p0, p1);
-        wave_lds_sync();
+        sync_lds<NW>();
 
         // ============ P5: dL/dw, lane = (k = tk, half of the symbol range)
         float gw0 = 0.f, gw1 = 0.f;
         {
             cacc ca = cacc0();
-            if (owner) {
-                const int Bq = ((B + 3) >> 2) << 1;
-                const int ma = (half * Bq) >> 1, mb = min(B, half * Bq + Bq) >> 1;
+            if (worker) {
+                const int Bq = ((B + 2 * NP - 1) / (2 * NP)) << 1;
+                const int ma = (part * Bq) >> 1, mb = min(B, part * Bq + Bq) >> 1;
                 const int cA = tk, cB = tk + 2;
                 const float2 *xA = Xs + (cA & 3) * Lph + (cA >> 2), *xB = Xs + (cB & 3) * Lph + (cB >> 2);
                 const float4 *G = reinterpret_cast<const float4 *>(GY);
@@ -473,6 +518,14 @@ __global__ __launch_bounds__(64, 2) void awgn_wave_kernel(const vaeq_awgn_args a
             float2 acc = cfinc(ca);                            // gy * conj(x) = (dL/dW0, -dL/dW1)
             acc.x += __shfl_xor(acc.x, 32, 64);
             acc.y += __shfl_xor(acc.y, 32, 64);
+            if constexpr (NW > 1) {                            // as for dL/dh: wave 0 adds the other waves' parts after the barrier
+                if (wv > 0) { XG[((wv - 1) * 2 + 0) * 64 + lane] = acc.x; XG[((wv - 1) * 2 + 1) * 64 + lane] = acc.y; }
+                sync_lds<NW>();
+                if (wown) {
+#pragma unroll
+                    for (int w = 0; w < NW - 1; w++) { acc.x += XG[(w * 2 + 0) * 64 + lane]; acc.y += XG[(w * 2 + 1) * 64 + lane]; }
+                }
+            }
             if (wown) {
                 gw0 = acc.x;
                 gw1 = -acc.y;
@@ -487,7 +540,7 @@ __global__ __launch_bounds__(64, 2) void awgn_wave_kernel(const vaeq_awgn_args a
             if (a.dbg_gW && !half) { a.dbg_gW[g0] = gw0; a.dbg_gW[g1] = gw1; }
             if (a.dbg_gh && half) { a.dbg_gh[g0] = gh0; a.dbg_gh[g1] = gh1; }
         }
-        wave_lds_sync();
+        sync_lds<NW>();
     }
 
     if (owner && !a.no_update) {
@@ -498,18 +551,18 @@ __global__ __launch_bounds__(64, 2) void awgn_wave_kernel(const vaeq_awgn_args a
         pv[g0] = av0; pv[g1] = av1;
         px[g0] = ax0; px[g1] = ax1;
     }
-    if (lane == 0 && !a.no_update) a.step[run] = step;
+    if (gl == 0 && !a.no_update) a.step[run] = step;
 }
 
-template <int M, int NLEV, int NR>
+template <int M, int NLEV, int NR, int NW = 1>
 static int launch_awgn_wave_k(const vaeq_awgn_args &a, hipStream_t st)
 {
-    const size_t lds = (size_t)awgn_wave_layout(a.B, M).total;
-    auto k = awgn_wave_kernel<M, NLEV, NR>;
+    const size_t lds = (size_t)awgn_wave_layout(a.B, M, NW).total;
+    auto k = awgn_wave_kernel<M, NLEV, NR, NW>;
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VAEQ_ERR_LDS;
-    hipLaunchKernelGGL(k, dim3(a.R), dim3(64), lds, st, a);
+    hipLaunchKernelGGL(k, dim3(a.R), dim3(64 * NW), lds, st, a);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
 
@@ -520,6 +573,11 @@ static int launch_awgn_wave_r(const vaeq_awgn_args &a, hipStream_t st)
     case 1: return launch_awgn_wave_k<M, NLEV, 1>(a, st);
     case 2: return launch_awgn_wave_k<M, NLEV, 2>(a, st);
     case 3: return launch_awgn_wave_k<M, NLEV, 3>(a, st);
+    case 4: return launch_awgn_wave_k<M, NLEV, 2, 2>(a, st);   // B <= 512: two wavefronts x two rounds
+    case 5:
+    case 6: return launch_awgn_wave_k<M, NLEV, 2, 3>(a, st);   // B <= 768
+    case 7:
+    case 8: return launch_awgn_wave_k<M, NLEV, 2, 4>(a, st);   // B <= 1024
     }
     return VAEQ_ERR_SHAPE;
 }
@@ -538,7 +596,7 @@ static int launch_awgn_wave_lev(const vaeq_awgn_args &a, hipStream_t st)
 // Whether the wave-per-run kernel covers this call (else the generic kernel runs).
 bool awgn_wave_supported(const vaeq_awgn_args &a)
 {
-    if (a.sps != 2 || (a.B & 1) || a.B > 384 || a.B < 2 * (a.M / 2) + 2) return false;
+    if (a.sps != 2 || (a.B & 1) || a.B > 1024 || a.B < 2 * (a.M / 2) + 2) return false;
     if (!(a.M == 25 || a.M == 17 || a.M == 9)) return false;
     if ((a.S & 3) || (reinterpret_cast<uintptr_t>(a.rx) & 15)) return false;              // 16-byte window loads
     if (a.q_out && (reinterpret_cast<uintptr_t>(a.q_out) & 7)) return false;
@@ -556,6 +614,6 @@ int launch_awgn_wave(const vaeq_awgn_args &a, hipStream_t st)
     return VAEQ_ERR_SHAPE;
 }
 
-int64_t awgn_wave_lds(int B, int M) { return (int64_t)awgn_wave_layout(B, M).total; }
+int64_t awgn_wave_lds(int B, int M) { return (int64_t)awgn_wave_layout(B, M, B <= 384 ? 1 : (B / 2 + 127) / 128).total; }
 
 }  // namespace vaeq

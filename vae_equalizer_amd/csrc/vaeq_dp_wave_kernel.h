@@ -108,13 +108,6 @@ __device__ __forceinline__ void pair_fir(cacc (&acc)[2][2], const float2 *xp, in
 // NW = wavefronts per run: 1 (B <= 128, no barriers at all) or 2 / 4 / 8 (B <= 256 / 512 / 1024): thread gl = 64 wv + lane owns the symbol pair
 // (2 gl, 2 gl + 1), the tap-gradient sums are split 2 NW ways, wave 0 owns the taps and their Adam moments; phases are separated
 // by s_barrier after an LDS-only wait (sync_lds), so the in-flight q / y stores still never stall a phase.
-template <int NW>
-__device__ __forceinline__ void sync_lds()
-{
-    if constexpr (NW == 1) wave_lds_sync();
-    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 template <int M, int NLEV, int BT, bool PAIR, int OUT, int NW = 1>
 __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args a)
 {

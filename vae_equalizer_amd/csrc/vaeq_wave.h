@@ -9,6 +9,35 @@ namespace vaeq {
 // __syncthreads() would also emit s_waitcnt vmcnt(0) and stall every phase on the step's in-flight q/y stores.
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("" ::: "memory"); }
 
+// NW wavefronts per run: phases are separated by s_barrier after an LDS-only wait -- the in-flight global stores of a step still
+// never stall a phase (gfx950 backs off barriers; the compiler adds no vmcnt(0) in front of this one).
+template <int NW>
+__device__ __forceinline__ void sync_lds()
+{
+    if constexpr (NW == 1) wave_lds_sync();
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Sum K per-wave values (already reduced over the wave's lanes) over the NW waves of a run, same order in every wave; red: K NW floats.
+template <int NW, int K>
+__device__ __forceinline__ void waves_sum(float (&v)[K], float *red, int lane, int wv)
+{
+    if constexpr (NW > 1) {
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < K; k++) red[k * NW + wv] = v[k];
+        }
+        sync_lds<NW>();
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            float t = red[k * NW];
+#pragma unroll
+            for (int w = 1; w < NW; w++) t += red[k * NW + w];
+            v[k] = t;
+        }
+    }
+}
+
 typedef float v2f __attribute__((ext_vector_type(2)));   // element-wise ops compile to v_pk_{add,mul,fma}_f32
 
 // Complex MACs.  A complex accumulator is kept as TWO packed partial sums,  a = sum re(t) * v  and  b = sum im(t) * v  (t = tap,
