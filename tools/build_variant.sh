@@ -1,8 +1,18 @@
 #!/bin/bash
-# Build an experimental variant of libvaeq_hip.so with a replacement for vaeq_dp_wave.hip:  tools/build_variant.sh <name> <wave_src>
-# -> gpurun_variants/libvaeq_<name>.so ; run with VAEQ_LIB=$PWD/gpurun_variants/libvaeq_<name>.so
+# Build an experimental variant of libvaeq_hip.so in which some translation units are replaced:
+#   tools/build_variant.sh <name> <replacement.hip>...   (each replaces the csrc file of the same base name; extra hipcc flags via HIPFLAGS)
+# -> gpurun_variants/libvaeq_<name>.so ; run with VAEQ_LIB=$PWD/gpurun_variants/libvaeq_<name>.so (tools/ab.sh A/Bs such builds).
+# The unchanged units are taken from vae_equalizer_amd/_obj (python -c "from vae_equalizer_amd import _native; _native.build()").
 set -e
-ROOT=$(cd $(dirname $0)/.. && pwd); C=$ROOT/vae_equalizer_amd/csrc
-mkdir -p $ROOT/gpurun_variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I $ROOT/include -I $C $C/vaeq_dp.hip $2 $C/vaeq_awgn.hip $C/vaeq_misc.hip -o $ROOT/gpurun_variants/libvaeq_$1.so 2>&1 | grep -E "error" || true
-ls -la $ROOT/gpurun_variants/libvaeq_$1.so | awk '{print $5, $9}'
+ROOT=$(cd $(dirname $0)/.. && pwd); C=$ROOT/vae_equalizer_amd/csrc; O=$ROOT/vae_equalizer_amd/_obj; V=$ROOT/gpurun_variants
+name=$1; shift
+mkdir -p $V/$name.obj
+objs=$(ls $O/*.o)
+for src in "$@"; do
+  b=$(basename $src .hip)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $HIPFLAGS -I $ROOT/include -I $C -c $src -o $V/$name.obj/$b.o
+  objs=$(echo "$objs" | grep -v "/$b.o$"; echo $V/$name.obj/$b.o)
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared $objs -lhipfft -o $V/libvaeq_$name.so
+rm -rf $V/$name.obj
+ls -la $V/libvaeq_$name.so | awk '{print $5, $9}'
