@@ -255,6 +255,40 @@ def test_multiwave_flex_windows_equal_generic_kernel(B, k0, klen):
     assert np.max(np.abs(_np(ea.W) - _np(eb.W))) < 2e-5 and np.max(np.abs(_np(ea.h) - _np(eb.h))) < 2e-5
 
 
+@pytest.mark.parametrize("B,M", [(200, 25), (600, 13)])
+def test_multiwave_against_oracle_frames_and_determinism(B, M):
+    """Two / eight wavefronts per run: each run == the CPU oracle; two frames in one launch == two launches (bitwise); a repeat is
+    bitwise identical (fixed-order cross-wave sums); no_update leaves taps, moments and the step counter alone."""
+    from vae_equalizer_amd.engine import DPEngine
+    rng = np.random.default_rng(B)
+    R, n, sps, steps = 4, 4, 2, 3
+    amp = np.array([-3, -1, 1, 3], np.float32) / np.sqrt(10).astype(np.float32)
+    P = rng.dirichlet(np.ones(n) * 5, R).astype(np.float32)
+    var = rng.uniform(0.002, 0.02, (R, 2)).astype(np.float32)
+    nu_sc = rng.uniform(0, 1, R).astype(np.float32)
+    lr = rng.uniform(1e-3, 4e-3, R).astype(np.float32)
+    rx = (0.4 * rng.standard_normal((R, 2, 2, 2, steps * B * sps))).astype(np.float32)          # [R, F=2, 2, 2, S]
+    rxd = torch.from_numpy(rx).to(DEV)
+    mk = lambda: DPEngine(R, M, amp, P, var, nu_sc, DEV, sps, 1)
+    e1, e2, e3 = mk(), mk(), mk()
+    r1 = e1.train(rxd, B, steps, lr)
+    r2 = [e2.train(rxd[:, f:f + 1].contiguous(), B, steps, lr) for f in range(2)]
+    r3 = e3.train(rxd, B, steps, lr)
+    torch.cuda.synchronize()
+    assert torch.equal(r1["loss"], torch.cat([x["loss"] for x in r2], 1)) and torch.equal(e1.W, e2.W) and torch.equal(e1.h, e2.h)
+    assert torch.equal(r1["loss"], r3["loss"]) and torch.equal(r1["q"], r3["q"]) and torch.equal(e1.W, e3.W) and torch.equal(e1.mh, e3.mh)
+    for i in range(R):
+        st = oracle.DPState(M, np.float32)
+        lo = [oracle.dp_train(st, rx[i, f], steps, B, amp, P[i], var[i], float(nu_sc[i]), float(lr[i]), float(lr[i]), sps) for f in range(2)]
+        assert np.max(np.abs(_np(r1["loss"])[i, 1] - lo[1]["loss"]) / np.abs(lo[1]["loss"])) < 2e-5, i
+        assert np.max(np.abs(_np(e1.W)[i] - st.W)) < 2e-5 and np.max(np.abs(_np(e1.h)[i] - st.h)) < 2e-5, i
+        assert relerr(_np(r1["y"])[i, 1], lo[1]["out"]) < 2e-5, i
+    W0, h0, m0, st0 = e1.W.clone(), e1.h.clone(), e1.mW.clone(), e1.step.clone()
+    e1.train(rxd, B, steps, lr, no_update=True)
+    torch.cuda.synchronize()
+    assert torch.equal(e1.W, W0) and torch.equal(e1.h, h0) and torch.equal(e1.mW, m0) and torch.equal(e1.step, st0)
+
+
 def test_wave_kernel_refused_for_unsupported_shape():
     from vae_equalizer_amd import _native as nat
     from vae_equalizer_amd.engine import DPEngine
