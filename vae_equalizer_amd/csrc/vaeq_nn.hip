@@ -15,6 +15,7 @@
 // Forward convolutions: item = (4 output channels, sample), consecutive lanes on consecutive samples, the 4 channels' weights of a
 // tap in one 16-byte broadcast read of a transposed weight copy.  Weight gradients: one wave per (input, tap) column, lanes stride
 // over the samples with all C channel sums in registers, then wave reductions -- every LDS access pattern is conflict free.
+// C = 16 (64-QAM): these five GEMM-shaped phases run on v_mfma_f32_16x16x4_f32 instead (mfma_conv16 / mfma_wgrad16 / mfma_convT16 below).
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,12 +33,14 @@ struct NNLayout {
 
 __host__ __device__ inline int npad4(int x) { return (x + 3) & ~3; }
 
-__host__ __device__ inline NNLayout nn_layout(int B, int sps, int M, int n, int k1, int k2, bool bn = false)
+__host__ __device__ inline NNLayout nn_layout(int B, int sps, int M, int n, int k1, int k2, bool bn = false, bool eval = false)
 {
     NNLayout l;
     l.C = 2 * n; l.L = B * sps; l.p1 = k1 / 2; l.p2 = k2 / 2;
     l.Lx = npad4(l.L + 2 * l.p1 + 8);                  // zero halo + room for the 4-wide windows of the last quad
     l.Lz = npad4(l.L + 2 * l.p2 + 4);
+    if (n == 8)                                        // C = 16 (MFMA path): rows 4 (mod 64) dwords apart, so that 16 channels x 4
+        while ((l.Lz & 63) != 4) l.Lz += 4;            // consecutive samples (an MFMA operand / result) fall into 64 different banks
     l.mh = M / 2; l.Mh = 2 * l.mh; l.nm = l.L - l.Mh;
     l.NW1 = l.C * 2 * k1;
     l.oW1 = 0; l.oB1 = l.NW1; l.oW2 = l.oB1 + l.C; l.oB2 = l.oW2 + l.C * l.C * k2;
@@ -47,15 +50,16 @@ __host__ __device__ inline NNLayout nn_layout(int B, int sps, int M, int n, int 
     auto take = [&](int cnt) { int r = o; o += npad4(cnt); return r; };
     l.xs = take(2 * l.Lx);
     l.z1 = take(l.C * l.Lz);
-    l.zb = bn ? take(l.C * l.Lz) : l.z1;               // Net_BN: BatchNorm output (fc2's input); z1 then holds the normalised zhat
+    l.zb = bn && !eval ? take(l.C * l.Lz) : l.z1;      // Net_BN: BatchNorm output (fc2's input); z1 then holds the normalised zhat
+                                                       // (eval mode folds the running statistics into fc1's epilogue: no second buffer)
     l.bnst = take(bn ? 6 * l.C : 0);                   // mean, rstd (batch) | running_mean, running_var | eval scale, shift
     l.a2 = take(l.C * B);
     l.mu = take(2 * B); l.vr = take(2 * B);
     l.es = take(2 * l.nm);
     l.VS = take(M);
     l.th = take(l.NP); l.gr = take(l.NP); l.am = take(l.NP); l.av = take(l.NP); l.ax = take(l.NP);
-    l.w1t = take(l.NW1);                               // fc1.weight as [i][k][c]: the 4 channels of a thread in one 16-byte read
-    l.w2t = take(l.C * l.C * k2);                      // fc2.weight as [cc][k][c]
+    l.w1t = take(l.NW1 + 7 * l.C);                     // fc1.weight as [i][k][c]: the 4 channels of a thread in one 16-byte read
+    l.w2t = take(l.C * l.C * k2 + 7 * l.C);            // fc2.weight as [cc][k][c]   (both zero-padded to a multiple of 8 rows: two MFMA k-steps)
     l.w2u = take(l.C * l.C * k2);                      // fc2.weight as [k][c][cc] (backward through fc2: 4 input channels per read)
     l.red = take(64);
     l.total = o;
@@ -145,11 +149,176 @@ __device__ __forceinline__ void nn_transpose_weights(const NNLayout &l, int k1, 
         const int c = j % C, r = j / C, cc = r / k2, k = r - cc * k2;
         w2t[j] = th[l.oW2 + (c * C + cc) * k2 + k];
     }
+    for (int j = threadIdx.x; j < 7 * C; j += NT) w1t[l.NW1 + j] = w2t[C * C * k2 + j] = 0.f;
     if (w2u)
         for (int j = threadIdx.x; j < C * C * k2; j += NT) {
             const int cc = j % C, r = j / C, c = r % C, k = r / C;
             w2u[j] = th[l.oW2 + (c * C + cc) * k2 + k];
         }
+}
+
+// ---- C = 16 (64-QAM): the three convolutions and their weight gradients as GEMMs on v_mfma_f32_16x16x4_f32 -- f32 in, f32 accumulate,
+// every output one exact fmaf chain.  Operand maps (cdna_hip_programming.md): A[m = lane & 15][k = lane >> 4], B[k = lane >> 4][n = lane & 15],
+// D[m = 4 (lane >> 4) + reg][n = lane & 15].  M is always the 16 channels.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Conv1d with 16 output channels:  D[c][col] = bias[c] + sum_{kk < K} wt[kk 16 + c] * in[(kk / kd) rstride + kk % kd + col cstep].
+// wt is zero-padded to a multiple of 8 rows.  A wave takes TB column tiles at once: one weight read feeds all of them, and the operands
+// of the next two k-steps are fetched from LDS while the 2 TB MFMAs of the current two run (straight-line code, no division).
+// out(c0, col, acc): the lane's channels c0 .. c0 + 3 of column col.
+template <int NT, int TB, typename OutF>
+__device__ __forceinline__ void mfma_conv16(const float *wt, int K, int kd, int rstride, const float *in, int cstep, int ncols, const float *bias,
+                                            OutF out)
+{
+    constexpr int NWV = NT / 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lc = lane & 15, lg = lane >> 4;
+    const int ntile = (ncols + 15) >> 4, K8 = (K + 7) >> 3;             // trips of two k-steps (wt is padded to 8 rows by its owner)
+    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias + 4 * lg);
+    // sample offset of the lane's row kk = 4 t + lg: (kk / kd) rstride + kk % kd, advanced by 4 rows per k-step without a division
+    const int q4 = 4 / kd, r4 = 4 - q4 * kd;                            // 4 = q4 kd + r4
+    const int i0 = lg / kd, k0 = lg - i0 * kd;
+    auto adv = [&](int &i, int &k) {
+        i += q4; k += r4;
+        const bool w = k >= kd;
+        i += w; k -= w ? kd : 0;
+    };
+    auto ld = [&](int t, int i, int k, float &a, float (&b)[TB], const int (&colb)[TB]) {
+        a = wt[64 * t + lane];
+        const float *bp = in + (4 * t + lg < K ? i * rstride + k : 0);  // padded rows: weight 0, any finite sample
+#pragma unroll
+        for (int u = 0; u < TB; u++) b[u] = bp[colb[u]];
+    };
+    for (int tg = wv * TB; tg < ntile; tg += NWV * TB) {
+        f32x4 acc[TB];
+        int colb[TB];
+#pragma unroll
+        for (int u = 0; u < TB; u++) {
+            acc[u] = b4;
+            const int col = (tg + u) * 16 + lc;
+            colb[u] = (col < ncols ? col : ncols - 1) * cstep;         // clamped columns are computed and dropped
+        }
+        int i = i0, k = k0;
+        float a0, a1, b0[TB], b1[TB];
+        ld(0, i, k, a0, b0, colb); adv(i, k);
+        ld(1, i, k, a1, b1, colb); adv(i, k);
+        for (int t2 = 0; t2 < K8; t2++) {
+            const float x0 = a0, x1 = a1;
+            float y0[TB], y1[TB];
+#pragma unroll
+            for (int u = 0; u < TB; u++) { y0[u] = b0[u]; y1[u] = b1[u]; }
+            const int tn = 2 * t2 + 2;                                  // past the end: rows >= K (sample offset 0) and the 128 floats behind
+                                                                        // wt's padding (another LDS array) are fetched and never used
+            ld(tn, i, k, a0, b0, colb); adv(i, k);
+            ld(tn + 1, i, k, a1, b1, colb); adv(i, k);
+#pragma unroll
+            for (int u = 0; u < TB; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, y0[u], acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < TB; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, y1[u], acc[u], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < TB; u++) {
+            const int col = (tg + u) * 16 + lc;
+            if (col < ncols) out(4 * lg, col, acc[u]);
+        }
+    }
+}
+
+// Weight gradient of such a convolution:  G[c][j] = sum_{r < nrows} g[c gstride + r] * in[(j / kd) rstride + j % kd + r rstep]  for j < J,
+// and the bias gradient G[c][J] = sum_r g[c gstride + r] as one more column.  Waves = (column tile, part of the row range); parts are
+// combined through `scratch` (cap floats; every thread of the block must make this call: it may hold a barrier).  Four k-steps of
+// operands are fetched per trip, four accumulators take them in turn.
+// out(c0, j, acc): the lane's channels c0 .. c0 + 3 of column j <= J.
+template <int NT, typename OutF>
+__device__ __forceinline__ void mfma_wgrad16(const float *g, int gstride, int nrows, const float *in, int rstep, int J, int kd, int rstride,
+                                             float *scratch, int cap, OutF out)
+{
+    constexpr int NWV = NT / 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lc = lane & 15, lg = lane >> 4;
+    const int ntile = (J + 1 + 15) >> 4, ntw = ntile < NWV ? ntile : NWV;
+    int nsplit = NWV / ntw;
+    if ((nsplit - 1) * ntw * 256 > cap) nsplit = 1 + cap / (ntw * 256);
+    const int tile0 = wv % ntw, part = wv / ntw;
+    const int steps = (nrows + 3) >> 2, sp = (((steps + nsplit - 1) / nsplit) + 3) & ~3;     // k-steps per part, a multiple of 4
+    for (int tile = tile0; tile < ntile; tile += ntw) {            // more than one trip only when ntile > NWV (then nsplit == 1)
+        f32x4 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (part < nsplit) {
+            const int j = tile * 16 + lc;
+            const int ji = j < J ? j / kd : 0, joff = j < J ? ji * rstride + (j - ji * kd) : 0;
+            const bool ones = j == J;
+            const float *gp = g + lc * gstride;
+            const int t1 = min(steps, (part + 1) * sp);
+            for (int t = part * sp; t < t1; t += 4) {
+                float av[4], bv[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {                      // rows past the end: clamped reads, zero gradient
+                    const int r = 4 * (t + q) + lg, rb = r < nrows ? r : nrows - 1;
+                    const float a_ = gp[rb], b_ = in[joff + rb * rstep];
+                    av[q] = r < nrows ? a_ : 0.f;
+                    bv[q] = ones ? 1.0f : b_;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc[q], 0, 0, 0);
+            }
+            acc[0] += acc[1]; acc[2] += acc[3]; acc[0] += acc[2];
+            if (part > 0) {
+                float *sp_ = scratch + ((part - 1) * ntw + tile0) * 256 + lane;
+                sp_[0] = acc[0].x; sp_[64] = acc[0].y; sp_[128] = acc[0].z; sp_[192] = acc[0].w;
+            }
+        }
+        if (nsplit > 1) __syncthreads();
+        if (part == 0) {
+            for (int q = 1; q < nsplit; q++) {
+                const float *sp_ = scratch + ((q - 1) * ntw + tile0) * 256 + lane;
+                acc[0].x += sp_[0]; acc[0].y += sp_[64]; acc[0].z += sp_[128]; acc[0].w += sp_[192];
+            }
+            const int j = tile * 16 + lc;
+            if (j <= J) out(4 * lg, j, acc[0]);
+        }
+    }
+}
+
+// Backward through the strided Conv1d fc2 (16 -> 16 channels):  gz[cc][s] = sum_{c, k : (s + p2 - k) % sps == 0} w2u[(k 16 + c) 16 + cc] * g2[c B + (s + p2 - k) / sps],
+// one polyphase component of s at a time (for each only every sps-th tap contributes).  out(cc0, s, acc).
+template <int NT, int TB, typename OutF>
+__device__ __forceinline__ void mfma_convT16(const float *w2u, int k2, int p2, int sps, const float *g2, int B, int L, OutF out)
+{
+    constexpr int NWV = NT / 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lc = lane & 15, lg = lane >> 4;
+    for (int ph = 0; ph < sps; ph++) {
+        const int kf = (ph + p2) % sps, nk = kf < k2 ? (k2 - kf + sps - 1) / sps : 0;
+        const int ncols = (L - ph + sps - 1) / sps, ntile = (ncols + 15) >> 4;      // columns m: s = sps m + ph
+        for (int tg = wv * TB; tg < ntile; tg += NWV * TB) {
+            f32x4 acc[TB];
+#pragma unroll
+            for (int u = 0; u < TB; u++) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int kj = 0; kj < nk; kj++) {
+                const int k = kf + kj * sps, nsh = (ph + p2 - k) / sps;             // exact division (may be negative)
+                float av[4], bv[4][TB];
+#pragma unroll
+                for (int cb = 0; cb < 4; cb++) {                                    // all 4 + 4 TB operands first, then the MFMAs
+                    const int c = 4 * cb + lg;
+                    av[cb] = w2u[(k * 16 + c) * 16 + lc];
+#pragma unroll
+                    for (int u = 0; u < TB; u++) {
+                        const int n = (tg + u) * 16 + lc + nsh, nc = n < 0 ? 0 : (n < B ? n : B - 1);
+                        const float b_ = g2[c * B + nc];
+                        bv[cb][u] = (n >= 0 && n < B) ? b_ : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+                    for (int u = 0; u < TB; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb], bv[cb][u], acc[u], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < TB; u++) {
+                const int m = (tg + u) * 16 + lc;
+                if (m < ncols) out(4 * lg, sps * m + ph, acc[u]);
+            }
+        }
+    }
 }
 
 // ---- forward on one LDS-resident window: xs (zero-haloed input) -> z1 (ELU output, zero-haloed) -> a2 (logits).
@@ -161,6 +330,20 @@ __device__ __forceinline__ void nn_fc1_elu(const NNLayout &l, int k1, const floa
 {
     // z1p[c][p2 + s] for s in [0, Lvalid); entries whose absolute position (zlo + s) lies outside [0, zhi) are fc2's zero padding
     constexpr int C = 2 * NLEV, CQ = C / 4;
+    if constexpr (C == 16) {
+        mfma_conv16<NT, (NT >= 1024 ? 3 : 5)>(w1t, 2 * k1, k1, l.Lx, xs, 1, Lvalid, th + l.oB1, [&](int c0, int sy, f32x4 acc) {
+            const int pos = zlo + sy;
+            const bool in = pos >= 0 && pos < zhi;
+            const float av[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                float z = av[t] > 0.f ? av[t] : __expf(av[t]) - 1.0f;                     // F.elu, alpha = 1 (:177)
+                if (aff) z = fmaf(aff[c0 + t], z, aff[C + c0 + t]);                       // eval-mode BatchNorm: running statistics folded
+                z1[(c0 + t) * l.Lz + l.p2 + sy] = in ? z : 0.f;
+            }
+        });
+        return;
+    }
     typedef float v2f __attribute__((ext_vector_type(2)));     // channel pairs: every MAC below is a v_pk_fma_f32
     const int H = (Lvalid + 1) / 2;                            // a thread takes samples sx and sx + H: one weight read feeds 8 MACs
     for (int it = threadIdx.x; it < CQ * H; it += NT) {
@@ -201,6 +384,13 @@ __device__ __forceinline__ void nn_fc2(const NNLayout &l, int sps, int k2, int B
                                        float *a2)
 {
     constexpr int C = 2 * NLEV, CQ = C / 4;
+    if constexpr (C == 16) {
+        mfma_conv16<NT, (NT >= 1024 ? 1 : 3)>(w2t, C * k2, k2, l.Lz, z1, sps, Bt, th + l.oB2, [&](int c0, int n, f32x4 acc) {
+            a2[(c0 + 0) * astride + n] = acc.x; a2[(c0 + 1) * astride + n] = acc.y;
+            a2[(c0 + 2) * astride + n] = acc.z; a2[(c0 + 3) * astride + n] = acc.w;
+        });
+        return;
+    }
     typedef float v2f __attribute__((ext_vector_type(2)));
     const int H = (Bt + 1) / 2;
     for (int it = threadIdx.x; it < CQ * H; it += NT) {
@@ -407,7 +597,17 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
         }
         __syncthreads();
         // ---- P7a: fc2 weight / bias gradients: one wave per (input channel, group of 4 taps); pseudo group at the end: the biases
-        {
+        if constexpr (C == 16) {
+            // gw2[c][cc][k] = sum_n g2[c][n] zb[cc][n sps + k]: columns j = cc k2 + k, plus the bias column
+            mfma_wgrad16<NT>(a2, B, B, zb, sps, C * k2, k2, Lz, mu, 4 * B + 2 * nm, [&](int c0, int j, f32x4 acc) {
+                const float av_[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if (j == C * k2) gr[l.oB2 + c0 + t] = av_[t];
+                    else gr[l.oW2 + (c0 + t) * C * k2 + j] = av_[t];
+                }
+            });
+        } else {
             const int nkq = (k2 + 3) / 4, ngrp = C * nkq;
             for (int grp = wv; grp <= ngrp; grp += NWV) {
                 const bool bias = grp == ngrp;
@@ -421,6 +621,20 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
         __syncthreads();
         // ---- P7b: dL/dz1 through fc2, times ELU' -> dL/da1 in place of z1; item = (4 input channels, sample): every dL/dlogit read
         //      feeds the 4 channels, whose weights come as one 16-byte read of the [k][c][cc] copy
+        if constexpr (C == 16) {
+            mfma_convT16<NT, 3>(w2u, k2, p2, sps, a2, B, L, [&](int cc0, int sx, f32x4 acc) {
+                const float gg[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int ix = (cc0 + u) * Lz + p2 + sx;
+                    if (BN) zb[ix] = gg[u];
+                    else {
+                        const float z = z1[ix];
+                        z1[ix] = gg[u] * (z > 0.f ? 1.0f : z + 1.0f);
+                    }
+                }
+            });
+        } else
         for (int it = tid; it < CQ * L; it += NT) {
             const int ccq = it / L, sx = it - ccq * L;
             float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
@@ -469,7 +683,17 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
             __syncthreads();
         }
         // ---- P8: fc1 weight / bias gradients, same scheme: one wave per (input row, group of 4 taps)
-        {
+        if constexpr (C == 16) {
+            // gw1[c][i][k] = sum_s gz[c][s] x[i][s + k]: columns j = i k1 + k, plus the bias column
+            mfma_wgrad16<NT>(z1 + p2, Lz, L, xs, 1, 2 * k1, k1, Lx, mu, 4 * B + 2 * nm, [&](int c0, int j, f32x4 acc) {
+                const float av_[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if (j == 2 * k1) gr[l.oB1 + c0 + t] = av_[t];
+                    else gr[l.oW1 + (c0 + t) * 2 * k1 + j] = av_[t];
+                }
+            });
+        } else {
             const int nkq = (k1 + 3) / 4, ngrp = 2 * nkq;
             for (int grp = wv; grp <= ngrp; grp += NWV) {
                 const bool bias = grp == ngrp;
@@ -538,7 +762,7 @@ __global__ __launch_bounds__(NT) void nn_forward_kernel(int N, int sps, int M, i
     constexpr int C = 2 * NLEV;
     const int tid = threadIdx.x, run = blockIdx.x;
     const bool bn = bn_running != nullptr;
-    const NNLayout l = nn_layout(NN_TILE, sps, M, NLEV, k1, k2, bn);
+    const NNLayout l = nn_layout(NN_TILE, sps, M, NLEV, k1, k2, bn, true);
     float *xs = sm + l.xs, *z1 = sm + l.z1, *a2 = sm + l.a2, *th = sm + l.th, *w1t = sm + l.w1t, *w2t = sm + l.w2t;
     float *aff = bn ? sm + l.bnst + 4 * C : nullptr;
     for (int i = tid; i < l.NP; i += NT) th[i] = theta[(size_t)run * l.NP + i];
@@ -586,7 +810,7 @@ __global__ __launch_bounds__(NT) void nn_validate_kernel(int N, int sps, int M, 
     const int tid = threadIdx.x, run = blockIdx.x;
     constexpr int C = 2 * NLEV;
     const bool bn = bn_running != nullptr;
-    const NNLayout l = nn_layout(NN_TILE, sps, M, NLEV, k1, k2, bn);
+    const NNLayout l = nn_layout(NN_TILE, sps, M, NLEV, k1, k2, bn, true);
     float *xs = sm + l.xs, *z1 = sm + l.z1, *a2 = sm + l.a2, *th = sm + l.th, *w1t = sm + l.w1t, *w2t = sm + l.w2t, *red = sm + l.red;
     float *aff = bn ? sm + l.bnst + 4 * C : nullptr;
     unsigned char *decs = reinterpret_cast<unsigned char *>(sm + l.total);      // [N] after the forward working set
@@ -642,7 +866,7 @@ template <int NLEV>
 static int launch_nn_validate(int R, int N, int sps, int M, int k1, int k2, int n_shift, const float *x, const float *theta, const float *bn,
                               const float *amp, const __half *data, float *ser, int *shift, hipStream_t st)
 {
-    const size_t lds = (size_t)nn_layout(NN_TILE, sps, M, NLEV, k1, k2, bn != nullptr).total * 4 + (((size_t)N + 15) & ~(size_t)15);
+    const size_t lds = (size_t)nn_layout(NN_TILE, sps, M, NLEV, k1, k2, bn != nullptr, true).total * 4 + (((size_t)N + 15) & ~(size_t)15);
     if (lds > 150 * 1024) return VAEQ_ERR_LDS;
     auto k = nn_validate_kernel<1024, NLEV>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -665,7 +889,7 @@ template <int NLEV>
 static int launch_nn_forward(int R, int N, int sps, int M, int k1, int k2, const float *x, const float *theta, const float *bn, float *q,
                              hipStream_t st)
 {
-    const size_t lds = (size_t)nn_layout(NN_TILE, sps, M, NLEV, k1, k2, bn != nullptr).total * 4;
+    const size_t lds = (size_t)nn_layout(NN_TILE, sps, M, NLEV, k1, k2, bn != nullptr, true).total * 4;
     if (lds > 160 * 1024) return VAEQ_ERR_LDS;
     auto k = nn_forward_kernel<1024, NLEV>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
