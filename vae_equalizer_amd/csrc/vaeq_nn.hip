@@ -249,13 +249,32 @@ __device__ __forceinline__ void mfma_wgrad16(const float *g, int gstride, int nr
             const bool ones = j == J;
             const float *gp = g + lc * gstride;
             const int t1 = min(steps, (part + 1) * sp);
-            for (int t = part * sp; t < t1; t += 4) {
+            // main trips: four k-steps whose rows all exist -- plain pointer walks, the next trip's operands are fetched while the
+            // current four MFMAs run; the (at most one) ragged trip at the end of the row range takes the clamped path below
+            const int t0 = part * sp, tfull = nrows >> 2;
+            const int nmain = max(0, (min(t1, tfull) - t0) >> 2);
+            const float *pa = gp + 4 * t0 + lg, *pb = in + joff + (4 * t0 + lg) * rstep;
+            const int sa = 4, sb = 4 * rstep;
+            float an[4], bn[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { an[q] = pa[q * sa]; bn[q] = pb[q * sb]; }       // (in range even when nmain == 0: rows < 4 t0 + 16 <= padded arrays)
+            for (int m = 0; m < nmain; m++) {
                 float av[4], bv[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {                      // rows past the end: clamped reads, zero gradient
+                for (int q = 0; q < 4; q++) { av[q] = an[q]; bv[q] = ones ? 1.0f : bn[q]; }
+                if (m + 1 < nmain) { pa += 4 * sa; pb += 4 * sb; }
+#pragma unroll
+                for (int q = 0; q < 4; q++) { an[q] = pa[q * sa]; bn[q] = pb[q * sb]; }
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc[q], 0, 0, 0);
+            }
+            for (int t = t0 + 4 * nmain; t < t1; t += 4) {
+                float av[4], bv[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {                      // rows past the end (of the array or of this part): clamped reads, zero gradient
                     const int r = 4 * (t + q) + lg, rb = r < nrows ? r : nrows - 1;
                     const float a_ = gp[rb], b_ = in[joff + rb * rstep];
-                    av[q] = r < nrows ? a_ : 0.f;
+                    av[q] = (r < nrows && t + q < t1) ? a_ : 0.f;
                     bv[q] = ones ? 1.0f : b_;
                 }
 #pragma unroll
@@ -417,14 +436,15 @@ __device__ __forceinline__ void nn_fc2(const NNLayout &l, int sps, int k2, int B
     }
 }
 
-template <int NT, int NLEV, bool BN>
+// SPS = 2 bakes the reference's oversampling factor into the kernel (every / sps and % sps becomes a shift); SPS = 0: run-time sps.
+template <int NT, int NLEV, bool BN, int SPS>
 __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
 {
     extern __shared__ float4 smem4[];
     float *sm = reinterpret_cast<float *>(smem4);
     constexpr int C = 2 * NLEV;
     const int tid = threadIdx.x, run = blockIdx.x;
-    const int B = a.B, sps = a.sps, M = a.M, k1 = a.k1, k2 = a.k2;
+    const int B = a.B, sps = SPS ? SPS : a.sps, M = a.M, k1 = a.k1, k2 = a.k2;
     const NNLayout l = nn_layout(B, sps, M, NLEV, k1, k2, BN);
     const int L = l.L, p1 = l.p1, p2 = l.p2, Lx = l.Lx, Lz = l.Lz, mh = l.mh, Mh = l.Mh, nm = l.nm, NP = l.NP;
     float *zb = sm + l.zb, *bnst = sm + l.bnst;                // BN ? separate buffers : zb aliases z1
@@ -497,7 +517,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
         nn_fc2<NT, NLEV>(l, sps, k2, B, B, zb, th, w2t, a2);
         __syncthreads();
         // ---- P3: per-axis softmax -> q (in place), moments, entropy term; item = (axis, n)
-        float klsum = 0.f;
+        float klsum = 0.f, vtot = 0.f;
         for (int it = tid; it < 2 * B; it += NT) {
             const int axq = it / B, n = it - axq * B;
             float z[NLEV], zmax = -3.0e38f;
@@ -521,10 +541,40 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
                 if (qf) qf[(size_t)(axq * NLEV + i) * No + (size_t)s * B + n] = z[i];
             }
             mu[it] = e1; vr[it] = e2;
+            vtot += e2;
         }
         __syncthreads();
         // ---- P4: residual e = x - D (item t), VS (item j), C
         float se = 0.f;
+        if (sps == 2) {
+            // D[2 tau + par] = sum_a h[2 a + par] U[tau + mh - a]: the two outputs of a pair share every U read; item = tau
+            for (int tau = tid; 2 * tau < nm; tau += NT) {
+                float d0r = 0.f, d0i = 0.f, d1r = 0.f, d1i = 0.f;
+                const float *ur = mu + tau + mh, *ui = ur + B;
+                for (int aa = 0; aa < mh; aa++) {
+                    const float a_ = ur[-aa], b_ = ui[-aa];
+                    const float c0 = hs[2 * aa], e0 = hs[M + 2 * aa], c1 = hs[2 * aa + 1], e1 = hs[M + 2 * aa + 1];
+                    d0r = fmaf(c0, a_, d0r); d0r = fmaf(-e0, b_, d0r);
+                    d0i = fmaf(c0, b_, d0i); d0i = fmaf(e0, a_, d0i);
+                    d1r = fmaf(c1, a_, d1r); d1r = fmaf(-e1, b_, d1r);
+                    d1i = fmaf(c1, b_, d1i); d1i = fmaf(e1, a_, d1i);
+                }
+                {                                              // a = mh: only the even tap j = Mh exists
+                    const float a_ = ur[-mh], b_ = ui[-mh], c0 = hs[Mh], e0 = hs[M + Mh];
+                    d0r = fmaf(c0, a_, d0r); d0r = fmaf(-e0, b_, d0r);
+                    d0i = fmaf(c0, b_, d0i); d0i = fmaf(e0, a_, d0i);
+                }
+                const int t = 2 * tau;
+                const float er0 = xs[p1 + mh + t] - d0r, ei0 = xs[Lx + p1 + mh + t] - d0i;
+                es[t] = er0; es[nm + t] = ei0;
+                se += er0 * er0 + ei0 * ei0;
+                if (t + 1 < nm) {
+                    const float er1 = xs[p1 + mh + t + 1] - d1r, ei1 = xs[Lx + p1 + mh + t + 1] - d1i;
+                    es[t + 1] = er1; es[nm + t + 1] = ei1;
+                    se += er1 * er1 + ei1 * ei1;
+                }
+            }
+        } else
         for (int t = tid; t < nm; t += NT) {
             float dr = 0.f, di = 0.f;
             for (int j = (t + Mh) % sps; j <= Mh; j += sps) {
@@ -537,16 +587,22 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
             es[t] = er; es[nm + t] = ei;
             se += er * er + ei * ei;
         }
-        for (int j = wv; j < M; j += NWV) {                    // one wave per tap, lanes stride over the symbols
-            const int lo = (Mh - j + sps - 1) / sps, hi_ = (nm - 1 + Mh - j) / sps;
-            float acc = 0.f;
-            for (int np = lo + lane; np <= hi_; np += 64) acc += vr[np] + vr[B + np];
-            acc = wave_sum(acc);
-            if (lane == 0) VS[j] = acc;
+        block_reduce3<NT>(se, klsum, vtot, red);              // vtot: this thread's part of sum_n (v_I + v_Q), collected in P3
+        float hterm = 0.f;
+        if (tid < M) {                                         // VS[j] = sum over the symbols tap j sees = total - the few it misses at the ends
+            const int j = tid, lo = (Mh - j + sps - 1) / sps, hi_ = (nm - 1 + Mh - j) / sps;
+            float miss = 0.f;
+            for (int np = 0; np < lo; np++) miss += vr[np] + vr[B + np];
+            for (int np = hi_ + 1; np < B; np++) miss += vr[np] + vr[B + np];
+            VS[j] = red[2] - miss;
+            hterm = (hs[j] * hs[j] + hs[M + j] * hs[M + j]) * VS[j];
         }
-        block_reduce3<NT>(se, klsum, 0.f, red);
-        float Cc = red[0];
-        for (int j = 0; j < M; j++) Cc = fmaf(hs[j] * hs[j] + hs[M + j] * hs[M + j], VS[j], Cc);
+        if (tid < 64) {                                        // sum_j |h_j|^2 VS[j]: M <= 63 taps, all in wave 0
+            hterm = wave_sum(hterm);
+            if (tid == 0) red[3] = hterm;
+        }
+        __syncthreads();
+        const float Cc = red[0] + red[3];
         const float gC = (float)nm / Cc;
         if (tid == 0 && a.loss) a.loss[(size_t)run * a.steps + s] = (float)nm * logf(Cc) + red[1];
         // ---- P5: dL/dh, one wave per tap j
@@ -878,7 +934,8 @@ static int launch_nn_validate(int R, int N, int sps, int M, int k1, int k2, int 
 template <int NLEV>
 static int launch_nn_train(const vaeq_nn_args &a, size_t lds, hipStream_t st)
 {
-    void (*k)(const vaeq_nn_args) = a.batch_norm ? nn_train_kernel<512, NLEV, true> : nn_train_kernel<512, NLEV, false>;
+    void (*k)(const vaeq_nn_args) = a.batch_norm ? nn_train_kernel<512, NLEV, true, 0> : nn_train_kernel<512, NLEV, false, 0>;
+    if (a.sps == 2) k = a.batch_norm ? nn_train_kernel<512, NLEV, true, 2> : nn_train_kernel<512, NLEV, false, 2>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VAEQ_ERR_LDS;
     hipLaunchKernelGGL(k, dim3(a.R), dim3(512), lds, st, a);
