@@ -350,7 +350,7 @@ __device__ __forceinline__ void nn_fc1_elu(const NNLayout &l, int k1, const floa
     // z1p[c][p2 + s] for s in [0, Lvalid); entries whose absolute position (zlo + s) lies outside [0, zhi) are fc2's zero padding
     constexpr int C = 2 * NLEV, CQ = C / 4;
     if constexpr (C == 16) {
-        mfma_conv16<NT, (NT >= 1024 ? 3 : 5)>(w1t, 2 * k1, k1, l.Lx, xs, 1, Lvalid, th + l.oB1, [&](int c0, int sy, f32x4 acc) {
+        mfma_conv16<NT, (NT >= 1024 ? 2 : 5)>(w1t, 2 * k1, k1, l.Lx, xs, 1, Lvalid, th + l.oB1, [&](int c0, int sy, f32x4 acc) {
             const int pos = zlo + sy;
             const bool in = pos >= 0 && pos < zhi;
             const float av[4] = {acc.x, acc.y, acc.z, acc.w};
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
 }
 
 // ---- eval-mode forward over N symbols in tiles (validation, :293-301): q[R][C][N]
-constexpr int NN_TILE = 256;                           // symbols per tile
+constexpr int NN_TILE = 255;                           // symbols per tile: (255 - 1) sps + k2 = 511 z1 samples at sps = 2, k2 = 3 -> 32 MFMA column tiles = 2 per wave of 1024 threads
 
 template <int NT, int NLEV>
 __device__ __forceinline__ void nn_forward_tile(const NNLayout &l, int sps, int k1, int k2, int64_t Ltot, const float *x0, const float *x1,
