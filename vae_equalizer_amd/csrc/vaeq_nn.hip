@@ -605,22 +605,29 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
         const float Cc = red[0] + red[3];
         const float gC = (float)nm / Cc;
         if (tid == 0 && a.loss) a.loss[(size_t)run * a.steps + s] = (float)nm * logf(Cc) + red[1];
-        // ---- P5: dL/dh, one wave per tap j
-        for (int j = wv; j < M; j += NWV) {
-            const int lo = (Mh - j + sps - 1) / sps, hi_ = (nm - 1 + Mh - j) / sps;
-            float ar = 0.f, ai = 0.f;
+        // ---- P5: dL/dh[j] = gC (-2 sum_np e[np sps - Mh + j] conj(mu[np]) + 2 h[j] VS[j]): one wave per group of 4 taps -- a symbol's mu and
+        //      4 + 4 adjacent residual samples give 16 FMAs; the 8 partial sums of the group share one reduce-scatter
+        for (int jg = wv; 4 * jg < M; jg += NWV) {
+            const int j0 = 4 * jg, jl = min(j0 + 3, M - 1);
+            const int lo = max(0, (Mh - jl + sps - 1) / sps), hi_ = min(B - 1, (nm - 1 + Mh - j0) / sps);
+            float acc[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) acc[q] = 0.f;
             for (int np = lo + lane; np <= hi_; np += 64) {
-                const int t = np * sps - Mh + j;
-                const float a_ = es[t], b_ = es[nm + t], c_ = mu[np], d_ = mu[B + np];
-                ar = fmaf(a_, c_, ar); ar = fmaf(b_, d_, ar);
-                ai = fmaf(b_, c_, ai); ai = fmaf(-a_, d_, ai);
+                const int t0 = np * sps - Mh + j0;
+                const float c_ = mu[np], d_ = mu[B + np];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int t = t0 + q, tc = t < 0 ? 0 : (t < nm ? t : nm - 1);
+                    const bool ok = t >= 0 && t < nm && j0 + q < M;    // exactly the symbols tap j0 + q sees
+                    const float a_ = ok ? es[tc] : 0.f, b_ = ok ? es[nm + tc] : 0.f;
+                    acc[2 * q] = fmaf(a_, c_, acc[2 * q]); acc[2 * q] = fmaf(b_, d_, acc[2 * q]);
+                    acc[2 * q + 1] = fmaf(b_, c_, acc[2 * q + 1]); acc[2 * q + 1] = fmaf(-a_, d_, acc[2 * q + 1]);
+                }
             }
-            ar = wave_sum(ar);
-            ai = wave_sum(ai);
-            if (lane == 0) {
-                gr[l.oH + j] = gC * (-2.0f * ar + 2.0f * hs[j] * VS[j]);
-                gr[l.oH + M + j] = gC * (-2.0f * ai + 2.0f * hs[M + j] * VS[j]);
-            }
+            const float sum = wave_reduce_scatter<8>(acc, lane);
+            const int idx = wave_reduce_channel<8>(lane), j = j0 + (idx >> 1), im = idx & 1;
+            if ((lane & 7) == 0 && j < M) gr[l.oH + im * M + j] = gC * (-2.0f * sum + 2.0f * hs[im * M + j] * VS[j]);
         }
         // ---- P6: dL/dmu, dL/drho -> dL/dq -> softmax backward -> dL/dlogits in place of q; item = n (both axes)
         for (int n = tid; n < B; n += NT) {
