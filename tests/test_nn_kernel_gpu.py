@@ -65,9 +65,56 @@ def test_nn_free_run(name):
     assert relerr(_np(eng.vmax)[0], g["vmax"]) < 5e-3 and int(eng.step[0]) == ns
 
 
+@pytest.mark.parametrize("B,sps,k1,k2,M,bn", [(64, 2, 5, 1, 9, False), (100, 1, 9, 5, 13, False), (40, 2, 25, 9, 9, False), (90, 3, 7, 3, 11, False),
+                                              (130, 2, 63, 3, 25, False), (34, 2, 3, 3, 5, True), (150, 2, 11, 5, 25, True)])
+def test_nn_64qam_mfma_shapes_match_oracle(B, sps, k1, k2, M, bn):
+    """64-QAM (16 channels): the MFMA path of the two convolutions, their weight gradients and the transposed convolution on ragged
+    shapes -- one teacher-forced step (q, loss, every gradient) against the fp64 oracle, Net and Net_BN."""
+    from vae_equalizer_amd.engine import NNEngine
+    rng = np.random.default_rng(B + k1)
+    n = 8
+    lev = np.arange(-(n - 1), n, 2).astype(np.float32)
+    amp = (lev / np.sqrt(np.mean(lev ** 2) * 2)).astype(np.float32)
+    eng = NNEngine(1, M, k1, k2, amp, DEV, sps, batch_norm=bn)
+    eng.init_parameters()
+    theta0 = (_np(eng.theta)[0] + 0.02 * rng.standard_normal(eng.NP)).astype(np.float32)
+    eng.theta.copy_(torch.from_numpy(theta0)[None].to(DEV))
+    x = (0.5 * rng.standard_normal((2, B * sps))).astype(np.float32)
+    r = eng.train(torch.from_numpy(x[None]).to(DEV), B, 1, 1e-3, want_q=True, debug_grads=True, no_update=True)
+    torch.cuda.synchronize()
+    if bn:
+        t = oracle.nnbn_step_grads(x, theta0, np.concatenate([np.zeros(2 * n), np.ones(2 * n)]), amp, k1, k2, M, sps, np.float64)
+    else:
+        t = oracle.nn_step_grads(x, theta0, amp, k1, k2, M, sps, np.float64)
+    assert np.max(np.abs(_np(r["q"])[0] - t["q"])) < 2e-5
+    assert abs(_np(r["loss"])[0, 0] - t["loss"]) / abs(t["loss"]) < 1e-5
+    o = eng.offsets()
+    for a, b in zip(o[:-1], o[1:]):
+        assert relerr(_np(r["g"])[0, a:b], t["g"][a:b]) < 1e-4, (a, b)
+
+
+@pytest.mark.parametrize("N,sps,k1,k2", [(700, 2, 7, 5), (255, 2, 25, 3), (256, 1, 9, 1), (511, 3, 5, 3), (1000, 2, 63, 9)])
+def test_nn_64qam_eval_forward_shapes_match_oracle(N, sps, k1, k2):
+    """64-QAM eval forward (MFMA convolutions, 255-symbol tiles with real neighbours in the halos) on ragged shapes == the oracle's
+    single-pass forward."""
+    from vae_equalizer_amd.engine import NNEngine
+    rng = np.random.default_rng(N + k1)
+    n, M = 8, 9
+    lev = np.arange(-(n - 1), n, 2).astype(np.float32)
+    amp = (lev / np.sqrt(np.mean(lev ** 2) * 2)).astype(np.float32)
+    eng = NNEngine(1, M, k1, k2, amp, DEV, sps)
+    eng.init_parameters()
+    theta = (_np(eng.theta)[0] + 0.02 * rng.standard_normal(eng.NP)).astype(np.float32)
+    eng.theta.copy_(torch.from_numpy(theta)[None].to(DEV))
+    x = (0.5 * rng.standard_normal((2, N * sps))).astype(np.float32)
+    q = eng.forward(torch.from_numpy(x[None]).to(DEV))
+    qo = oracle.nn_forward(x, theta, n, k1, k2, sps, np.float64)
+    assert np.max(np.abs(_np(q)[0] - qo)) < 2e-5
+
+
 @pytest.mark.parametrize("name,N", [("G8_vaenn_64qam", 1500), ("G8_vaenn_16qam_small", 180), ("G8_vaenn_4qam_k5", 123)])
 def test_nn_forward_tiles_match_oracle(name, N):
-    """Eval-mode forward over a long block, computed in 256-symbol tiles with real neighbours in the halos, == the oracle's
+    """Eval-mode forward over a long block, computed in 255-symbol tiles with real neighbours in the halos, == the oracle's
     single-pass forward (zero padding only at the block's ends)."""
     g = load_golden(name)
     sps = int(g["sps"])

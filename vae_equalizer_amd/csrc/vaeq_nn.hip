@@ -57,10 +57,12 @@ __host__ __device__ inline NNLayout nn_layout(int B, int sps, int M, int n, int 
     l.mu = take(2 * B); l.vr = take(2 * B);
     l.es = take(2 * l.nm);
     l.VS = take(M);
-    l.th = take(l.NP); l.gr = take(l.NP); l.am = take(l.NP); l.av = take(l.NP); l.ax = take(l.NP);
+    l.th = take(l.NP);
+    const int NPt = eval ? 0 : l.NP;                   // gradient and AMSGrad state: training only
+    l.gr = take(NPt); l.am = take(NPt); l.av = take(NPt); l.ax = take(NPt);
     l.w1t = take(l.NW1 + 7 * l.C);                     // fc1.weight as [i][k][c]: the 4 channels of a thread in one 16-byte read
     l.w2t = take(l.C * l.C * k2 + 7 * l.C);            // fc2.weight as [cc][k][c]   (both zero-padded to a multiple of 8 rows: two MFMA k-steps)
-    l.w2u = take(l.C * l.C * k2);                      // fc2.weight as [k][c][cc] (backward through fc2: 4 input channels per read)
+    l.w2u = take(eval ? 0 : l.C * l.C * k2);           // fc2.weight as [k][c][cc] (backward through fc2: 4 input channels per read)
     l.red = take(64);
     l.total = o;
     return l;
