@@ -2,7 +2,7 @@
 
 Citations: DP = optical_DP_channel/shared_funcs.py, LEDP = func_VAELE_DP_MQAM_shaping.py,
 FLEX = func_VAEflex_DP_MQAM_shaping.py, AWGN = AWGN_channel/func_VAELE_MQAM_shaping.py.
-Pinned by tests/golden/G5_dp_epilogue.npz and G7_runs.npz.
+Pinned by tests/golden/G5_dp_epilogue.npz and G7_runs.npz; cma_frame_epilogue by G14_cma_epilogue_*.npz.
 """
 import numpy as np
 
@@ -63,8 +63,9 @@ def SER_IQflip(q, tx):
     return SER.min(axis=(0, 2))                                                           # DP:221
 
 
-def SER_constell_shaping(rx, tx, amp_levels, nu_sc, var):
-    """DP:225-287: SER from the FIR output against PCS-aware decision thresholds."""
+def SER_constell_shaping(rx, tx, amp_levels, nu_sc, var, inplace=None):
+    """DP:225-287: SER from the FIR output against PCS-aware decision thresholds.  The reference rescales its `rx` argument in place
+    (DP:242, `rx *= ...`); callers that hand in a slice view see that (the CMA modules do): pass the view as `inplace` to get it."""
     n = amp_levels.shape[0]
     a = amp_levels.astype(np.float32)
     d_vec = (np.float32(1) + np.float32(2 * nu_sc) * np.float32(var[0])) * (a[:-1] + a[1:]) / 2    # DP:234
@@ -75,6 +76,8 @@ def SER_constell_shaping(rx, tx, amp_levels, nu_sc, var):
     txf = tx.astype(np.float32)
     rx = rx.astype(np.float32) * (np.mean(np.sqrt(txf[:, 0] ** 2 + txf[:, 1] ** 2, dtype=np.float32), dtype=np.float32)
                                   / np.mean(np.sqrt(rx[:, 0] ** 2 + rx[:, 1] ** 2, dtype=np.float32), dtype=np.float32))  # DP:242
+    if inplace is not None:
+        inplace[...] = rx
 
     def on_bound(r, d):                                                                   # DP:267-287
         ok = (lo[d] <= r) & (r < hi[d])
@@ -176,3 +179,25 @@ def cpe(y, M_ma=501):
         c, s = np.cos(phi), np.sin(phi)
         out[p, 0], out[p, 1] = a * c - b * s, b * c + a * s
     return out
+
+
+def cma_frame_epilogue(out_const, data, amp_levels, nu_sc, var, soft_dec, N_cut=10, N_shift=21):
+    """The two-stage epilogue of the constant-modulus modules (func_CMA_DP_MQAM_shaping.py:39-53, same in CMAbatch :37-51 / CMAflex):
+    out_const[2,2,K] = equaliser output of one frame, data[2,2,K]; soft_dec(out, var, amp, nu_sc) = DP:529-542 (oracle.dp_soft_dec).
+
+    :44 hands SER_constell_shaping a slice VIEW of out_const, whose in-place normalisation (DP:242) therefore rescales the kept window
+    [11 : -11 - max|shift|] of out_const itself -- the soft demapper of :48 sees the normalised constellation there and the raw scale
+    at the frame edges."""
+    y = cpe(out_const[:, :, N_cut:-N_cut]).astype(np.float32)                              # :39
+    d = data[:, :, N_cut:-N_cut]                                                          # :40
+    shift_c, r_c = find_shift_symb_full(y, d, N_shift)                                    # :41
+    y = _align(y, shift_c, r_c)                                                           # :42-43
+    sl = slice(11, -11 - int(np.max(np.abs(shift_c))))
+    SER = np.empty(4, np.float32)
+    SER[:2] = SER_constell_shaping(y[:, :, sl], d[:, :, sl], amp_levels, nu_sc, var, inplace=y[:, :, sl])   # :44
+    q = soft_dec(y, var, amp_levels, nu_sc)                                               # :48
+    shift_q, r_q = find_shift(q, d, N_shift, amp_levels)                                  # :49
+    q = _align(q, shift_q, r_q)                                                           # :50-51
+    sl = slice(11, -11 - int(np.max(np.abs(shift_q))))
+    SER[2:] = SER_IQflip(q[:, :, sl], d[:, :, sl])                                        # :52
+    return dict(SER=SER, shift_c=shift_c, r_c=r_c, shift_q=shift_q, r_q=r_q, y=y)

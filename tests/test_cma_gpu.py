@@ -81,3 +81,41 @@ def test_eval_run_dp_serves_the_cma_loss_types(tmp_path, monkeypatch):
     assert "SERvsSNR_CMAflex_DP_4-QAM_" in name and np.isfinite(d["SER"]).all()
     assert d["SER"][..., -1].mean() < 0.01 < d["SER"][..., 0].mean()              # converging already inside the first frame, clean at the end
     assert set(io.loadmat(name)["dict"].dtype.names) >= {"SER", "Var_est", "var_real", "symb_step"}
+
+
+@pytest.mark.parametrize("name", ["G14_cma_epilogue_64qam", "G14_cma_epilogue_16qam", "G14_cma_epilogue_64qam_pcs"])
+def test_cma_frame_epilogue_against_reference(name):
+    """cma_runs.cma_frame_epilogue on the last frame of a hand-driven reference loop at 16- / 64-QAM: the reference's SER_constell_shaping
+    normalises the kept window of out_const IN PLACE (shared_funcs.py:242 through the slice view of func_CMA_DP_MQAM_shaping.py:44), so the
+    soft demapper of :48 sees the normalised constellation -- rows 2:4 depend on it (4-QAM, G12, is scale invariant and cannot)."""
+    from vae_equalizer_amd.cma_runs import cma_frame_epilogue
+    g = load_golden(name)
+    R = 2
+    rep = lambda a: torch.from_numpy(a)[None].expand(R, *a.shape).contiguous().to(DEV)
+    amp = torch.from_numpy(g["amp_levels"]).to(DEV)
+    var = torch.from_numpy(g["var"])[None].expand(R, 2).contiguous().to(DEV)
+    nu = torch.full((R,), float(g["nu_sc"]), device=DEV)
+    r = cma_frame_epilogue(rep(g["cma_out"]), rep(g["data"]), amp, nu, var)
+    torch.cuda.synchronize()
+    for i in range(R):
+        assert r["shift_c"][i].tolist() == g["shifts"][-1, 0].tolist() and int(r["r_c"][i]) == int(g["rs"][-1, 0])
+        assert r["shift_q"][i].tolist() == g["shifts"][-1, 1].tolist() and int(r["r_q"][i]) == int(g["rs"][-1, 1])
+        assert relerr(r["y"][i].cpu().numpy(), g["out_const_after"]) < 5e-5
+        assert np.max(np.abs(r["SER"][i].cpu().numpy() - g["SER"][:, -1])) < 1.5e-3, (r["SER"][i], g["SER"][:, -1])
+    o = oracle.cma_frame_epilogue(g["cma_out"], g["data"], g["amp_levels"], float(g["nu_sc"]), g["var"], oracle.dp_soft_dec)
+    assert np.max(np.abs(r["SER"][0].cpu().numpy() - o["SER"])) < 1.5e-3
+
+
+@pytest.mark.parametrize("name,mod,SNR,nu", [("G14_cma_epilogue_16qam", "16-QAM", 20, 0.0), ("G14_cma_epilogue_64qam", "64-QAM", 25, 0.0)])
+def test_cma_processing_16_64qam_vs_reference_trajectory(name, mod, SNR, nu):
+    """func_CMA_DP_MQAM_shaping.processing at 16- / 64-QAM (the sweep script's default modulation) on the frames the reference saw: all four
+    SER rows frame by frame -- the soft-demapper rows 2:4 follow rows 0:2 closely only with the reference's in-place normalisation."""
+    from vae_equalizer_amd import func_CMA_DP_MQAM_shaping as mod_
+    g = load_golden(name)
+    nf, N = int(g["num_frames"]), int(g["N"])
+    SER, Var_est, var = mod_.processing(mod, 2, SNR, nu, 25, float(g["theta_diff"]), np.pi / 10, float(g["lr"]), 100, N, nf, 10, "h0", 90e9, -26e-24,
+                                        TAU_PMD, PHI, 170, seed=int(g["seed"]), verbose=False)
+    ours, ref = SER.numpy(), g["SER"]
+    assert ours.shape == ref.shape == (4, nf)
+    assert np.mean(np.abs(ours - ref)) < 0.02, np.round(np.abs(ours - ref).max(0), 3)
+    assert np.max(np.abs((ours[2:] - ours[:2])[:, 3:] - (ref[2:] - ref[:2])[:, 3:])) < 0.02      # soft-demap rows track the constellation rows

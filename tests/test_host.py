@@ -191,3 +191,34 @@ def test_unbatched_mirrors_keep_reference_shapes():
     s = sfun.SER_constell_shaping(yy, data[:, :, 11:-11], amp, float(g["nu_sc"]), torch.from_numpy(g["var"]))
     assert np.allclose(s.numpy(), o, atol=1e-7)
     assert not torch.equal(yy, y[:, :, 11:-11])       # rescaled in place like the reference (shared_funcs.py:242)
+
+
+def test_host_threads_divide_by_local_world_size(monkeypatch):
+    """under torch.distributed.run every rank takes its share of the host cores, not all of them."""
+    from vae_equalizer_amd import dp_runs
+    monkeypatch.delenv("VAEQ_CPU_THREADS", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    n1 = dp_runs.host_threads()
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert dp_runs.host_threads() == max(1, n1 // 8)
+    monkeypatch.setenv("VAEQ_CPU_THREADS", "3")
+    assert dp_runs.host_threads() == 3
+
+
+def test_device_generators_refuse_mixed_symbol_rates():
+    """the on-device simulators take one symbol rate per call; a mixed batch must not silently run at runs[0]'s rate."""
+    from vae_equalizer_amd.dp_runs import DPRun, check_one_symb_rate
+    runs = [DPRun(23, 0.0, 0.0, 0.3, 2.5e-3, 40e9), DPRun(23, 0.0, 0.0, 0.3, 2.5e-3, 90e9)]
+    check_one_symb_rate(runs, "numpy")
+    for g in ("hip", "torch"):
+        with pytest.raises(ValueError, match="symb_rate"):
+            check_one_symb_rate(runs, g)
+    check_one_symb_rate(runs[:1] * 2, "hip")
+
+
+def test_stream_seeds_differ_across_ranks_batches_and_unseeded_invocations():
+    from vae_equalizer_amd import sweep
+    s = {sweep.stream_seed(5, r, b) for r in range(8) for b in range(4)}
+    assert len(s) == 32 and sweep.stream_seed(5, 1, 2) == sweep.stream_seed(5, 1, 2)
+    assert sweep.stream_seed(None, 0, 0) != sweep.stream_seed(None, 0, 0)

@@ -279,3 +279,27 @@ def test_cpe_against_reference():
     g = load_golden("G12_cma")
     assert relerr(oracle.cpe(g["cpe_in"]), g["cpe_out"]) < 2e-6
     assert np.abs(g["cpe_out"] - g["cpe_in"]).max() > 0.3                      # a real de-rotation with unwrapped drift
+
+
+@pytest.mark.parametrize("name", ["G14_cma_epilogue_64qam", "G14_cma_epilogue_16qam", "G14_cma_epilogue_64qam_pcs"])
+def test_cma_frame_epilogue(name):
+    """The CMA modules' two-stage epilogue incl. the in-place normalisation of the kept window (func_CMA_DP_MQAM_shaping.py:39-53,
+    shared_funcs.py:242) on the last frame of a hand-driven reference loop; without the write-back the soft-demapper rows are far off at
+    16- / 64-QAM (the CMA output settles at ~0.85 x the constellation's scale for R = 1)."""
+    g = load_golden(name)
+    amp, var, nu = g["amp_levels"], g["var"], float(g["nu_sc"])
+    sd = lambda out, v, a, n: oracle.dp_soft_dec(out, v, a, n)
+    r = oracle.cma_frame_epilogue(g["cma_out"], g["data"], amp, nu, var, sd)
+    assert list(r["shift_c"]) == list(g["shifts"][-1, 0]) and r["r_c"] == g["rs"][-1, 0]
+    assert list(r["shift_q"]) == list(g["shifts"][-1, 1]) and r["r_q"] == g["rs"][-1, 1]
+    assert relerr(r["y"], g["out_const_after"]) < 2e-5
+    assert np.max(np.abs(r["SER"] - g["SER"][:, -1])) < 1.5e-3, (r["SER"], g["SER"][:, -1])
+    if name != "G14_cma_epilogue_64qam_pcs":          # what the test is for: the raw-scale flow is measurably different
+        raw = oracle.cpe(g["cma_out"][:, :, 10:-10]).astype(np.float32)
+        from oracle.epilogue import _align, find_shift, SER_IQflip
+        ya = _align(raw, r["shift_c"], r["r_c"])
+        q = oracle.dp_soft_dec(ya, var, amp, nu)
+        s2, r2 = find_shift(q, g["data"][:, :, 10:-10], 21, amp)
+        ms = int(np.max(np.abs(s2)))
+        ser_raw = SER_IQflip(_align(q, s2, r2)[:, :, 11:-11 - ms], g["data"][:, :, 10:-10][:, :, 11:-11 - ms])
+        assert np.min(ser_raw - g["SER"][2:, -1]) > 0.02, (ser_raw, g["SER"][2:, -1])

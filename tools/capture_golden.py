@@ -17,7 +17,8 @@ The reference seeds nothing; determinism comes from patching
 
 Fixture families: G0 init tables, G1-G3 DP step / free runs (VAE-LE, VAEflex), G4 AWGN VAE-LE, G5 DP epilogue, G6 generator,
 G7 processing()-level runs (configs 1-3), G8 AWGN VAE-NN (Net), G9 converging VAEflex run (config 4), G10 converging PCS VAE-LE
-run (config 5 shape), G11 VAE-NN with BatchNorm (Net_BN).
+run (config 5 shape), G11 VAE-NN with BatchNorm (Net_BN), G12 CMA / CPE, G1b heavy-shaping DP steps, G13 config-5 on-grid runs,
+G14 the CMA modules' epilogue at 16- / 64-QAM.
 
 Usage:  python tools/capture_golden.py [--only G1,G2] [--full-run]
 """
@@ -680,6 +681,99 @@ def capture_G12(sfun, awgn):
     save("G12_cma_runs", **runs)
 
 
+# --------------------------------------------------------------------------
+# G1b: teacher-forced DP steps at config 5's heavy shaping (64-QAM, nu = 0.0872449 / 0.1222578, Eval_run_DP.py:24) -- where the
+#      log P terms of the KL are largest
+# --------------------------------------------------------------------------
+def capture_G1b(sfun, awgn):
+    save("G1_dp_step_64qam_nu0872", **_dp_case(sfun, "64-QAM", 0.0872449, 20, 25, 100, seed=15))
+    save("G1_dp_step_64qam_nu1222", **_dp_case(sfun, "64-QAM", 0.1222578, 28, 25, 100, seed=16))
+
+
+# --------------------------------------------------------------------------
+# G13: config 5 on-grid points through the reference's processing() (Eval_run_DP.py:24,34 sweep vectors)
+# --------------------------------------------------------------------------
+def _g13_point(tag, nu, SNR, seed, N_frame_max, num_frames, theta_diff):
+    import contextlib
+    import io
+    import func_VAELE_DP_MQAM_shaping as ref_vaele
+
+    t0 = time.time()
+    with SeededRng(seed), contextlib.redirect_stdout(io.StringIO()):
+        SER, Var_est, var = ref_vaele.processing("64-QAM", 2, SNR, nu, 25, theta_diff, np.pi / 10, 2.5e-3, 100, N_frame_max, num_frames, 10, "h0", 90e9,
+                                                 -26e-24, 0.1e-12 * np.sqrt(1000), np.array([0.0314, 0.0314], dtype=np.complex64), 170)
+    print(f"   G13 {tag}: {time.time() - t0:.0f}s  SER last {SER[:, -1].tolist()}", flush=True)
+    save(f"G13_cfg5_{tag}", SER=t2n(SER), Var_est=t2n(Var_est), var=t2n(var), seed=np.int64(seed), seconds=np.float64(time.time() - t0),
+         N_frame_max=np.int64(N_frame_max), num_frames=np.int64(num_frames), theta_diff=np.float64(theta_diff), nu=np.float64(nu), SNR=np.float64(SNR))
+
+
+def capture_G13a(sfun, awgn):      # reduced frame size (G10's): same-frames run-level parity
+    _g13_point("nu0872_snr20", 0.0872449, 20, 131, 3000, 200, 0.006 * np.pi)
+
+
+def capture_G13b(sfun, awgn):
+    _g13_point("nu1222_snr28", 0.1222578, 28, 132, 3000, 200, 0.006 * np.pi)
+
+
+def capture_G13c(sfun, awgn):      # script-faithful size (170 frames x 10 000 symbols, 0.06 pi drift): anchors of the 300-run grid
+    _g13_point("full_nu0872_snr20", 0.0872449, 20, 133, 10000, 170, 0.06 * np.pi)
+
+
+def capture_G13d(sfun, awgn):
+    _g13_point("full_nu1222_snr28", 0.1222578, 28, 134, 10000, 170, 0.06 * np.pi)
+
+
+# --------------------------------------------------------------------------
+# G14: the CMA modules' two-stage epilogue at 16- / 64-QAM (func_CMA_DP_MQAM_shaping.py:39-53): SER_constell_shaping rescales the
+#      slice VIEW of out_const in place (shared_funcs.py:242), so soft_dec / SER_IQflip see the normalised constellation.
+#      Hand-driven in processing()'s order so that the per-frame tensors can be pinned; the SER rows equal processing()'s.
+# --------------------------------------------------------------------------
+def _g14_case(sfun, mod, SNR, nu, lr, seed, num_frames=16, N=1500, M_est=25):
+    sps, N_cut = 2, 10
+    h_est, h_channel, P, amp_levels, amps, pol, nu_sc, var, pow_mean = sfun.init("h0", mod, "cpu", nu, sps, M_est, SNR)
+    theta, theta_diff = np.pi / 10, 0.006 * np.pi
+    SER_valid = torch.empty(4, num_frames)
+    shifts = np.zeros((num_frames, 2, 2), dtype=np.int64)
+    rs = np.zeros((num_frames, 2), dtype=np.int64)
+    keep = {}
+    with SeededRng(seed), torch.no_grad():
+        for frame in range(num_frames):
+            rx, data, _ = sfun.generate_data_shaping(N, amps, SNR, h_channel, P, pol, DP_DEFAULTS["symb_rate"], sps, DP_DEFAULTS["tau_cd"],
+                                                     DP_DEFAULTS["tau_pmd"], DP_DEFAULTS["phiIQ"], theta, "cpu")
+            out_const, h_est, e = sfun.CMA(rx, 1, h_est, lr, sps, True)
+            theta += theta_diff
+            if frame == num_frames - 1:
+                keep.update(cma_out=t2n(out_const), data=t2n(data))
+            out_const = sfun.CPE(out_const[:, :, N_cut:-N_cut])
+            data = data[:, :, N_cut:-N_cut]
+            shift, r = sfun.find_shift_symb_full(out_const, data, 21)
+            shifts[frame, 0], rs[frame, 0] = shift.numpy(), r
+            out_const = out_const.roll(r, 0)
+            out_const[0, :, :], out_const[1, :, :] = out_const[0, :, :].roll(int(-shift[0]), -1), out_const[1, :, :].roll(int(-shift[1]), -1)
+            ms = torch.max(torch.abs(shift))
+            SER_valid[:2, frame] = sfun.SER_constell_shaping(out_const[:, :, 11:-11 - ms], data[:, :, 11:-11 - ms], amp_levels, nu_sc, var)
+            if frame == num_frames - 1:
+                keep.update(out_const_after=t2n(out_const))              # aligned; kept window rescaled in place by the call above
+            out_train = sfun.soft_dec(out_const, var, amp_levels, nu_sc)
+            shift, r = sfun.find_shift(out_train, data, 21, amp_levels, pol)
+            shifts[frame, 1], rs[frame, 1] = shift.numpy(), r
+            out_train = out_train.roll(r, 0)
+            out_train[0, :, :], out_train[1, :, :] = out_train[0, :, :].roll(int(-shift[0]), -1), out_train[1, :, :].roll(int(-shift[1]), -1)
+            ms = torch.max(torch.abs(shift))
+            SER_valid[2:, frame] = sfun.SER_IQflip(out_train[:, :, 11:-11 - ms], data[:, :, 11:-11 - ms])
+            print(f"   G14 {mod} frame {frame}: SER {np.round(SER_valid[:, frame].numpy(), 4).tolist()} shift {shifts[frame].tolist()} r {rs[frame].tolist()}",
+                  flush=True)
+    return dict(SER=t2n(SER_valid), shifts=shifts, rs=rs, amp_levels=t2n(amp_levels), var=t2n(var), nu_sc=np.float64(nu_sc), seed=np.int64(seed),
+                lr=np.float64(lr), SNR=np.float64(SNR), nu=np.float64(nu), mod=np.array(mod), num_frames=np.int64(num_frames), N=np.int64(N),
+                theta_diff=np.float64(theta_diff), **keep)
+
+
+def capture_G14(sfun, awgn):
+    save("G14_cma_epilogue_64qam", **_g14_case(sfun, "64-QAM", 25, 0.0, 1e-3, seed=141))
+    save("G14_cma_epilogue_16qam", **_g14_case(sfun, "16-QAM", 20, 0.0, 1e-3, seed=142))
+    save("G14_cma_epilogue_64qam_pcs", **_g14_case(sfun, "64-QAM", 25, NU_572, 1e-3, seed=143, num_frames=12))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -688,7 +782,7 @@ def main():
     torch.set_num_threads(1)
     os.makedirs(OUT, exist_ok=True)
     sfun, awgn = _import_reference()
-    todo = [s for s in args.only.split(",") if s] or ["G0", "G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12"]
+    todo = [s for s in args.only.split(",") if s] or ["G0", "G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G1b", "G13a", "G13b", "G13c", "G13d", "G14"]
     for g in todo:
         print(f"[{g}]")
         if g == "G7":

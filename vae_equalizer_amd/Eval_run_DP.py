@@ -69,11 +69,12 @@ def main():
     points = list(sweep_points())
     rows = torch.zeros(len(points), 8, num_frames, dtype=torch.float32)   # per run: SER[4] | Var_est[2] | var[2] (broadcast)
     mine = sweep.my_slice(len(points), rank, world)
-    # one batch per problem shape (M, batch_len, flex_step)
-    shapes = sorted({(points[i][1]["M"], points[i][1]["batch_len"], points[i][1]["flex_step"]) for i in mine})
+    # one batch per problem shape (M, batch_len, flex_step) and symbol rate (the device generators simulate one rate per call)
+    key = lambda i: (points[i][1]["M"], points[i][1]["batch_len"], points[i][1]["flex_step"], points[i][1]["symb_rate"])
+    shapes = sorted({key(i) for i in mine})
     local = torch.zeros(len(mine), 8, num_frames, dtype=torch.float32)
-    for (M, batch_len, fs) in shapes:
-        sel = [k for k, i in enumerate(mine) if (points[i][1]["M"], points[i][1]["batch_len"], points[i][1]["flex_step"]) == (M, batch_len, fs)]
+    for (M, batch_len, fs, rate) in shapes:
+        sel = [k for k, i in enumerate(mine) if key(i) == (M, batch_len, fs, rate)]
         runs = [DPRun(points[mine[k]][1]["SNR"], points[mine[k]][1]["nu"], points[mine[k]][1]["theta_diff"], points[mine[k]][1]["theta"],
                       points[mine[k]][1]["lr_optim"], points[mine[k]][1]["symb_rate"],
                       None if base_seed is None else base_seed + 1000 * mine[k]) for k in sel]

@@ -43,12 +43,12 @@ def main():
     points = list(sweep_points())
     mine = sweep.my_slice(len(points), rank, world)
     local = torch.zeros(len(mine), num_epochs // epe, dtype=torch.float32)
-    for (M, N_train) in sorted({(points[i][1]["M"], points[i][1]["N_train"]) for i in mine}):      # one batch per problem shape
+    for b, (M, N_train) in enumerate(sorted({(points[i][1]["M"], points[i][1]["N_train"]) for i in mine})):   # one batch per problem shape
         sel = [k for k, i in enumerate(mine) if (points[i][1]["M"], points[i][1]["N_train"]) == (M, N_train)]
         runs = [dict(SNR=points[mine[k]][1]["SNR"], nu=points[mine[k]][1]["nu"], lr_optim=points[mine[k]][1]["lr"],
                      seed=None if base_seed is None else base_seed + 1000 * mine[k]) for k in sel]
         local[sel] = run_awgn_batch(runs, mod, sps, M, N_train, N_valid, train_len, num_epochs, epe, channel, device=device,
-                                    generator=generator, seed=(base_seed or 0) + 7919 * rank)
+                                    generator=generator, seed=sweep.stream_seed(base_seed, rank, b))
     rows = sweep.gather_rows(local, len(points), rank, world)
     if rank != 0:
         return None

@@ -48,13 +48,13 @@ def main():
         mine = sweep.my_slice(len(points), rank, world)
         local = torch.zeros(len(mine), num_epochs // epe, dtype=torch.float32)
         key = lambda p: (p["M"], p["k1"], p["k2"], p["batch_len"])
-        for shape in sorted({key(points[i][1]) for i in mine}):                     # one batch per problem shape
+        for b, shape in enumerate(sorted({key(points[i][1]) for i in mine})):       # one batch per problem shape
             sel = [k for k, i in enumerate(mine) if key(points[i][1]) == shape]
             runs = [dict(SNR=points[mine[k]][1]["SNR"], lr_optim=points[mine[k]][1]["lr"],
                          seed=None if base_seed is None else base_seed + 1000 * mine[k]) for k in sel]
             M, k1, k2, batch_len = shape
             local[sel] = run_vaenn_batch(runs, mod, sps, M, k1, k2, batch_len, N_valid, train_len, num_epochs, epe, channel, device=device,
-                                         generator=generator, seed=(base_seed or 0) + 7919 * rank, net_type=net_type)
+                                         generator=generator, seed=sweep.stream_seed(base_seed, rank, b + 1000 * net_type_vec.index(net_type)), net_type=net_type)
         rows = sweep.gather_rows(local, len(points), rank, world)
         if rank != 0:
             continue

@@ -3,7 +3,8 @@ func_CMAflex_DP_MQAM_shaping.py), R independent runs at once.
 
 Per frame: channel model -> vaeq_cma (HIP: CMA / CMAbatch / CMAflex) -> cut 10 symbols at both ends -> vaeq_cpe (HIP, Viterbi-Viterbi)
 -> the reference's two-stage epilogue (find_shift_symb_full + SER_constell_shaping on the phase-corrected output, then soft_dec on
-the ALIGNED output, find_shift and SER_IQflip; func_CMA_DP_MQAM_shaping.py:39-53) with the batched torch restatements of
+the ALIGNED output whose kept window SER_constell_shaping has normalised in place, find_shift and SER_IQflip;
+func_CMA_DP_MQAM_shaping.py:39-53) with the batched torch restatements of
 epilogue.py and the HIP soft demapper."""
 import math
 
@@ -13,7 +14,7 @@ import torch
 from . import channel as ch
 from . import epilogue as epi
 from . import shared_funcs as sfun
-from .dp_runs import DPRun, _host_pool, default_device  # noqa: F401
+from .dp_runs import DPRun, _host_pool, check_one_symb_rate, default_device, fresh_seed  # noqa: F401
 from .engine import cma, cpe, soft_demap
 
 N_CUT = 10   # symbols cut at both frame ends before the phase estimation (func_CMA_DP_MQAM_shaping.py:26,39)
@@ -23,12 +24,15 @@ def cma_frame_epilogue(out_const, data, amp, nu_sc, var):
     """out_const[R,2,2,K] (CMA output of one frame), data[R,2,2,K] fp16 -> dict(SER[R,4], shift_c, r_c, shift_q, r_q, y)."""
     y = cpe(out_const[..., N_CUT:-N_CUT].contiguous())                          # :39
     d = data[..., N_CUT:-N_CUT]                                                 # :40
-    N = y.shape[-1]
+    R, N = y.shape[0], y.shape[-1]
     shift_c, r_c = epi.shift_search(y[:, :, 0], d)                              # :41
     ya = epi._align(y, shift_c, r_c)                                            # :42-43
     mask_c = epi._keep_mask(shift_c, N, None, y.device)                         # [11 : -11 - max|shift|], :44
-    ser_c = epi.ser_constellation(ya, d, mask_c, amp, nu_sc, var[:, 0])
-    q = soft_demap(ya.contiguous(), amp, var, nu_sc)                            # :48, on the aligned output
+    ser_c, scale_n = epi.ser_constellation(ya, d, mask_c, amp, nu_sc, var[:, 0], return_scale=True)
+    # :44 passes a slice VIEW of out_const, and SER_constell_shaping normalises its argument in place (shared_funcs.py:242): from here on
+    # the kept window of out_const carries the mean-radius normalisation, the 11 + max|shift| edge symbols keep the raw CMA scale
+    ya = torch.where(mask_c.reshape(R, 1, 1, N), ya * scale_n.reshape(R, 1, 1, 1), ya)
+    q = soft_demap(ya.contiguous(), amp, var, nu_sc)                            # :48, on the aligned, window-normalised output
     n = amp.numel()
     Eq = torch.einsum("i,rpin->rpn", amp, q[:, :, :n])
     shift_q, r_q = epi.shift_search(Eq, d)                                      # :49
@@ -62,7 +66,8 @@ def run_cma_batch(runs, mode, mod, sps, M_est, batch_len, N_train_max, num_frame
     streams = [ch.SeededStreams(r.seed) if r.seed is not None else None for r in runs]
     SER = torch.empty(R, 4, num_frames, dtype=torch.float32, device=device)
     P = np.stack([t["P"] for t in tabs])
-    hip_seed = int(runs[0].seed) if R and runs[0].seed is not None else 0
+    check_one_symb_rate(runs, generator)
+    hip_seed = int(runs[0].seed) if R and runs[0].seed is not None else fresh_seed()   # unseeded: fresh entropy per call and rank
     for frame in range(num_frames):
         if frame % N_lrhalf == 0 and frame != 0:                                # :30-31
             lr = lr * 0.5

@@ -3,7 +3,8 @@ optical_DP_channel/func_VAELE_DP_MQAM_shaping.py:17-95 and func_VAEflex_DP_MQAM_
 done for R runs per frame with one training-kernel launch (engine.DPEngine) and one epilogue-kernel launch (engine.dp_epilogue).
 
 Runs in one batch share (mod, sps, M_est, batch_len, N_frame_max, num_frames, flex_step, channel, N_lrhalf) -- the
-shape of the problem -- and may differ in SNR, nu, theta_diff, theta, lr_optim, symb_rate and seed.
+shape of the problem -- and may differ in SNR, nu, theta_diff, theta, lr_optim and seed; with the host generator ("numpy") also in
+symb_rate (the on-device generators simulate one symbol rate per call: Eval_run_DP batches by symbol rate, mixed batches are refused).
 """
 import math
 from dataclasses import dataclass
@@ -31,24 +32,46 @@ class DPRun:
 _POOL = None
 
 
+def host_threads():
+    """Host threads THIS process may use for the host-side channel model: VAEQ_CPU_THREADS if set, else the affinity mask capped by
+    the cgroup CPU quota, divided by the number of ranks sharing the node (LOCAL_WORLD_SIZE, else WORLD_SIZE): under
+    torch.distributed.run with 8 ranks each rank takes an eighth of the cores instead of all of them."""
+    import os
+    if os.environ.get("VAEQ_CPU_THREADS"):
+        return max(1, int(os.environ["VAEQ_CPU_THREADS"]))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(p)))
+    except (OSError, ValueError):
+        pass
+    ranks = int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1)
+    return max(1, min(n // max(1, ranks), 32))
+
+
 def _host_pool():
-    """Thread pool for the host-side channel model (sized to the CPU share of this process)."""
+    """Thread pool for the host-side channel model (sized to this rank's share of the host cores, see host_threads)."""
     global _POOL
     if _POOL is None:
-        import os
         from concurrent.futures import ThreadPoolExecutor
-        try:
-            n = len(os.sched_getaffinity(0))
-        except AttributeError:
-            n = os.cpu_count() or 1
-        try:
-            q, p = open("/sys/fs/cgroup/cpu.max").read().split()
-            if q != "max":
-                n = min(n, max(1, int(q) // int(p)))
-        except (OSError, ValueError):
-            pass
-        _POOL = ThreadPoolExecutor(max_workers=max(1, min(n, 32)))
+        _POOL = ThreadPoolExecutor(max_workers=host_threads())
     return _POOL
+
+
+def fresh_seed():
+    """Entropy for an unseeded run batch on a device generator: distinct per call, per process and per rank."""
+    return int(np.random.SeedSequence().entropy & 0xFFFFFFFFFFFF)
+
+
+def check_one_symb_rate(runs, generator):
+    """The device generators take one symbol rate per call; a batch that mixes them would silently simulate runs[0]'s."""
+    if generator != "numpy" and len({float(r.symb_rate) for r in runs}) > 1:
+        raise ValueError(f"generator={generator!r} simulates ONE symb_rate per batch, got {sorted({float(r.symb_rate) for r in runs})}: "
+                         "batch the runs by symb_rate (Eval_run_DP.main does) or use generator='numpy'")
 
 
 def default_device():
@@ -68,6 +91,7 @@ def run_dp_batch(runs, mod, sps, M_est, batch_len, N_frame_max, num_frames, flex
     """
     device = default_device() if device is None else torch.device(device)
     R = len(runs)
+    check_one_symb_rate(runs, generator)
     tabs = [sfun.qam_tables(mod, r.nu) for r in runs]
     h_channel = sfun.upsampled_channel(channel, sps)
     amps = tabs[0]["amps"]
@@ -109,9 +133,8 @@ def run_dp_batch(runs, mod, sps, M_est, batch_len, N_frame_max, num_frames, flex
         cur_lr_W = lr0 * 0.5 if frame >= N_lrhalf else lr0
         if generator == "hip":                                                  # HIP generator kernels + hipFFT (row f1)
             SNRs = np.array([r.SNR for r in runs], dtype=np.float32)
-            gseed = int(runs[0].seed) if runs[0].seed is not None else int(np.random.SeedSequence().entropy & 0xFFFFFFFF)
             if frame == 0:
-                hip_seed = gseed
+                hip_seed = int(runs[0].seed) if runs[0].seed is not None else fresh_seed()
             rx, data = ch.generate_batch_hip(R, N_frame, amps, P, SNRs, h_channel, runs[0].symb_rate, sps, tau_cd, tau_pmd, phiIQ,
                                              theta, device, hip_seed, frame)
         elif generator == "torch":

@@ -85,8 +85,9 @@ def ser_soft_demap(dec, tx, mask, n_lev):
     return torch.stack(rates, dim=0).amin(dim=0)                             # :221  -> [R,2]
 
 
-def ser_constellation(y, tx, mask, amp, nu_sc, var0):
-    """SER_constell_shaping + dec_on_bound (shared_funcs.py:225-287) on aligned FIR outputs y[R,2,2,N], masked."""
+def ser_constellation(y, tx, mask, amp, nu_sc, var0, return_scale=False):
+    """SER_constell_shaping + dec_on_bound (shared_funcs.py:225-287) on aligned FIR outputs y[R,2,2,N], masked.
+    return_scale: also return the mean-radius normalisation factor [R] of :242 (the reference applies it IN PLACE to its argument)."""
     n_lev = amp.numel()
     R = y.shape[0]
     d_vec = (1 + 2 * nu_sc * var0).reshape(R, 1) * ((amp[:-1] + amp[1:]) / 2).reshape(1, -1)   # :234
@@ -98,7 +99,8 @@ def ser_constellation(y, tx, mask, amp, nu_sc, var0):
     cnt = (2 * mask.sum(dim=1)).clamp(min=1).float()
     num = (torch.sqrt(txf[:, :, 0] ** 2 + txf[:, :, 1] ** 2) * mk).sum(dim=(1, 2)) / cnt
     den = (torch.sqrt(y[:, :, 0] ** 2 + y[:, :, 1] ** 2) * mk).sum(dim=(1, 2)) / cnt
-    y = y * (num / den).reshape(R, 1, 1, 1)                                                      # :242
+    scale_n = num / den
+    y = y * scale_n.reshape(R, 1, 1, 1)                                                          # :242
 
     def on_bound(r, d):                                                                          # :267-287
         di = d.long().clamp(0, n_lev - 1).reshape(R, -1)
@@ -112,7 +114,8 @@ def ser_constellation(y, tx, mask, amp, nu_sc, var0):
     for r_ in (y, -y, y_pi4, -y_pi4):                                                            # :245-262
         rates.append(on_bound(r_, data))
         rates.append(on_bound(r_, inv))
-    return torch.stack(rates, dim=0).amin(dim=0)                                                 # :264
+    ser = torch.stack(rates, dim=0).amin(dim=0)                                                  # :264
+    return (ser, scale_n) if return_scale else ser
 
 
 def dp_frame_epilogue(q, y, data, amp, nu_sc, var, batch_len=None):

@@ -38,6 +38,15 @@ def device_for_rank(local_rank, world):
     return torch.device("cuda", local_rank if world > 1 else torch.cuda.current_device())
 
 
+def stream_seed(base_seed, rank, batch_index=0):
+    """Key of a rank's device-generator streams for one batch of runs: reproducible from ``base_seed``, fresh entropy per invocation when it
+    is None (the reference seeds nothing), and never shared between ranks or between the batches (problem shapes) of one rank."""
+    if base_seed is None:
+        import numpy as np
+        base_seed = int(np.random.SeedSequence().entropy & 0xFFFFFFFFFFFF)
+    return int(base_seed) + 7919 * int(rank) + 104729 * int(batch_index)
+
+
 def my_slice(n_runs, rank=None, world=None):
     """Indices of the runs this rank owns: r = rank (mod world)."""
     if rank is None:
