@@ -322,6 +322,14 @@ int vaeq_cpe(int32_t R, int64_t N, int32_t M_ma, const float *y, float *y_out, v
 int vaeq_version(void);
 const char *vaeq_strerror(int code);
 
+/* Measurement helpers (no reference counterpart; SURVEY 8d asks for them).
+ * vaeq_last_kernel: name of the kernel instantiation the calling thread's most recent vaeq_dp_train / vaeq_awgn_train launched (as a profiler
+ * prints it, e.g. "vaeq::dp_wave_kernel<25, 8, 100, true, 1, 1>"), copied into buf[len] -- bench.py names its roofline kernel from this.
+ * vaeq_stream_copy: dst[bytes] = src[bytes] with a plain 16-byte grid-stride copy kernel (bytes and both pointers multiples of 16): the
+ * measured HBM copy bandwidth that stands next to the 8 TB/s spec peak in the roofline. */
+int vaeq_last_kernel(char *buf, int32_t len);
+int vaeq_stream_copy(void *dst, const void *src, int64_t bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

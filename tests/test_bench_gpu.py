@@ -1,0 +1,60 @@
+"""bench.py end to end on the GPU box: the JSON contract (parity gate, both roofline fractions, the kernel name taken from the launch,
+extra.pipeline / extra.configs, cpu_baseline) and a two-rank rehearsal of `--gpus 2` (gloo, both ranks on the one GPU of the box)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _last_json(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert lines, stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_line_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--runs", "512", "--steps", "3", "--warmup", "1", "--min-seconds", "0.3",
+                        "--cpu-seconds", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "f32" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["timed_regions"] >= 2 and d["region_ms"]["min"] <= d["region_ms"]["median"] <= d["region_ms"]["max"]
+    assert abs(d["ms_per_step"] * 3 - d["region_ms"]["median"]) < 1e-6 * d["region_ms"]["median"] + 1e-9
+    assert abs(d["value"] - 512 * 10000 * 3 / (d["region_ms"]["median"] * 1e-3)) < 1e-6 * d["value"]
+    p = d["parity"]
+    assert p["ok"] and p["elbo_rel_max"] <= p["tol"] == 2e-5 and p["taps_abs_max"] <= 2e-5 and p["ser_abs_max"] <= 2e-3 and p["runs"] >= 8
+    rf = d["roofline"]
+    assert rf["kernel"] == "vaeq::dp_wave_kernel<25, 8, 100, true, 1, 1>"          # what vaeq_dp_train launched, not a literal in bench.py
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / 8000.0) < 1e-12 and rf["kernel_ms"] <= d["ms_per_step"] * 1.001
+    assert abs(rf["achieved"] - 176 * 512 * 10000 / (rf["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
+    assert 0 < rf["flop_frac"] < 1 and abs(rf["flop_frac"] - 5043.0 * 512 * 10000 / (rf["kernel_ms"] * 1e-3) / 157.3e12) < 1e-9
+    assert 2000 < rf["peak_measured_copy"] < 8000 and rf["frac_of_measured_copy"] > rf["frac"]
+    e = d["extra"]
+    assert e["pipeline"]["ms_per_frame"] > rf["kernel_ms"] and e["pipeline"]["dp_symbols_per_s"] > 0
+    c4, c2 = e["configs"]["config4_vaeflex"], e["configs"]["config2_awgn"]
+    assert c4["kernel"].startswith("vaeq::dp_wave_kernel<25, 8, ") and c4["value"] > 0 and 0 < c4["flop_frac"] < 1
+    assert c2["kernel"].startswith("vaeq::awgn_wave_kernel<25, 8, 3, 1>") and c2["value"] > 0 and 0 < c2["flop_frac"] < 1
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "2170" in cb["sample"] and cb["reference_dp_symbols_per_s"] == 2170.0
+
+
+def test_bench_two_ranks_rehearsal():
+    """`bench.py --gpus 2` exactly as the driver launches it, with gloo instead of RCCL and both ranks on cuda:0 (VERDICT r1 #7a): weak scaling
+    bookkeeping, the gather inside every timed region, the same number of timed regions on both ranks."""
+    env = dict(os.environ, VAEQ_DIST_BACKEND="gloo", VAEQ_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--runs", "256", "--steps", "2", "--warmup", "1",
+                        "--min-seconds", "0.2"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["parity"]["ok"]
+    assert abs(d["value"] - 2 * d["per_gpu"]) < 1e-9 * d["value"]
+    assert abs(d["value"] - 2 * 256 * 10000 * 2 / (d["region_ms"]["median"] * 1e-3)) < 1e-6 * d["value"]
+    assert "extra" not in d and "cpu_baseline" not in d                               # N = 1 only
+    assert "x2" in d["config"]["parallelism"]

@@ -13,7 +13,7 @@ from conftest import load_golden, relerr
 
 pytestmark = pytest.mark.gpu
 
-G1 = ["G1_dp_step_64qam_pcs", "G1_dp_step_64qam", "G1_dp_step_16qam", "G1_dp_step_4qam"]
+G1 = ["G1_dp_step_64qam_pcs", "G1_dp_step_64qam", "G1_dp_step_16qam", "G1_dp_step_4qam", "G1_dp_step_64qam_nu0872", "G1_dp_step_64qam_nu1222"]   # the last two: config 5's heavy shaping (Eval_run_DP.py:24)
 DEV = "cuda:0"
 
 

@@ -11,7 +11,7 @@ import pytest
 import oracle
 from conftest import load_golden, relerr
 
-G1 = ["G1_dp_step_64qam_pcs", "G1_dp_step_64qam", "G1_dp_step_16qam", "G1_dp_step_4qam"]
+G1 = ["G1_dp_step_64qam_pcs", "G1_dp_step_64qam", "G1_dp_step_16qam", "G1_dp_step_4qam", "G1_dp_step_64qam_nu0872", "G1_dp_step_64qam_nu1222"]   # the last two: config 5's heavy shaping (Eval_run_DP.py:24)
 
 
 @pytest.mark.parametrize("name", G1)
@@ -26,7 +26,9 @@ def test_dp_forward_loss_grads(name, dtype):
     assert abs(r["loss"] - g["loss0"]) / abs(g["loss0"]) < 1e-5
     assert relerr(r["var_est"], g["var_est0"]) < 1e-5
     assert relerr(r["gh"], g["gh0"]) < 2e-5
-    assert relerr(r["gW"], g["gW0"]) < 1e-4
+    # SNR 28 dB with nu = 0.1222578: var = 1.5e-4 puts the logits at ~1e4, and the reference's OWN fp32 gradient sits 1.1e-4 of its
+    # max away from the f64 truth (its fp32 restatement agrees with it to < 1e-4 like everywhere else)
+    assert relerr(r["gW"], g["gW0"]) < (2e-4 if (dtype == np.float64 and name.endswith("nu1222")) else 1e-4)
     # the stand-alone entry points agree with the fused one
     q, out = oracle.dp_forward(x, g["W0"], g["amp_levels"], g["var"], float(g["nu_sc"]), sps, dtype)
     assert np.array_equal(q, r["q"]) and np.array_equal(out, r["out"])

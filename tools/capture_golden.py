@@ -768,6 +768,14 @@ def _g14_case(sfun, mod, SNR, nu, lr, seed, num_frames=16, N=1500, M_est=25):
                 theta_diff=np.float64(theta_diff), **keep)
 
 
+def capture_G13e(sfun, awgn):      # two converging anchors of the grid at the script-faithful size
+    _g13_point("full_nu0271_snr26", NU_572, 26, 135, 10000, 170, 0.06 * np.pi)
+
+
+def capture_G13f(sfun, awgn):
+    _g13_point("full_nu0_snr20", 0.0, 20, 136, 10000, 170, 0.06 * np.pi)
+
+
 def capture_G14(sfun, awgn):
     save("G14_cma_epilogue_64qam", **_g14_case(sfun, "64-QAM", 25, 0.0, 1e-3, seed=141))
     save("G14_cma_epilogue_16qam", **_g14_case(sfun, "16-QAM", 20, 0.0, 1e-3, seed=142))
@@ -782,7 +790,7 @@ def main():
     torch.set_num_threads(1)
     os.makedirs(OUT, exist_ok=True)
     sfun, awgn = _import_reference()
-    todo = [s for s in args.only.split(",") if s] or ["G0", "G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G1b", "G13a", "G13b", "G13c", "G13d", "G14"]
+    todo = [s for s in args.only.split(",") if s] or ["G0", "G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G1b", "G13a", "G13b", "G13c", "G13d", "G13e", "G13f", "G14"]
     for g in todo:
         print(f"[{g}]")
         if g == "G7":

@@ -104,7 +104,7 @@ class NNArgs(C.Structure):
 
 # every symbol include/vaeq.h declares; tests check the library exports all of them
 EXPORTS = ["vaeq_dp_train", "vaeq_dp_lds_bytes", "vaeq_dp_resident_runs", "vaeq_soft_demap", "vaeq_dp_forward", "vaeq_dp_loss", "vaeq_dp_loss_bwd", "vaeq_dp_forward_bwd", "vaeq_dp_epilogue", "vaeq_dp_epilogue_ws_bytes", "vaeq_dp_epilogue_compact", "vaeq_gen_dp_tx", "vaeq_gen_dp_disperse", "vaeq_gen_dp_finish", "vaeq_gen_dp_frame", "vaeq_awgn_train",
-           "vaeq_awgn_lds_bytes", "vaeq_awgn_forward", "vaeq_awgn_validate", "vaeq_awgn_loss", "vaeq_awgn_loss_bwd", "vaeq_awgn_forward_bwd", "vaeq_gen_awgn", "vaeq_nn_train", "vaeq_nn_param_count", "vaeq_nn_lds_bytes", "vaeq_nn_forward", "vaeq_nn_validate", "vaeq_cma", "vaeq_cpe", "vaeq_version", "vaeq_strerror"]
+           "vaeq_awgn_lds_bytes", "vaeq_awgn_forward", "vaeq_awgn_validate", "vaeq_awgn_loss", "vaeq_awgn_loss_bwd", "vaeq_awgn_forward_bwd", "vaeq_gen_awgn", "vaeq_nn_train", "vaeq_nn_param_count", "vaeq_nn_lds_bytes", "vaeq_nn_forward", "vaeq_nn_validate", "vaeq_cma", "vaeq_cpe", "vaeq_version", "vaeq_strerror", "vaeq_last_kernel", "vaeq_stream_copy"]
 
 
 def lib():
@@ -118,6 +118,10 @@ def lib():
         L.vaeq_strerror.restype = C.c_char_p
         L.vaeq_strerror.argtypes = [C.c_int]
         L.vaeq_version.restype = C.c_int
+        L.vaeq_last_kernel.restype = C.c_int
+        L.vaeq_last_kernel.argtypes = [C.c_char_p, C.c_int32]
+        L.vaeq_stream_copy.restype = C.c_int
+        L.vaeq_stream_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.vaeq_dp_train.restype = C.c_int
         L.vaeq_dp_train.argtypes = [C.POINTER(DPArgs), C.c_void_p]
         L.vaeq_dp_lds_bytes.restype = C.c_int64
@@ -182,6 +186,13 @@ def lib():
         L.vaeq_gen_awgn.argtypes = [C.c_int32] * 8 + [C.c_void_p] * 4 + [C.c_uint64, C.c_uint32] + [C.c_void_p] * 7
         _LIB = L
     return _LIB
+
+
+def last_kernel():
+    """Name of the kernel instantiation this thread's latest vaeq_dp_train / vaeq_awgn_train call launched."""
+    buf = C.create_string_buffer(160)
+    check(lib().vaeq_last_kernel(buf, 160), "vaeq_last_kernel")
+    return buf.value.decode()
 
 
 def check(code, what):

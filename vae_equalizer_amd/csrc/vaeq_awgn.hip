@@ -738,6 +738,7 @@ static int launch_awgn(const vaeq_awgn_args &a, size_t lds, hipStream_t st)
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VAEQ_ERR_LDS;
+    note_kernel("vaeq::awgn_train_kernel<%d, %d>", NT, NLEV);
     hipLaunchKernelGGL(k, dim3(a.R), dim3(NT), lds, st, a);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }

@@ -562,6 +562,7 @@ static int launch_awgn_wave_k(const vaeq_awgn_args &a, hipStream_t st)
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VAEQ_ERR_LDS;
+    note_kernel("vaeq::awgn_wave_kernel<%d, %d, %d, %d>", M, NLEV, NR, NW);
     hipLaunchKernelGGL(k, dim3(a.R), dim3(64 * NW), lds, st, a);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }

@@ -4,6 +4,10 @@
 
 namespace vaeq {
 
+// Host side: every training-kernel launcher records the instantiation it launched (vaeq_last_kernel reports it, so a benchmark names
+// the kernel it actually timed instead of a literal that can go stale when the dispatch changes).  Defined in vaeq_misc.hip.
+void note_kernel(const char *fmt, ...);
+
 // Sum over the 64 lanes of a wave, result in every lane.  Fixed xor-butterfly order:
 // bitwise reproducible run to run (no float atomics anywhere in this library).
 __device__ __forceinline__ float wave_sum(float v)

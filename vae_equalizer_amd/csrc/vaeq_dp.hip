@@ -399,6 +399,7 @@ static int launch_dp(const vaeq_dp_args &a, size_t lds, hipStream_t st)
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return VAEQ_ERR_LDS;
     }
+    note_kernel("vaeq::dp_train_kernel<%d, %d>", NT, NLEV);
     hipLaunchKernelGGL(k, dim3(a.R), dim3(NT), lds, st, a);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
