@@ -67,8 +67,12 @@ def test_three_steps_and_moments(name):
         assert abs(_np(r["loss"])[0, 0, s] - g[f"loss{s}"]) / abs(g[f"loss{s}"]) < 2e-5
     assert np.max(np.abs(_np(eng.W)[0] - g["W3"])) < 2e-5
     assert np.max(np.abs(_np(eng.h)[0] - g["h3"])) < 2e-5
-    assert relerr(_np(eng.mW)[0], g["mW"]) < 1e-4 and relerr(_np(eng.vW)[0], g["vW"]) < 1e-4
-    assert relerr(_np(eng.mh)[0], g["mh"]) < 1e-4 and relerr(_np(eng.vh)[0], g["vh"]) < 1e-4
+    # Adam moments = running sums of the gradients: 1e-4 of their max, or -- where the reference's own fp32 gradients are noisier than that
+    # (SNR 28 dB with nu = 0.1222578: logits ~1e4) -- at least as close to the f64 truth as the reference's moments are (x3 slack)
+    st = oracle.DPState(int(g["M_est"]), np.float64, g["W0"], g["h0"])
+    oracle.dp_train(st, g["rx"], 3, B, g["amp_levels"], g["P"], g["var"], float(g["nu_sc"]), float(g["lr"]), float(g["lr"]), int(g["sps"]), dtype=np.float64)
+    for ours, key, truth in ((eng.mW, "mW", st.mW), (eng.vW, "vW", st.vW), (eng.mh, "mh", st.mh), (eng.vh, "vh", st.vh)):
+        assert relerr(_np(ours)[0], g[key]) < 1e-4 or relerr(_np(ours)[0], truth) < 3 * relerr(g[key], truth), key
     assert int(eng.step[0]) == 3
 
 
@@ -114,10 +118,13 @@ def test_freerun_flex_golden(threads):
     loss = _np(r["loss"])[0, 0]
     assert np.max(np.abs(loss[:10] - g["loss"][:10]) / np.abs(g["loss"][:10])) < 1e-5
     assert relerr(_np(r["y"])[0, 0][:, :, :10 * fs], g["out_const"][:, :, :10 * fs]) < 1e-5
-    assert np.max(np.abs(loss - g["loss"]) / np.abs(g["loss"])) < 1e-4
-    assert relerr(_np(r["y"])[0, 0], g["out_const"]) < 3e-4
-    assert np.max(np.abs(_np(eng.W)[0] - g[f"W_after{ns}"])) < 3e-4
-    assert np.max(np.abs(_np(eng.h)[0] - g[f"h_after{ns}"])) < 3e-4
+    # 30 free steps against the reference, measured on the GPU with the wave kernel (printed below): loss 5.6e-6 relative, y 9.7e-5 of its max, taps
+    # W 2.5e-5 / h 1.6e-5 absolute; the reference's own noise at this horizon is ~2e-5 on the taps (1 vs 4 CPU threads).
+    # Bounds = 3 x the measured values.
+    dl, dy = np.max(np.abs(loss - g["loss"]) / np.abs(g["loss"])), relerr(_np(r["y"])[0, 0], g["out_const"])
+    dW, dh = np.max(np.abs(_np(eng.W)[0] - g[f"W_after{ns}"])), np.max(np.abs(_np(eng.h)[0] - g[f"h_after{ns}"]))
+    print(f"flex free run, {ns} steps, threads={threads}: loss rel {dl:.2e}  y rel {dy:.2e}  W abs {dW:.2e}  h abs {dh:.2e}")
+    assert dl < 2e-5 and dy < 3e-4 and dW < 8e-5 and dh < 8e-5, (dl, dy, dW, dh)
 
 
 def test_batch_of_runs_matches_oracle():
@@ -255,14 +262,16 @@ def test_multiwave_flex_windows_equal_generic_kernel(B, k0, klen):
     assert np.max(np.abs(_np(ea.W) - _np(eb.W))) < 2e-5 and np.max(np.abs(_np(ea.h) - _np(eb.h))) < 2e-5
 
 
-@pytest.mark.parametrize("B,M", [(200, 25), (600, 13)])
-def test_multiwave_against_oracle_frames_and_determinism(B, M):
-    """Two / eight wavefronts per run: each run == the CPU oracle; two frames in one launch == two launches (bitwise); a repeat is
-    bitwise identical (fixed-order cross-wave sums); no_update leaves taps, moments and the step counter alone."""
+@pytest.mark.parametrize("B,M,n", [(200, 25, 4), (600, 13, 4), (400, 25, 8), (256, 31, 8), (130, 25, 8), (1000, 25, 8), (100, 25, 8), (128, 21, 2)])
+def test_multiwave_against_oracle_frames_and_determinism(B, M, n):
+    """One / two / four / eight wavefronts per run (B <= 128 / 256 / 512 / 1024), 4- to 64-QAM: each run == the CPU oracle; two frames in one
+    launch == two launches (bitwise); a repeat is bitwise identical (fixed-order cross-wave sums); no_update leaves taps, moments and the step
+    counter alone."""
     from vae_equalizer_amd.engine import DPEngine
     rng = np.random.default_rng(B)
-    R, n, sps, steps = 4, 4, 2, 3
-    amp = np.array([-3, -1, 1, 3], np.float32) / np.sqrt(10).astype(np.float32)
+    R, sps, steps = 4, 2, 3
+    lev = np.arange(-(n - 1), n, 2).astype(np.float64)
+    amp = (lev / np.sqrt(2 * np.mean(lev ** 2))).astype(np.float32)
     P = rng.dirichlet(np.ones(n) * 5, R).astype(np.float32)
     var = rng.uniform(0.002, 0.02, (R, 2)).astype(np.float32)
     nu_sc = rng.uniform(0, 1, R).astype(np.float32)

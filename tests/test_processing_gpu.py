@@ -351,3 +351,94 @@ def test_vaele_pcs_run_vs_reference():
     assert np.all(np.abs(ours[:, lo:].mean(1) - ref[:, lo:].mean(1)) < 2.5e-3), (ours[:, lo:].mean(1), ref[:, lo:].mean(1))
     ve, vr = Var_est.numpy()[:, lo:].mean(1), g["Var_est"][:, lo:].mean(1)
     assert np.max(np.abs(ve - vr) / vr) < 0.05, (ve, vr)
+
+
+# ------------------------------------------------------------------ config 5: optical DP 64-QAM + PCS, SNR x shaping x seed sweep
+@pytest.mark.parametrize("name", ["G13_cfg5_nu0872_snr20", "G13_cfg5_nu1222_snr28"])
+def test_config5_heavy_shaping_runs_vs_reference(name):
+    """Two on-grid points of config 5's sweep vectors (Eval_run_DP.py:24,34) through processing() on the 200 frames x 3000 symbols the reference
+    saw.  At these shaping strengths (H = 4.6 / 4.125 bit) the reference's blind equaliser does NOT lock within the run -- all four SER estimates
+    stay at ~0.85-0.9 and the noise estimate at 5-6 x (nu .0872, 20 dB) resp. 35 x (nu .1222, 28 dB) the true variance -- and neither must this
+    implementation: same plateau, frame window by frame window."""
+    from vae_equalizer_amd.func_VAELE_DP_MQAM_shaping import processing
+    g = load_golden(name)
+    F, N = int(g["num_frames"]), int(g["N_frame_max"])
+    SER, Var_est, var = processing("64-QAM", 2, float(g["SNR"]), float(g["nu"]), 25, float(g["theta_diff"]), np.pi / 10, 2.5e-3, 100, N, F, 10, "h0", 90e9,
+                                   -26e-24, TAU_PMD, PHI, 170, seed=int(g["seed"]), verbose=False)
+    ours, ref, ve, vr = SER.numpy(), g["SER"], Var_est.numpy(), g["Var_est"]
+    assert np.allclose(var.numpy(), g["var"], rtol=1e-6)
+    assert np.max(np.abs(ours[:, :3] - ref[:, :3])) < 0.05 and np.max(np.abs(ve[:, :3] - vr[:, :3]) / vr[:, :3]) < 0.05    # before chaos sets in
+    assert ref[:, 20:].min() > 0.6 and ours[:, 20:].min() > 0.6                        # neither locks
+    for a, b in ((0, 20), (20, 60), (60, 120), (120, 200)):
+        assert np.max(np.abs(ours[:, a:b].mean(1) - ref[:, a:b].mean(1))) < 0.07, (a, b, ours[:, a:b].mean(1), ref[:, a:b].mean(1))
+        assert np.max(np.abs(ve[:, a:b].mean(1) - vr[:, a:b].mean(1)) / vr[:, a:b].mean(1)) < 0.06, (a, b, ve[:, a:b].mean(1), vr[:, a:b].mean(1))
+    assert ve[:, 100:].mean() > 4 * float(var[0])                                       # the plateau's noise estimate, far above the true variance
+
+
+def test_config5_grid_one_batch_on_one_gpu(tmp_path, monkeypatch):
+    """BASELINE config 5, script-faithful: nu in {0, .0270955, .0872449, .1222578} x SNR in {20..28} x 3 learning rates x iter = 5 = 300 runs of
+    170 frames x 10 000 symbols through the drop-in sweep script in ONE batch on one GPU (Eval_run_DP.py:24,34,67-95; the N = 1 anchor of the
+    8-way shard).  Checks the .mat schema, the reference's on-grid behaviour (four script-size captures, G13_cfg5_full_*: the two light shapings
+    lock, the two heavy ones never do) and that SER falls with the SNR until it reaches the tracking floor."""
+    import time
+    from vae_equalizer_amd import Eval_run_DP as ev
+    NU, SNR = [0, 0.0270955, 0.0872449, 0.1222578], [20, 22, 24, 26, 28]
+    monkeypatch.setattr(ev, "nu_vec", NU); monkeypatch.setattr(ev, "SNR_vec", SNR); monkeypatch.setattr(ev, "generator", "hip")
+    monkeypatch.setattr(ev, "base_seed", 5); monkeypatch.setattr(ev, "savePATH", str(tmp_path) + "/")
+    assert (ev.iter, ev.num_frames, ev.N_frame_max, ev.lr_optim_vec, ev.loss_type, ev.mod) == (5, 170, 10000, [2.5e-3, 2e-3, 3e-3], "VAE", "64-QAM")
+    t0 = time.time()
+    name, d = ev.main()
+    wall = time.time() - t0
+    print(f"config 5: 300 runs x 170 frames x 10 000 symbols in {wall:.1f} s on one GPU")
+    m = io.loadmat(name)["dict"]
+    assert m["SER"][0, 0].shape == (4, 5, 1, 4, 1, 1, 3, 1, 1, 1, 5, 170) and m["Var_est"][0, 0].shape == (2, 5, 1, 4, 1, 1, 3, 1, 1, 1, 5, 170)
+    assert m["var_real"][0, 0].shape == (2, 5, 1, 4, 1, 1, 3, 1, 1, 1, 5, 1)
+    assert np.allclose(np.ravel(m["nu"][0, 0]), NU) and np.allclose(np.ravel(m["SNR"][0, 0]), SNR)
+    S, V = d["SER"], d["Var_est"]
+    assert np.isfinite(S).all() and np.isfinite(V).all() and wall < 120
+    tail = lambda A, s, n: A[:, s, 0, n, 0, 0, :, 0, 0, 0, :, -30:].mean(-1)             # [rows, lr, iter]: mean over the last 30 frames
+    # light shaping locks in every run; SER falls with the SNR down to the floor the 0.06 pi/frame drift leaves (reached at ~26 dB)
+    for n in (0, 1):
+        ser = np.array([tail(S, s, n).mean() for s in range(5)])
+        assert (np.array([tail(S, s, n).max() for s in range(5)]) < 0.2).all(), ser
+        assert ser[0] > 1.5 * ser[1] > 1.5 * 1.2 * ser[2] and (ser[3:] < 1.05 * ser[2]).all() and (ser[3:] > 0.3 * ser[2]).all(), ser
+        assert np.array([tail(V, s, n).mean() for s in range(5)]).argsort().tolist() == [4, 3, 2, 1, 0]      # noise estimate falls with the SNR
+    assert tail(S, 0, 1).mean() < 0.5 * tail(S, 0, 0).mean()                             # H = 5.72 bit needs fewer errors at equal SNR
+    # heavy shaping: no run locks, at any SNR
+    for n in (2, 3):
+        assert min(tail(S, s, n).min() for s in range(5)) > 0.6
+    # the reference's own runs at four grid points (one run each, lr 2.5e-3 = index 0 of the lr axis)
+    for fx, tol_ser, tol_var in (("G13_cfg5_full_nu0872_snr20", 0.04, 0.03), ("G13_cfg5_full_nu1222_snr28", 0.04, 0.03),
+                                 ("G13_cfg5_full_nu0271_snr26", None, 0.05), ("G13_cfg5_full_nu0_snr20", None, 0.05)):
+        g = load_golden(fx)
+        s, n = SNR.index(int(g["SNR"])), int(np.argmin(np.abs(np.array(NU) - float(g["nu"]))))
+        ours_s, ours_v = tail(S, s, n)[:, 0].mean(-1), tail(V, s, n)[:, 0].mean(-1)       # lr 2.5e-3, mean over the 5 seeds
+        ref_s, ref_v = g["SER"][:, -30:].mean(1), g["Var_est"][:, -30:].mean(1)
+        if tol_ser is None:                                                             # locked: Monte-Carlo error + seed-to-seed spread of the tracking error
+            assert np.max(np.abs(ours_s - ref_s)) < 0.15 * ref_s.mean() + 1e-3, (fx, ours_s, ref_s)
+        else:                                                                           # plateau
+            assert np.max(np.abs(ours_s - ref_s)) < tol_ser, (fx, ours_s, ref_s)
+        assert np.max(np.abs(ours_v - ref_v) / ref_v) < tol_var, (fx, ours_v, ref_v)
+
+
+def test_eval_run_dp_batches_by_symbol_rate(tmp_path, monkeypatch):
+    """A symb_rate sweep axis (Eval_run_DP.py lists [40e9 .. 100e9]) with a device generator: each rate is simulated in its own batch, so every
+    result row carries the rate it is labelled with (a mixed batch used to run at the first rate)."""
+    from vae_equalizer_amd import Eval_run_DP as ev
+    from vae_equalizer_amd.dp_runs import DPRun, run_dp_batch
+    for k, v in dict(symb_rate_vec=[40e9, 90e9], lr_optim_vec=[2.5e-3], iter=2, num_frames=4, N_frame_max=2000, generator="hip", base_seed=3,
+                     savePATH=str(tmp_path) + "/").items():
+        monkeypatch.setattr(ev, k, v)
+    name, d = ev.main()
+    S = d["SER"]                                                                        # [4, SNR, rate, nu, td, M, lr, B, fs, th, iter, frames]
+    assert S.shape == (4, 1, 2, 1, 1, 1, 1, 1, 1, 1, 2, 4) and np.isfinite(S).all()
+    pts = list(ev.sweep_points())
+    for sr, rate in enumerate([40e9, 90e9]):
+        idx = [i for i, (_, p) in enumerate(pts) if p["symb_rate"] == rate]
+        runs = [DPRun(23, 0, 0.06 * np.pi, np.pi / 10, 2.5e-3, rate, 3 + 1000 * i) for i in idx]
+        r = run_dp_batch(runs, "64-QAM", 2, 25, 100, 2000, 4, 10, "h0", ev.tau_cd, ev.tau_pmd, ev.phiIQ, 170, generator="hip")
+        assert np.array_equal(r["SER"].numpy().transpose(1, 0, 2), S[:, 0, sr, 0, 0, 0, 0, 0, 0, 0])       # rows carry THEIR rate
+    assert not np.array_equal(S[:, 0, 0], S[:, 0, 1])
+    with pytest.raises(ValueError, match="symb_rate"):
+        run_dp_batch([DPRun(23, 0, 0.0, 0.3, 2.5e-3, 40e9, 1), DPRun(23, 0, 0.0, 0.3, 2.5e-3, 90e9, 2)], "64-QAM", 2, 25, 100, 2000, 1, 10, "h0",
+                     ev.tau_cd, ev.tau_pmd, ev.phiIQ, 170, generator="hip")

@@ -26,6 +26,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "vaeq.h"
 #include "vaeq_common.h"
@@ -66,40 +67,34 @@ __host__ __device__ inline WaveLayout wave_layout(int B, int M, int NW = 1)
 // shape on the residual with conjugated channel taps (dL/dU).  xp = phase-0 pointer of the lane (slot = lane).
 //   FIR : T = float4 tap quads (o0.re, o0.im, o1.re, o1.im), acc[sym][o]  += w * x
 //   DU  : two float2 tap arrays (nu = 0, 1),                   acc[sym][nu] += e * conj(h)
-template <int M, bool CONJ>
+// INIT: the first tap starts the accumulators (no zeroing); else they are added to.
+template <int M, bool CONJ, bool INIT>
 __device__ __forceinline__ void pair_fir(cacc (&acc)[2][2], const float2 *xp, int Lph, const float4 *wq, const float2 *ha,
                                          const float2 *hb)
 {
-    auto tap = [&](int k, float &ar, float &ai, float &br, float &bi) {
-        if (CONJ) {
-            const float2 a_ = ha[k], b_ = hb[k];
-            ar = a_.x; ai = a_.y; br = b_.x; bi = b_.y;
-        } else {
-            const float4 w = wq[k];
-            ar = w.x; ai = w.y; br = w.z; bi = w.w;
-        }
-    };
-    auto mac = [&](int sy, float2 x, float ar, float ai, float br, float bi) {
-        cmac(acc[sy][0], ar, ai, x);                   // FIR: w * x;  dL/dU: e * conj(h) -- same accumulation, different final combine
-        cmac(acc[sy][1], br, bi, x);
-    };
+    // tap k as two register pairs: FIR (re, im) of o = 0 / 1; dL/dU (re, im) of h[chi][nu = 0 / 1]
+    auto tapA = [&](int k) -> v2f { return CONJ ? lds2(ha + k) : lds2(reinterpret_cast<const float2 *>(wq + k)); };
+    auto tapB = [&](int k) -> v2f { return CONJ ? lds2(hb + k) : lds2(reinterpret_cast<const float2 *>(wq + k) + 1); };
     constexpr int G = M / 4;
-#pragma unroll 1
-    for (int g = 0; g < G; g++) {                      // taps 4g..4g+3, samples c' = 4g..4g+5
+    auto group = [&](int g, auto first) {              // taps 4g..4g+3, samples c' = 4g..4g+5 (14 independent 8-byte LDS reads, then 32 packed FMAs)
+        constexpr bool F = decltype(first)::value;
         const float2 *xg = xp + g;
-        const float2 x0 = xg[0], x1 = xg[Lph], x2 = xg[2 * Lph], x3 = xg[3 * Lph], x4 = xg[1], x5 = xg[Lph + 1];
-        float ar, ai, br, bi;
-        tap(4 * g + 0, ar, ai, br, bi); mac(0, x0, ar, ai, br, bi); mac(1, x2, ar, ai, br, bi);
-        tap(4 * g + 1, ar, ai, br, bi); mac(0, x1, ar, ai, br, bi); mac(1, x3, ar, ai, br, bi);
-        tap(4 * g + 2, ar, ai, br, bi); mac(0, x2, ar, ai, br, bi); mac(1, x4, ar, ai, br, bi);
-        tap(4 * g + 3, ar, ai, br, bi); mac(0, x3, ar, ai, br, bi); mac(1, x5, ar, ai, br, bi);
-    }
+        const v2f x0 = lds2(xg), x1 = lds2(xg + Lph), x2 = lds2(xg + 2 * Lph), x3 = lds2(xg + 3 * Lph), x4 = lds2(xg + 1), x5 = lds2(xg + Lph + 1);
+        const v2f a0 = tapA(4 * g), b0 = tapB(4 * g), a1 = tapA(4 * g + 1), b1 = tapB(4 * g + 1);
+        const v2f a2 = tapA(4 * g + 2), b2 = tapB(4 * g + 2), a3 = tapA(4 * g + 3), b3 = tapB(4 * g + 3);
+        cmacf<F>(acc[0][0], a0, x0); cmacf<F>(acc[0][1], b0, x0); cmacf<F>(acc[1][0], a0, x2); cmacf<F>(acc[1][1], b0, x2);
+        cmac(acc[0][0], a1, x1); cmac(acc[0][1], b1, x1); cmac(acc[1][0], a1, x3); cmac(acc[1][1], b1, x3);
+        cmac(acc[0][0], a2, x2); cmac(acc[0][1], b2, x2); cmac(acc[1][0], a2, x4); cmac(acc[1][1], b2, x4);
+        cmac(acc[0][0], a3, x3); cmac(acc[0][1], b3, x3); cmac(acc[1][0], a3, x5); cmac(acc[1][1], b3, x5);
+    };
+    if constexpr (INIT) group(0, std::true_type{});    // the first tap starts the accumulators (cmul): nothing to zero
+#pragma unroll 1
+    for (int g = INIT ? 1 : 0; g < G; g++) group(g, std::false_type{});
 #pragma unroll
     for (int k = 4 * G; k < M; k++) {                  // remaining 1 or 3 taps
-        float ar, ai, br, bi;
-        tap(k, ar, ai, br, bi);
-        mac(0, xp[(k & 3) * Lph + (k >> 2)], ar, ai, br, bi);
-        mac(1, xp[((k + 2) & 3) * Lph + ((k + 2) >> 2)], ar, ai, br, bi);
+        const v2f a = tapA(k), b = tapB(k);
+        const v2f xa = lds2(xp + (k & 3) * Lph + (k >> 2)), xb = lds2(xp + ((k + 2) & 3) * Lph + ((k + 2) >> 2));
+        cmac(acc[0][0], a, xa); cmac(acc[0][1], b, xa); cmac(acc[1][0], a, xb); cmac(acc[1][1], b, xb);
     }
 }
 
@@ -178,6 +173,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
     const int nq = (nm + 3) / 4;                               // residual quads t = 4l' .. 4l'+3
     const int n0 = 2 * gl;
     const float2 *Xl = Xs + gl, *El = Es + gl, *Ul = Us + gl;
+    const float2 *Xa = Xs + (act ? gl : 0), *Ea = Es + (act ? gl : 0);   // symbol-pair phases: idle lanes shadow lane 0 (results unused)
 
     // The window of the NEXT step is fetched into registers while the current step computes (one 16-byte load per lane and
     // row: B <= 128 means L/4 <= 64 lanes), so a step never waits for HBM after the first.
@@ -215,12 +211,9 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
             // ============ P1: FIR for the lane's symbol pair, both output polarisations
             float2 y[2][2];                                    // [sym][o]
             {
-                cacc ya[2][2];
-                ya[0][0] = ya[0][1] = ya[1][0] = ya[1][1] = cacc0();
-                if (act) {
-                    pair_fir<M, false>(ya, Xl, Lph, Wt, nullptr, nullptr);
-                    pair_fir<M, false>(ya, Xl + 4 * Lph, Lph, Wt + M, nullptr, nullptr);
-                }
+                cacc ya[2][2];                                 // lanes without a symbol pair recompute lane 0's (Xa): no divergence, nothing to zero
+                pair_fir<M, false, true>(ya, Xa, Lph, Wt, nullptr, nullptr);
+                pair_fir<M, false, false>(ya, Xa + 4 * Lph, Lph, Wt + M, nullptr, nullptr);
 #pragma unroll
                 for (int sy = 0; sy < 2; sy++)
 #pragma unroll
@@ -381,51 +374,57 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
             // ============ P3: residual e = x - D for the quad t = 4l'..4l'+3, both chi.
             //   D[chi, 2 tau + par] = sum_nu sum_a h[chi,nu,2a+par] U[nu, tau + mh - a],   tau in {2l', 2l'+1}, a = 0..mh
             float se0 = 0.f, se1 = 0.f;
-            if (gl < nq) {
-                cacc D[2][4];                                  // [chi][i], i = 2*dl + par
-#pragma unroll
-                for (int chi = 0; chi < 2; chi++)
-#pragma unroll
-                    for (int i = 0; i < 4; i++) D[chi][i] = cacc0();
+            {
+                cacc D[2][4];                                  // [chi][i], i = 2*dl + par; lanes without a quad shadow lane 0 (no divergence, unused)
+                constexpr int NA = mh + 1, NB = NA / 2;        // a = 0..mh; pairs (2b, 2b+1)
 #pragma unroll
                 for (int v = 0; v < 2; v++) {
                     const float2 *h0 = Ht + (0 * 2 + v) * MP, *h1 = Ht + (1 * 2 + v) * MP;
-                    const float2 *up = Ul + v * 2 * Uph;       // U[nu][2l' + d] = up[(d & 1) * Uph + (d >> 1)]
-                    auto step_a = [&](int aa, float2 ulo, float2 uhi) {   // ulo = U[2l' + mh - a], uhi = U[2l' + mh - a + 1]
-                        const float2 e0 = h0[2 * aa], o0 = h0[2 * aa + 1], e1 = h1[2 * aa], o1 = h1[2 * aa + 1];
-                        cmac(D[0][0], e0.x, e0.y, ulo); cmac(D[0][1], o0.x, o0.y, ulo);
-                        cmac(D[0][2], e0.x, e0.y, uhi); cmac(D[0][3], o0.x, o0.y, uhi);
-                        cmac(D[1][0], e1.x, e1.y, ulo); cmac(D[1][1], o1.x, o1.y, ulo);
-                        cmac(D[1][2], e1.x, e1.y, uhi); cmac(D[1][3], o1.x, o1.y, uhi);
+                    const float2 *up = Us + (gl < nq ? gl : 0) + v * 2 * Uph;       // U[nu][2l' + d] = up[(d & 1) * Uph + (d >> 1)]
+                    auto step_a = [&](int aa, v2f ulo, v2f uhi, auto first) {        // ulo = U[2l' + mh - a], uhi = U[2l' + mh - a + 1]
+                        constexpr bool F = decltype(first)::value;
+                        const v2f e0 = lds2(h0 + 2 * aa), o0 = lds2(h0 + 2 * aa + 1), e1 = lds2(h1 + 2 * aa), o1 = lds2(h1 + 2 * aa + 1);
+                        cmacf<F>(D[0][0], e0, ulo); cmacf<F>(D[0][1], o0, ulo);
+                        cmacf<F>(D[0][2], e0, uhi); cmacf<F>(D[0][3], o0, uhi);
+                        cmacf<F>(D[1][0], e1, ulo); cmacf<F>(D[1][1], o1, ulo);
+                        cmacf<F>(D[1][2], e1, uhi); cmacf<F>(D[1][3], o1, uhi);
                     };
-                    constexpr int NA = mh + 1, NB = NA / 2;    // a = 0..mh; pairs (2b, 2b+1)
+                    // a = mh first (d = 0 -> U[2l'], U[2l'+1]; its odd tap is the zero pad when mh is even); for nu = 0 it starts the accumulators
+                    if (NA & 1) {
+                        if (v == 0) step_a(mh, lds2(up), lds2(up + Uph), std::true_type{});
+                        else step_a(mh, lds2(up), lds2(up + Uph), std::false_type{});
+                    } else if (v == 0) {
+#pragma unroll
+                        for (int chi = 0; chi < 2; chi++)
+#pragma unroll
+                            for (int i = 0; i < 4; i++) D[chi][i] = cacc0();
+                    }
 #pragma unroll 1
                     for (int b = 0; b < NB; b++) {             // d = mh - 2b: samples d+1, d, d-1
                         constexpr int ph = mh & 1;             // phase of d (d and mh have equal parity)
                         const int sl = (mh >> 1) - b;          // slot of d   (d >> 1)
-                        const float2 ud = up[ph * Uph + sl];
-                        const float2 udp = up[(ph ^ 1) * Uph + sl + ph];            // d + 1
-                        const float2 udm = up[(ph ^ 1) * Uph + sl + ph - 1];        // d - 1
-                        step_a(2 * b, ud, udp);
-                        step_a(2 * b + 1, udm, ud);
-                    }
-                    if (NA & 1) {                              // a = mh: d = 0 -> U[2l'], U[2l'+1]
-                        step_a(mh, up[0], up[Uph]);
+                        const v2f ud = lds2(up + ph * Uph + sl);
+                        const v2f udp = lds2(up + (ph ^ 1) * Uph + sl + ph);            // d + 1
+                        const v2f udm = lds2(up + (ph ^ 1) * Uph + sl + ph - 1);        // d - 1
+                        step_a(2 * b, ud, udp, std::false_type{});
+                        step_a(2 * b + 1, udm, ud, std::false_type{});
                     }
                 }
+                if (gl < nq) {
 #pragma unroll
-                for (int chi = 0; chi < 2; chi++)
+                    for (int chi = 0; chi < 2; chi++)
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int ce = Mh + i;                 // + 4*lane: same (phase, slot) arithmetic as x
-                        const float2 x = Xl[(chi * 4 + (ce & 3)) * Lph + (ce >> 2)];
-                        const float2 Dv = cfin(D[chi][i]);
-                        float2 e = make_float2(x.x - Dv.x, x.y - Dv.y);
-                        if (4 * gl + i >= nm) e = make_float2(0.f, 0.f);
-                        Es[(chi * 4 + (ce & 3)) * Lph + gl + (ce >> 2)] = e;
-                        const float e2 = e.x * e.x + e.y * e.y;
-                        if (chi) se1 += e2; else se0 += e2;
-                    }
+                        for (int i = 0; i < 4; i++) {
+                            const int ce = Mh + i;             // + 4*lane: same (phase, slot) arithmetic as x
+                            const float2 x = Xl[(chi * 4 + (ce & 3)) * Lph + (ce >> 2)];
+                            const float2 Dv = cfin(D[chi][i]);
+                            float2 e = make_float2(x.x - Dv.x, x.y - Dv.y);
+                            if (4 * gl + i >= nm) e = make_float2(0.f, 0.f);
+                            Es[(chi * 4 + (ce & 3)) * Lph + gl + (ce >> 2)] = e;
+                            const float e2 = e.x * e.x + e.y * e.y;
+                            if (chi) se1 += e2; else se0 += e2;
+                        }
+                }
             }
             se0 = wave_sum(se0);
             se1 = wave_sum(se1);
@@ -495,16 +494,16 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
                     const float2 *uA = Us + (npA & 1) * Uph + (npA >> 1), *uB = Us + (npB & 1) * Uph + (npB >> 1);
 #pragma unroll 2
                     for (int m = ma; m < mb; m++) {
-                        const float2 e0 = eA[m], e1 = eA[4 * Lph + m], u0 = uA[m], u1 = uA[2 * Uph + m];
-                        const float2 f0 = eB[m], f1 = eB[4 * Lph + m], w0 = uB[m], w1 = uB[2 * Uph + m];
-                        cmac(ca[0][0], u0.x, u0.y, e0);
-                        cmac(ca[0][1], u1.x, u1.y, e0);
-                        cmac(ca[1][0], u0.x, u0.y, e1);
-                        cmac(ca[1][1], u1.x, u1.y, e1);
-                        cmac(ca[0][0], w0.x, w0.y, f0);
-                        cmac(ca[0][1], w1.x, w1.y, f0);
-                        cmac(ca[1][0], w0.x, w0.y, f1);
-                        cmac(ca[1][1], w1.x, w1.y, f1);
+                        const v2f e0 = lds2(eA + m), e1 = lds2(eA + 4 * Lph + m), u0 = lds2(uA + m), u1 = lds2(uA + 2 * Uph + m);
+                        const v2f f0 = lds2(eB + m), f1 = lds2(eB + 4 * Lph + m), w0 = lds2(uB + m), w1 = lds2(uB + 2 * Uph + m);
+                        cmac(ca[0][0], u0, e0);
+                        cmac(ca[0][1], u1, e0);
+                        cmac(ca[1][0], u0, e1);
+                        cmac(ca[1][1], u1, e1);
+                        cmac(ca[0][0], w0, f0);
+                        cmac(ca[0][1], w1, f0);
+                        cmac(ca[1][0], w0, f1);
+                        cmac(ca[1][1], w1, f1);
                     }
                 }
                 float2 acc[2][2];
@@ -562,12 +561,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
                 float2 au0[2][2], au1[2][2];                   // chi = 0 / 1: [sym][nu]
                 {
                     cacc c0[2][2], c1[2][2];
-                    c0[0][0] = c0[0][1] = c0[1][0] = c0[1][1] = cacc0();
-                    c1[0][0] = c1[0][1] = c1[1][0] = c1[1][1] = cacc0();
-                    if (act) {
-                        pair_fir<M, true>(c0, El, Lph, nullptr, Ht + 0 * MP, Ht + 1 * MP);
-                        pair_fir<M, true>(c1, El + 4 * Lph, Lph, nullptr, Ht + 2 * MP, Ht + 3 * MP);
-                    }
+                    pair_fir<M, true, true>(c0, Ea, Lph, nullptr, Ht + 0 * MP, Ht + 1 * MP);
+                    pair_fir<M, true, true>(c1, Ea + 4 * Lph, Lph, nullptr, Ht + 2 * MP, Ht + 3 * MP);
 #pragma unroll
                     for (int sy = 0; sy < 2; sy++)
 #pragma unroll
@@ -636,19 +631,19 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
                     const int ma = (part * Bq) >> 1, mb = min(B, part * Bq + Bq) >> 1;
                     const int cA = tk, cB = tk + 2;
                     const float2 *xA = Xs + (cA & 3) * Lph + (cA >> 2), *xB = Xs + (cB & 3) * Lph + (cB >> 2);
-                    const float4 *G0 = reinterpret_cast<const float4 *>(GY), *G1 = reinterpret_cast<const float4 *>(GY + B);
+                    const float2 *G0 = GY, *G1 = GY + B;
 #pragma unroll 2
                     for (int m = ma; m < mb; m++) {
-                        const float4 ga = G0[m], gb = G1[m];                             // (gy[o][2m], gy[o][2m+1])
-                        const float2 x0 = xA[m], x1 = xA[4 * Lph + m], z0 = xB[m], z1 = xB[4 * Lph + m];
-                        cmac(ca[0][0], x0.x, x0.y, make_float2(ga.x, ga.y));
-                        cmac(ca[0][1], x1.x, x1.y, make_float2(ga.x, ga.y));
-                        cmac(ca[1][0], x0.x, x0.y, make_float2(gb.x, gb.y));
-                        cmac(ca[1][1], x1.x, x1.y, make_float2(gb.x, gb.y));
-                        cmac(ca[0][0], z0.x, z0.y, make_float2(ga.z, ga.w));
-                        cmac(ca[0][1], z1.x, z1.y, make_float2(ga.z, ga.w));
-                        cmac(ca[1][0], z0.x, z0.y, make_float2(gb.z, gb.w));
-                        cmac(ca[1][1], z1.x, z1.y, make_float2(gb.z, gb.w));
+                        const v2f ga = lds2(G0 + 2 * m), gc = lds2(G0 + 2 * m + 1), gb = lds2(G1 + 2 * m), gd = lds2(G1 + 2 * m + 1);   // gy[o][2m], gy[o][2m+1]
+                        const v2f x0 = lds2(xA + m), x1 = lds2(xA + 4 * Lph + m), z0 = lds2(xB + m), z1 = lds2(xB + 4 * Lph + m);
+                        cmac(ca[0][0], x0, ga);
+                        cmac(ca[0][1], x1, ga);
+                        cmac(ca[1][0], x0, gb);
+                        cmac(ca[1][1], x1, gb);
+                        cmac(ca[0][0], z0, gc);
+                        cmac(ca[0][1], z1, gc);
+                        cmac(ca[1][0], z0, gd);
+                        cmac(ca[1][1], z1, gd);
                     }
                 }
                 float2 acc[2][2];
