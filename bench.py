@@ -43,8 +43,10 @@ FP32_PEAK_TFLOPS = 157.3            # MI355X fp32 vector peak (v_pk_fma_f32; the
 ALGO_FLOPS_PER_DP_SYMBOL = 4300.0
 ISSUED_FMA_FLOPS_PER_DP_SYMBOL = 5043.0
 REFERENCE_DP_SYMBOLS_PER_S = 2.17e3  # the reference itself (PyTorch CPU, 4 threads), measured in the survey container: BASELINE.md section 2
-PARITY_TOL = 2e-5                    # ELBO (relative) and taps (absolute) over the gate's free run; the run-to-run noise floor of fp32
-PARITY_STEPS = 20                    # free-running steps from the Dirac start (beyond ~30 the trajectories are chaotic: SURVEY section 7)
+PARITY_TOL = 1e-5                    # north_star's bound: per-batch ELBO (relative) and taps (absolute) over the gate's free run
+PARITY_STEPS = 10                    # free-running steps from the Dirac start.  fp32 chaos doubles the tap deviation every ~3-4 steps (measured, GPU vs
+                                     # oracle over 256 runs, tools/probe_parity.py: 3e-6 at 10 steps, 2e-5 at 20, 1.3e-4 at 30; SURVEY section 7 shows the
+                                     # same for the reference against itself), so 10 steps is where a 1e-5 gate still has a 3x margin
 
 CFG = dict(mod="64-QAM", sps=2, nu=0.0, channel="h0", SNR=23.0, symb_rate=90e9, tau_cd=-26e-24, tau_pmd=0.1e-12 * np.sqrt(1000),
            phiIQ=np.array([0.0314, 0.0314], dtype=np.complex64), theta=np.pi / 10, theta_diff=0.06 * np.pi, M_est=25, batch_len=100,
@@ -115,8 +117,8 @@ def parity_gate(frame_rx, data0, t, var, lr, device, threads):
 
     The first Rc runs train PARITY_STEPS free-running minibatch steps from the Dirac start on the GPU (the product path, through the C ABI) and
     in the oracle; gate: every step's ELBO <= PARITY_TOL relative, taps after the last step <= PARITY_TOL absolute, the epilogue's four SER
-    estimates of the equalised block <= 2e-3 absolute.  The whole 100-step frame is compared too, as information only: free runs that long are
-    chaotic in fp32 (the reference itself differs by 2.6e-2 in W between 1 and 4 CPU threads after 100 steps)."""
+    estimates of the equalised block <= 2e-3 absolute.  20 steps and the whole 100-step frame are compared too, as information only: free runs
+    that long are chaotic in fp32 (the reference itself differs by 2.6e-2 in W between 1 and 4 CPU threads after 100 steps)."""
     import oracle
     from vae_equalizer_amd.engine import DPEngine, dp_epilogue
     B, M, sps = CFG["batch_len"], CFG["M_est"], CFG["sps"]
@@ -126,7 +128,7 @@ def parity_gate(frame_rx, data0, t, var, lr, device, threads):
     rx_dev = frame_rx[:Rc].contiguous()
     rx_np = rx_dev[:, 0].cpu().numpy()
     res = {}
-    for tag, steps in (("gate", PARITY_STEPS), ("frame", steps_frame)):
+    for tag, steps in (("gate", PARITY_STEPS), ("s20", 20), ("frame", steps_frame)):
         eng = DPEngine(Rc, M, t["amps"], t["P"], [var, var], t["nu_sc"], device, sps, threads)
         lr_t = torch.tensor(lr[:Rc], device=device)
         g = eng.train(rx_dev, B, steps, lr_t, want_q=(tag == "gate"))
@@ -153,8 +155,9 @@ def parity_gate(frame_rx, data0, t, var, lr, device, threads):
     return {"ok": ok, "against": "oracle/ (C restatement of the reference, fp32, pinned by tests/golden)", "runs": Rc, "steps": PARITY_STEPS,
             "elbo_rel_max": gt["loss_rel"], "taps_abs_max": gt["taps_abs"], "tol": PARITY_TOL, "ser_abs_max": gt["ser_abs"], "ser_tol": 2e-3,
             "ser_level": gt["ser_mean"],
-            "full_frame_100_steps_informational": {"elbo_rel_max": res["frame"]["loss_rel"], "taps_abs_max": res["frame"]["taps_abs"],
-                                                   "note": "free run past the chaotic horizon (SURVEY section 7); not gated"}}
+            "informational_not_gated": {"20_steps": {"elbo_rel_max": res["s20"]["loss_rel"], "taps_abs_max": res["s20"]["taps_abs"]},
+                                        "full_frame_100_steps": {"elbo_rel_max": res["frame"]["loss_rel"], "taps_abs_max": res["frame"]["taps_abs"]},
+                                        "note": "free runs past the chaotic horizon (SURVEY section 7)"}}
 
 
 def cpu_baseline(frame_rx, t, var, lr, target_s, threads):

@@ -28,7 +28,7 @@ def test_bench_line_contract():
     assert abs(d["ms_per_step"] * 3 - d["region_ms"]["median"]) < 1e-6 * d["region_ms"]["median"] + 1e-9
     assert abs(d["value"] - 512 * 10000 * 3 / (d["region_ms"]["median"] * 1e-3)) < 1e-6 * d["value"]
     p = d["parity"]
-    assert p["ok"] and p["elbo_rel_max"] <= p["tol"] == 2e-5 and p["taps_abs_max"] <= 2e-5 and p["ser_abs_max"] <= 2e-3 and p["runs"] >= 8
+    assert p["ok"] and p["elbo_rel_max"] <= p["tol"] == 1e-5 and p["taps_abs_max"] <= 1e-5 and p["ser_abs_max"] <= 2e-3 and p["runs"] >= 8 and p["steps"] == 10
     rf = d["roofline"]
     assert rf["kernel"] == "vaeq::dp_wave_kernel<25, 8, 100, true, 1, 1>"          # what vaeq_dp_train launched, not a literal in bench.py
     assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / 8000.0) < 1e-12 and rf["kernel_ms"] <= d["ms_per_step"] * 1.001

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Shader-clock cycles per phase of the last step of one wave of the DP wave kernel under full load (library built with the phase
-stamps: tools/build_phase_probe.sh dp_wave -> gpurun_variants/libvaeq_dp_waveprof.so).  VAEQ_LIB=... python tools/probe_dp_phases.py [R]"""
+stamps: tools/snap_variant.sh stamps -DVAEQ_PHASE_STAMPS -> gpurun_variants/libvaeq_stamps.so).  VAEQ_LIB=... python tools/probe_dp_phases.py [R]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,8 +12,9 @@ rx = 0.4 * torch.randn(R, 1, 2, 2, 20000, device="cuda:0")
 for _ in range(2):
     out = eng.train(rx, 100, 100, 2.5e-3)
 torch.cuda.synchronize()
-t = out["loss"].reshape(-1)[:7].cpu().numpy()
-names = ["P0 window->LDS", "P1 FIR", "P2 demap", "P3 residual D", "P4a dh + Adam(h)", "P4b dU, dy", "P5 dW + Adam(W)"]
+t = out["loss"].reshape(-1)[:11].cpu().numpy()
+names = ["P0 window->LDS", "P1 FIR", "P1 y stores", "P2 demap + q stores", "P2 scan, VS", "P3 D conv", "P3 e, sums, loss, PSh", "P4a dh + Adam(h)",
+         "P4b dU, dy", "P4b h, gy -> LDS", "P5 dW + Adam(W)"]
 for n, v in zip(names, t):
     print(f"{n:20s} {v:9.0f} cycles  {100 * v / t.sum():5.1f} %")
 print("sum", t.sum(), "cycles per step")

@@ -16,8 +16,22 @@ __global__ __launch_bounds__(64) void k(float *out, int iters, long long *cyc)
     for (int i = 0; i < 8; i++) { a[i] = v2f{0.f, (float)i}; d[i] = v4f{0, 0, 0, (float)i}; }
     for (int i = 0; i < 2; i++) for (int j = 0; j < 16; j++) e[i][j] = (float)j;
     float ma = threadIdx.x * 0.01f, mb = 1.0f - threadIdx.x * 0.001f;
+    v2f a2[8];
+    for (int i = 0; i < 8; i++) a2[i] = v2f{1.f, (float)i};
     long long t0 = clock64();
     for (int it = 0; it < iters; it++) {
+        if (MODE == 7) {                                  // 16 pk_fma on 16 independent accumulators
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(t), "v"(x));
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a2[i]) : "v"(t), "v"(x));
+        }
+        if (MODE == 8) {                                  // 16 pk_fma on 4 accumulators
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(t), "v"(x));
+        }
         if (MODE == 0 || MODE == 2 || MODE == 4 || MODE == 6) {       // 16 pk_fma (8 accumulators x 2)
 #pragma unroll
             for (int r = 0; r < 2; r++)
@@ -43,7 +57,7 @@ __global__ __launch_bounds__(64) void k(float *out, int iters, long long *cyc)
     }
     long long t1 = clock64();
     float s = 0;
-    for (int i = 0; i < 8; i++) s += a[i].x + a[i].y + d[i][0] + d[i][3];
+    for (int i = 0; i < 8; i++) s += a[i].x + a[i].y + d[i][0] + d[i][3] + a2[i].x + a2[i].y;
     for (int i = 0; i < 2; i++) for (int j = 0; j < 16; j++) s += e[i][j];
     out[blockIdx.x * 64 + threadIdx.x] = s;
     if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
@@ -69,7 +83,9 @@ void run(const char *name, int waves_per_simd)
 int main()
 {
     for (int w = 1; w <= 2; w++) {
-        run<0>("16 pk_fma", w);
+        run<0>("16 pk_fma (8 chains)", w);
+        run<7>("16 pk_fma (16 chains)", w);
+        run<8>("16 pk_fma (4 chains)", w);
         run<1>("8 mfma_4x4x1", w);
         run<2>("16 pk_fma + 8 mfma_4x4x1", w);
         run<3>("2 mfma_16x16x4", w);

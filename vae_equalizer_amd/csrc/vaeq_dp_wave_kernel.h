@@ -32,11 +32,23 @@
 #include "vaeq_common.h"
 #include "vaeq_wave.h"
 
+// -DVAEQ_PHASE_STAMPS: shader-clock stamps around the phases of the LAST step of one wave under full load, written over loss[0..] of the launch
+// (tools/probe_dp_phases.py reads them; the build is for that probe only: tools/snap_variant.sh stamps -DVAEQ_PHASE_STAMPS).
+#ifdef VAEQ_PHASE_STAMPS
+#define VAEQ_STAMP(i) do { if (s == a.steps - 1) tst[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define VAEQ_STAMP(i) do { } while (0)
+#endif
+#define VAEQ_NSTAMP 12
+#ifndef VAEQ_WPS
+#define VAEQ_WPS 2                                     // workgroups per SIMD the register budget is sized for (3 would need <= 168 VGPRs: it spills)
+#endif
+
 namespace vaeq {
 
 struct WaveLayout {
     int Lph, Uph;                                      // float2 per polyphase component of x/e and of mu
-    int X, E, U, PSv, W, H, PSh, VS, RED, XG, total;   // byte offsets (the dL/dy buffer aliases U)
+    int X, E, U, PSv, W, H, PSh, VS, MOM, RED, XG, total;   // byte offsets (the dL/dy buffer aliases U)
 };
 
 __host__ __device__ inline WaveLayout wave_layout(int B, int M, int NW = 1)
@@ -57,45 +69,116 @@ __host__ __device__ inline WaveLayout wave_layout(int B, int M, int NW = 1)
     l.H = take(2 * 2 * (M + 1) * 8);                   // one zero pad tap per (chi, nu): j = M
     l.PSh = take(2 * (M + 1) * 4);
     l.VS = take(2 * M * 4);
+    l.MOM = take(16 * 64 * 4);                         // Adam moments of the taps a lane owns: [16][64 lanes] (registers are the scarcer resource)
     l.RED = take(NW > 1 ? 64 * 4 : 0);                 // NW > 1: cross-wave scan offsets and sums
     l.XG = take((NW - 1) * 4 * 64 * 4);                // ... and the tap-gradient partial sums of waves 1..NW-1
     l.total = o;
     return l;
 }
 
-// y[sym] += sum_k taps[k] * x[4l + 2*sym + k] for the lane's symbol pair, one input polarisation (FIR) -- or the same
-// shape on the residual with conjugated channel taps (dL/dU).  xp = phase-0 pointer of the lane (slot = lane).
-//   FIR : T = float4 tap quads (o0.re, o0.im, o1.re, o1.im), acc[sym][o]  += w * x
-//   DU  : two float2 tap arrays (nu = 0, 1),                   acc[sym][nu] += e * conj(h)
-// INIT: the first tap starts the accumulators (no zeroing); else they are added to.
-template <int M, bool CONJ, bool INIT>
-__device__ __forceinline__ void pair_fir(cacc (&acc)[2][2], const float2 *xp, int Lph, const float4 *wq, const float2 *ha,
-                                         const float2 *hb)
+// y[sym] += sum_k taps[k] * x[4l + 2*sym + k] for the lane's symbol pair, one input polarisation (FIR): T = float4 tap quads
+// (o0.re, o0.im, o1.re, o1.im), acc[sym][o] += w * x.  xp = phase-0 pointer of the lane (slot = lane).
+// A dependent v_pk_fma_f32 can issue only every ~12 cycles (measured: one wave with 8 accumulator chains reaches 64 % of the packed-FMA rate,
+// tools/ubench/coissue.hip), and with 2 waves per SIMD a wave is often alone in its FMA burst -- so every convolution-shaped phase keeps 16
+// independent chains: here the even taps accumulate into acc, the odd taps into acc2 (the caller adds them once at the end).
+// INIT: the first taps start the accumulators (no zeroing); else they are added to.
+template <int M, bool INIT, bool PIPE = true>
+__device__ __forceinline__ void pair_fir(cacc (&acc)[2][2], cacc (&acc2)[2][2], const float2 *xp, int Lph, const float4 *wq)
 {
-    // tap k as two register pairs: FIR (re, im) of o = 0 / 1; dL/dU (re, im) of h[chi][nu = 0 / 1]
-    auto tapA = [&](int k) -> v2f { return CONJ ? lds2(ha + k) : lds2(reinterpret_cast<const float2 *>(wq + k)); };
-    auto tapB = [&](int k) -> v2f { return CONJ ? lds2(hb + k) : lds2(reinterpret_cast<const float2 *>(wq + k) + 1); };
+    auto tapA = [&](int k) -> v2f { return lds2(reinterpret_cast<const float2 *>(wq + k)); };       // (re, im) of o = 0
+    auto tapB = [&](int k) -> v2f { return lds2(reinterpret_cast<const float2 *>(wq + k) + 1); };   // (re, im) of o = 1
     constexpr int G = M / 4;
-    auto group = [&](int g, auto first) {              // taps 4g..4g+3, samples c' = 4g..4g+5 (14 independent 8-byte LDS reads, then 32 packed FMAs)
-        constexpr bool F = decltype(first)::value;
+    // stage g: taps 4g..4g+3, samples c' = 4g..4g+5 -- 14 independent 8-byte LDS reads feeding 32 packed FMAs
+    auto load = [&](int g, v2f (&r)[14]) {
         const float2 *xg = xp + g;
-        const v2f x0 = lds2(xg), x1 = lds2(xg + Lph), x2 = lds2(xg + 2 * Lph), x3 = lds2(xg + 3 * Lph), x4 = lds2(xg + 1), x5 = lds2(xg + Lph + 1);
-        const v2f a0 = tapA(4 * g), b0 = tapB(4 * g), a1 = tapA(4 * g + 1), b1 = tapB(4 * g + 1);
-        const v2f a2 = tapA(4 * g + 2), b2 = tapB(4 * g + 2), a3 = tapA(4 * g + 3), b3 = tapB(4 * g + 3);
-        cmacf<F>(acc[0][0], a0, x0); cmacf<F>(acc[0][1], b0, x0); cmacf<F>(acc[1][0], a0, x2); cmacf<F>(acc[1][1], b0, x2);
-        cmac(acc[0][0], a1, x1); cmac(acc[0][1], b1, x1); cmac(acc[1][0], a1, x3); cmac(acc[1][1], b1, x3);
-        cmac(acc[0][0], a2, x2); cmac(acc[0][1], b2, x2); cmac(acc[1][0], a2, x4); cmac(acc[1][1], b2, x4);
-        cmac(acc[0][0], a3, x3); cmac(acc[0][1], b3, x3); cmac(acc[1][0], a3, x5); cmac(acc[1][1], b3, x5);
+        r[0] = lds2(xg); r[1] = lds2(xg + Lph); r[2] = lds2(xg + 2 * Lph); r[3] = lds2(xg + 3 * Lph); r[4] = lds2(xg + 1); r[5] = lds2(xg + Lph + 1);
+#pragma unroll
+        for (int t = 0; t < 4; t++) { r[6 + 2 * t] = tapA(4 * g + t); r[7 + 2 * t] = tapB(4 * g + t); }
     };
-    if constexpr (INIT) group(0, std::true_type{});    // the first tap starts the accumulators (cmul): nothing to zero
-#pragma unroll 1
-    for (int g = INIT ? 1 : 0; g < G; g++) group(g, std::false_type{});
+    auto fma = [&](int, const v2f (&r)[14], auto first) {
+        constexpr bool F = decltype(first)::value;     // the very first taps start the accumulators (cmul): nothing to zero
+        cmacf<F>(acc[0][0], r[6], r[0]); cmacf<F>(acc[0][1], r[7], r[0]); cmacf<F>(acc[1][0], r[6], r[2]); cmacf<F>(acc[1][1], r[7], r[2]);
+        cmacf<F>(acc2[0][0], r[8], r[1]); cmacf<F>(acc2[0][1], r[9], r[1]); cmacf<F>(acc2[1][0], r[8], r[3]); cmacf<F>(acc2[1][1], r[9], r[3]);
+        cmac(acc[0][0], r[10], r[2]); cmac(acc[0][1], r[11], r[2]); cmac(acc[1][0], r[10], r[4]); cmac(acc[1][1], r[11], r[4]);
+        cmac(acc2[0][0], r[12], r[3]); cmac(acc2[0][1], r[13], r[3]); cmac(acc2[1][0], r[12], r[5]); cmac(acc2[1][1], r[13], r[5]);
+    };
+    pipe2<14, INIT, PIPE>(G, load, fma);
 #pragma unroll
     for (int k = 4 * G; k < M; k++) {                  // remaining 1 or 3 taps
         const v2f a = tapA(k), b = tapB(k);
         const v2f xa = lds2(xp + (k & 3) * Lph + (k >> 2)), xb = lds2(xp + ((k + 2) & 3) * Lph + ((k + 2) >> 2));
-        cmac(acc[0][0], a, xa); cmac(acc[0][1], b, xa); cmac(acc[1][0], a, xb); cmac(acc[1][1], b, xb);
+        if (k & 1) { cmac(acc2[0][0], a, xa); cmac(acc2[0][1], b, xa); cmac(acc2[1][0], a, xb); cmac(acc2[1][1], b, xb); }
+        else { cmac(acc[0][0], a, xa); cmac(acc[0][1], b, xa); cmac(acc[1][0], a, xb); cmac(acc[1][1], b, xb); }
     }
+}
+
+// dL/dU for the lane's symbol pair: the FIR's shape on the residual e with conjugated channel taps, acc[chi][sym][nu] += e[chi] * conj(h[chi][nu]),
+// BOTH chi in one loop (16 independent accumulator chains, see pair_fir).  ep = phase-0 pointer of the lane into e[chi = 0] (chi = 1: + 4 Lph);
+// ht[chi * 2 + nu] = the tap rows (float2, MP apart).  Runs at the kernel's register peak (the demapper's moments are live): one operand set.
+template <int M, bool PIPE = false>
+__device__ __forceinline__ void pair_du(cacc (&acc)[2][2][2], const float2 *ep, int Lph, const float2 *ht, int MP)
+{
+    constexpr int G = M / 4;
+    // stage g: taps 4g..4g+3 of the 4 rows, samples c' = 4g..4g+5 of both chi -- 28 independent LDS reads feeding 64 packed FMAs
+    auto load = [&](int g, v2f (&r)[28]) {
+#pragma unroll
+        for (int chi = 0; chi < 2; chi++) {
+            const float2 *xg = ep + chi * 4 * Lph + g;
+            v2f *x = r + chi * 14;
+            x[0] = lds2(xg); x[1] = lds2(xg + Lph); x[2] = lds2(xg + 2 * Lph); x[3] = lds2(xg + 3 * Lph); x[4] = lds2(xg + 1); x[5] = lds2(xg + Lph + 1);
+#pragma unroll
+            for (int t = 0; t < 4; t++) { x[6 + 2 * t] = lds2(ht + (chi * 2 + 0) * MP + 4 * g + t); x[7 + 2 * t] = lds2(ht + (chi * 2 + 1) * MP + 4 * g + t); }
+        }
+    };
+    auto fma = [&](int, const v2f (&r)[28], auto first) {
+        constexpr bool F = decltype(first)::value;
+#pragma unroll
+        for (int chi = 0; chi < 2; chi++) {
+            const v2f *x = r + chi * 14;
+            cmacf<F>(acc[chi][0][0], x[6], x[0]); cmacf<F>(acc[chi][0][1], x[7], x[0]); cmacf<F>(acc[chi][1][0], x[6], x[2]); cmacf<F>(acc[chi][1][1], x[7], x[2]);
+        }
+#pragma unroll
+        for (int t = 1; t < 4; t++)
+#pragma unroll
+            for (int chi = 0; chi < 2; chi++) {
+                const v2f *x = r + chi * 14;
+                cmac(acc[chi][0][0], x[6 + 2 * t], x[t]); cmac(acc[chi][0][1], x[7 + 2 * t], x[t]);
+                cmac(acc[chi][1][0], x[6 + 2 * t], x[t + 2]); cmac(acc[chi][1][1], x[7 + 2 * t], x[t + 2]);
+            }
+    };
+    pipe2<28, true, PIPE>(G, load, fma);
+#pragma unroll
+    for (int k = 4 * G; k < M; k++)                    // remaining 1 or 3 taps
+#pragma unroll
+        for (int chi = 0; chi < 2; chi++) {
+            const float2 *xp = ep + chi * 4 * Lph;
+            const v2f a = lds2(ht + (chi * 2 + 0) * MP + k), b = lds2(ht + (chi * 2 + 1) * MP + k);
+            const v2f xa = lds2(xp + (k & 3) * Lph + (k >> 2)), xb = lds2(xp + ((k + 2) & 3) * Lph + ((k + 2) >> 2));
+            cmac(acc[chi][0][0], a, xa); cmac(acc[chi][0][1], b, xa); cmac(acc[chi][1][0], a, xb); cmac(acc[chi][1][1], b, xb);
+        }
+}
+
+// Whether the dL/dh (T = B - mh terms per parity) and dL/dw (B / 2 pairs) sums split into NP parts of equal, non-zero length.
+constexpr bool uniform_parts(int B, int M, int NP)
+{
+    const int mh = M / 2, nm = 2 * B - 2 * mh;
+    for (int par = 0; par < 2; par++) {
+        const int T = (nm - par + 1) >> 1, Th = ((T + 2 * NP - 1) / (2 * NP)) << 1;
+        int n0 = -1;
+        for (int part = 0; part < NP; part++) {
+            const int ma = (part * Th) >> 1, e = part * Th + Th, mb = ((T < e ? T : e) + 1) >> 1;
+            if (mb - ma <= 0 || (n0 >= 0 && mb - ma != n0)) return false;
+            n0 = mb - ma;
+        }
+    }
+    const int Bq = ((B + 2 * NP - 1) / (2 * NP)) << 1;
+    int n0 = -1;
+    for (int part = 0; part < NP; part++) {
+        const int ma = (part * Bq) >> 1, e = part * Bq + Bq, mb = (B < e ? B : e) >> 1;
+        if (mb - ma <= 0 || (n0 >= 0 && mb - ma != n0)) return false;
+        n0 = mb - ma;
+    }
+    return true;
 }
 
 // OUT: 0 = every output nullable at run time; 1 = no compact outputs (eq_out / dec_out ignored); 2 = compact outputs, q not written.
@@ -104,7 +187,7 @@ __device__ __forceinline__ void pair_fir(cacc (&acc)[2][2], const float2 *xp, in
 // (2 gl, 2 gl + 1), the tap-gradient sums are split 2 NW ways, wave 0 owns the taps and their Adam moments; phases are separated
 // by s_barrier after an LDS-only wait (sync_lds), so the in-flight q / y stores still never stall a phase.
 template <int M, int NLEV, int BT, bool PAIR, int OUT, int NW = 1>
-__global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args a)
+__global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_dp_args a)
 {
     constexpr int mh = M / 2, Mh = 2 * mh, MP = M + 1;
     constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
@@ -112,6 +195,16 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
     char *sm = reinterpret_cast<char *>(smem4);
     const int gl = threadIdx.x, lane = NW > 1 ? (gl & 63) : gl, wv = NW > 1 ? (gl >> 6) : 0, run = blockIdx.x;
     constexpr int NT = 64 * NW, NP = 2 * NW;              // threads per run; parts a tap-gradient sum is split into
+    // baked shape whose tap-gradient sums split into NP equal, non-empty parts: their loops run on a scalar trip count and start from the first term
+    constexpr bool UNI = BT > 0 && uniform_parts(BT, M, NP);
+#ifndef VAEQ_PIPE_DU
+#define VAEQ_PIPE_DU 0
+#endif
+#ifndef VAEQ_PIPE
+#define VAEQ_PIPE 1
+#endif
+    constexpr bool PIPE = VAEQ_PIPE;
+    constexpr bool PIPE_DU = VAEQ_PIPE_DU;                 // dL/dU runs at the kernel's register peak (moments of the demapper still live): no second operand set there
     const int B = BT ? BT : a.B;
     const int L = 2 * B, nm = L - Mh, P2 = B / 2;
     const WaveLayout lay = wave_layout(B, M, NW);
@@ -145,8 +238,17 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
     const bool worker = tk < M, owner = worker && wv == 0;     // worker: sums a part of a tap's gradient; owner: holds the tap
     const int part = wv * 2 + half;
     const size_t gbase = (size_t)run * 8 * M;
-    float mWr[2] = {0, 0}, mWi[2] = {0, 0}, vWr[2] = {0, 0}, vWi[2] = {0, 0};   // [p]  moments of W[o=half][p][k=tk]
-    float mHr[2] = {0, 0}, mHi[2] = {0, 0}, vHr[2] = {0, 0}, vHi[2] = {0, 0};   // [nu] moments of h[chi=half][nu][.][j=tk]
+    // Adam moments of the taps this lane owns live in LDS, one 64-lane row per quantity (touched twice per step; 16 VGPRs freed):
+    // rows 0-7: m, v of W[o=half][p][k=tk] (re, im); rows 8-15: m, v of h[chi=half][nu][.][j=tk]
+    float *MOM = reinterpret_cast<float *>(sm + lay.MOM) + lane;
+#define mWr(p) MOM[(0 + (p)) * 64]
+#define mWi(p) MOM[(2 + (p)) * 64]
+#define vWr(p) MOM[(4 + (p)) * 64]
+#define vWi(p) MOM[(6 + (p)) * 64]
+#define mHr(p) MOM[(8 + (p)) * 64]
+#define mHi(p) MOM[(10 + (p)) * 64]
+#define vHr(p) MOM[(12 + (p)) * 64]
+#define vHi(p) MOM[(14 + (p)) * 64]
     if (owner) {
 #pragma unroll
         for (int p = 0; p < 2; p++) {
@@ -154,12 +256,12 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
             float *wq = reinterpret_cast<float *>(&Wt[p * M + tk]);
             wq[half * 2 + 0] = a.W[ir];
             wq[half * 2 + 1] = a.W[ii];
-            mWr[p] = a.adam_mW[ir]; mWi[p] = a.adam_mW[ii];
-            vWr[p] = a.adam_vW[ir]; vWi[p] = a.adam_vW[ii];
+            mWr(p) = a.adam_mW[ir]; mWi(p) = a.adam_mW[ii];
+            vWr(p) = a.adam_vW[ir]; vWi(p) = a.adam_vW[ii];
             const size_t hr = gbase + ((half * 2 + p) * 2 + 0) * M + tk, hi = hr + M;
             Ht[(half * 2 + p) * MP + tk] = make_float2(a.h[hr], a.h[hi]);
-            mHr[p] = a.adam_mh[hr]; mHi[p] = a.adam_mh[hi];
-            vHr[p] = a.adam_vh[hr]; vHi[p] = a.adam_vh[hi];
+            mHr(p) = a.adam_mh[hr]; mHi(p) = a.adam_mh[hi];
+            vHr(p) = a.adam_vh[hr]; vHi(p) = a.adam_vh[hi];
         }
     }
     int step = a.step[run];
@@ -179,20 +281,29 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
     // row: B <= 128 means L/4 <= 64 lanes), so a step never waits for HBM after the first.
     const bool ldl = gl < L / 4;
     float4 pf[4];
+    const uint32_t S4 = (uint32_t)a.S * 4u;                    // bytes per received row; a frame of a run = 4 rows
     auto fetch = [&](int f, int s) {
-        const float *src = a.rx + ((size_t)run * a.n_frames + f) * 4 * (size_t)a.S + (size_t)s * a.stride_sym * 2 + 4 * gl;
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.rx + ((size_t)run * a.n_frames + f) * 4 * (size_t)a.S, 4u * S4);
+        const uint32_t vo = ldl ? ((uint32_t)s * (uint32_t)a.stride_sym * 2u + 4u * gl) * 4u : OOB;   // lanes beyond the window read zeros
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-            pf[r] = ldl ? *reinterpret_cast<const float4 *>(src + (size_t)r * a.S) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = 0; r < 4; r++) pf[r] = bld128(xr, vo, (uint32_t)r * S4);
     };
+#ifdef VAEQ_PHASE_STAMPS
+    long long tst[VAEQ_NSTAMP];
+#endif
     fetch(0, 0);
     for (int f = 0; f < a.n_frames; f++) {
-        float *qf = (OUT != 2 && a.q_out) ? a.q_out + ((size_t)run * a.n_frames + f) * (4 * NLEV) * No : nullptr;
-        float *yf = a.y_out ? a.y_out + ((size_t)run * a.n_frames + f) * 4 * No : nullptr;
-        float *ef = (OUT != 1 && a.eq_out) ? a.eq_out + ((size_t)run * a.n_frames + f) * 2 * No : nullptr;
-        int8_t *df = (OUT != 1 && a.dec_out) ? a.dec_out + ((size_t)run * a.n_frames + f) * 4 * No : nullptr;
+        // one buffer descriptor per output array and frame; rows are addressed by scalar offsets (row * No4) folded into the stores
+        const bool qf = OUT != 2 && a.q_out, yf = a.y_out, ef = OUT != 1 && a.eq_out, df = OUT != 1 && a.dec_out;
+        const uint32_t No4 = (uint32_t)No * 4u;
+        const size_t fr = (size_t)run * a.n_frames + f;
+        const __amdgpu_buffer_rsrc_t qr = make_rsrc(qf ? a.q_out + fr * (4 * NLEV) * No : nullptr, qf ? 4u * NLEV * No4 : 0u);
+        const __amdgpu_buffer_rsrc_t yr = make_rsrc(yf ? a.y_out + fr * 4 * No : nullptr, yf ? 4u * No4 : 0u);
+        const __amdgpu_buffer_rsrc_t er = make_rsrc(ef ? a.eq_out + fr * 2 * No : nullptr, ef ? 2u * No4 : 0u);
+        const __amdgpu_buffer_rsrc_t dr = make_rsrc(df ? a.dec_out + fr * 4 * No : nullptr, df ? (uint32_t)(4 * No) : 0u);
 #pragma unroll 1
         for (int s = 0; s < a.steps; s++) {
+            VAEQ_STAMP(0);
             // ============ P0: prefetched window -> LDS (polyphase scatter; halo stays zero)
             if (ldl) {
 #pragma unroll
@@ -208,38 +319,43 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
             }
             sync_lds<NW>();
 
+            VAEQ_STAMP(1);
             // ============ P1: FIR for the lane's symbol pair, both output polarisations
             float2 y[2][2];                                    // [sym][o]
             {
-                cacc ya[2][2];                                 // lanes without a symbol pair recompute lane 0's (Xa): no divergence, nothing to zero
-                pair_fir<M, false, true>(ya, Xa, Lph, Wt, nullptr, nullptr);
-                pair_fir<M, false, false>(ya, Xa + 4 * Lph, Lph, Wt + M, nullptr, nullptr);
+                cacc ya[2][2], yb[2][2];                       // lanes without a symbol pair recompute lane 0's (Xa): no divergence, nothing to zero
+                pair_fir<M, true, PIPE>(ya, yb, Xa, Lph, Wt);
+                pair_fir<M, false, PIPE>(ya, yb, Xa + 4 * Lph, Lph, Wt + M);
 #pragma unroll
                 for (int sy = 0; sy < 2; sy++)
 #pragma unroll
-                    for (int o = 0; o < 2; o++) y[sy][o] = cfin(ya[sy][o]);
+                    for (int o = 0; o < 2; o++) {
+                        ya[sy][o].a += yb[sy][o].a;
+                        ya[sy][o].b += yb[sy][o].b;
+                        y[sy][o] = cfin(ya[sy][o]);
+                    }
             }
             // pin: hipcc otherwise sinks whole FMA chains to their (much later) use and keeps their inputs alive instead
             asm volatile("" : "+v"(y[0][0].x), "+v"(y[0][0].y), "+v"(y[0][1].x), "+v"(y[0][1].y), "+v"(y[1][0].x), "+v"(y[1][0].y),
                          "+v"(y[1][1].x), "+v"(y[1][1].y));
+            VAEQ_STAMP(2);
             const bool kept0 = act && (n0 >= k0) && (n0 < k0 + klen), kept1 = act && (n0 + 1 >= k0) && (n0 + 1 < k0 + klen);
-            const size_t col = (size_t)s * klen + (n0 - k0);
+            const uint32_t col = (uint32_t)(s * klen + (n0 - k0));
+            const uint32_t vo0 = kept0 ? col * 4u : OOB, vo1 = kept1 ? col * 4u + 4u : OOB;     // byte offsets inside a row; OOB = not stored
             if (yf) {
 #pragma unroll
                 for (int o = 0; o < 2; o++) {
-                    float *rI = yf + (size_t)(o * 2 + 0) * No + col, *rQ = yf + (size_t)(o * 2 + 1) * No + col;
                     if (pairst) {
-                        if (kept0) {
-                            *reinterpret_cast<float2 *>(rI) = make_float2(y[0][o].x, y[1][o].x);
-                            *reinterpret_cast<float2 *>(rQ) = make_float2(y[0][o].y, y[1][o].y);
-                        }
+                        bst64(v2f{y[0][o].x, y[1][o].x}, yr, vo0, (uint32_t)(o * 2 + 0) * No4);
+                        bst64(v2f{y[0][o].y, y[1][o].y}, yr, vo0, (uint32_t)(o * 2 + 1) * No4);
                     } else {
-                        if (kept0) { rI[0] = y[0][o].x; rQ[0] = y[0][o].y; }
-                        if (kept1) { rI[1] = y[1][o].x; rQ[1] = y[1][o].y; }
+                        bst32(y[0][o].x, yr, vo0, (uint32_t)(o * 2 + 0) * No4); bst32(y[0][o].y, yr, vo0, (uint32_t)(o * 2 + 1) * No4);
+                        bst32(y[1][o].x, yr, vo1, (uint32_t)(o * 2 + 0) * No4); bst32(y[1][o].y, yr, vo1, (uint32_t)(o * 2 + 1) * No4);
                     }
                 }
             }
 
+            VAEQ_STAMP(3);
             // ============ P2: soft demap + moments (registers), mu -> LDS, prefix sums of the variances
             float mv[2][2][2], mt3[2][2][2], mkc[2][2][2];     // [sym][o][c]: Var_q, 3rd central moment, KL-gradient moment
             float klsum = 0.f, vv[2][2];                       // vv[o][sym] = v_I + v_Q
@@ -277,13 +393,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
                     }
                     // compact stand-ins for q in the epilogue: E_q[x_I] and the first maximum of q, exactly as it would derive them
                     if (ef && c == 0) {
-                        float *r = ef + (size_t)o * No + col;
-                        if (pairst) {
-                            if (kept0) *reinterpret_cast<v2f *>(r) = m1;
-                        } else {
-                            if (kept0) r[0] = m1.x;
-                            if (kept1) r[1] = m1.y;
-                        }
+                        if (pairst) bst64(m1, er, vo0, (uint32_t)o * No4);
+                        else { bst32(m1.x, er, vo0, (uint32_t)o * No4); bst32(m1.y, er, vo1, (uint32_t)o * No4); }
                     }
                     if (df) {
                         float v0 = q[0].x, v1 = q[0].y;
@@ -293,13 +404,9 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
                             if (q[i].x > v0) { v0 = q[i].x; b0 = i; }
                             if (q[i].y > v1) { v1 = q[i].y; b1 = i; }
                         }
-                        int8_t *r = df + (size_t)(o * 2 + c) * No + col;
-                        if (pairst) {
-                            if (kept0) *reinterpret_cast<uint16_t *>(r) = (uint16_t)(b0 | (b1 << 8));
-                        } else {
-                            if (kept0) r[0] = (int8_t)b0;
-                            if (kept1) r[1] = (int8_t)b1;
-                        }
+                        const uint32_t ro = (uint32_t)(o * 2 + c) * (uint32_t)No;                 // one byte per decision
+                        if (pairst) bst16((unsigned short)(b0 | (b1 << 8)), dr, kept0 ? col : OOB, ro);
+                        else { bst8((unsigned char)b0, dr, kept0 ? col : OOB, ro); bst8((unsigned char)b1, dr, kept1 ? col + 1u : OOB, ro); }
                     }
                     // log(q_i/P_i) = z_i ln2 - log(ssum) - log P_i: the softmax's own logits; the +1e-12 inside the reference's
                     // log and the q/(q+eps P) factor of its derivative change q*log(.) by < 1e-12, and the terms
@@ -326,13 +433,9 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
                     if (qf) {
 #pragma unroll
                         for (int i = 0; i < NLEV; i++) {
-                            float *r = qf + (size_t)(o * 2 * NLEV + c * NLEV + i) * No + col;
-                            if (pairst) {
-                                if (kept0) *reinterpret_cast<v2f *>(r) = q[i];
-                            } else {
-                                if (kept0) r[0] = q[i].x;
-                                if (kept1) r[1] = q[i].y;
-                            }
+                            const uint32_t ro = (uint32_t)(o * 2 * NLEV + c * NLEV + i) * No4;
+                            if (pairst) bst64(q[i], qr, vo0, ro);
+                            else { bst32(q[i].x, qr, vo0, ro); bst32(q[i].y, qr, vo1, ro); }
                         }
                     }
                 }
@@ -343,6 +446,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
                     Us[(o * 2 + 1) * Uph + gl] = muv[1];
                 }
             }
+            VAEQ_STAMP(4);
             // exclusive prefix sums PSv[nu][n], n = 0..B  (VS[nu][j] = PSv[hi+1] - PSv[lo])
             {
                 float inc[2];
@@ -371,6 +475,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
             }
             sync_lds<NW>();
 
+            VAEQ_STAMP(5);
             // ============ P3: residual e = x - D for the quad t = 4l'..4l'+3, both chi.
             //   D[chi, 2 tau + par] = sum_nu sum_a h[chi,nu,2a+par] U[nu, tau + mh - a],   tau in {2l', 2l'+1}, a = 0..mh
             float se0 = 0.f, se1 = 0.f;
@@ -399,17 +504,25 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
 #pragma unroll
                             for (int i = 0; i < 4; i++) D[chi][i] = cacc0();
                     }
-#pragma unroll 1
-                    for (int b = 0; b < NB; b++) {             // d = mh - 2b: samples d+1, d, d-1
-                        constexpr int ph = mh & 1;             // phase of d (d and mh have equal parity)
+                    // stage b: a = 2b, 2b+1 (d = mh - 2b: samples d+1, d, d-1): 3 + 8 independent LDS reads feeding 32 packed FMAs
+                    constexpr int ph = mh & 1;                 // phase of d (d and mh have equal parity)
+                    auto load = [&](int b, v2f (&r)[11]) {
                         const int sl = (mh >> 1) - b;          // slot of d   (d >> 1)
-                        const v2f ud = lds2(up + ph * Uph + sl);
-                        const v2f udp = lds2(up + (ph ^ 1) * Uph + sl + ph);            // d + 1
-                        const v2f udm = lds2(up + (ph ^ 1) * Uph + sl + ph - 1);        // d - 1
-                        step_a(2 * b, ud, udp, std::false_type{});
-                        step_a(2 * b + 1, udm, ud, std::false_type{});
-                    }
+                        r[0] = lds2(up + ph * Uph + sl);                            // d
+                        r[1] = lds2(up + (ph ^ 1) * Uph + sl + ph);                 // d + 1
+                        r[2] = lds2(up + (ph ^ 1) * Uph + sl + ph - 1);             // d - 1
+#pragma unroll
+                        for (int t = 0; t < 4; t++) { r[3 + t] = lds2(h0 + 4 * b + t); r[7 + t] = lds2(h1 + 4 * b + t); }   // (e, o) of a = 2b, 2b+1
+                    };
+                    auto fma = [&](int, const v2f (&r)[11], auto) {
+                        cmac(D[0][0], r[3], r[0]); cmac(D[0][1], r[4], r[0]); cmac(D[0][2], r[3], r[1]); cmac(D[0][3], r[4], r[1]);
+                        cmac(D[1][0], r[7], r[0]); cmac(D[1][1], r[8], r[0]); cmac(D[1][2], r[7], r[1]); cmac(D[1][3], r[8], r[1]);
+                        cmac(D[0][0], r[5], r[2]); cmac(D[0][1], r[6], r[2]); cmac(D[0][2], r[5], r[0]); cmac(D[0][3], r[6], r[0]);
+                        cmac(D[1][0], r[9], r[2]); cmac(D[1][1], r[10], r[2]); cmac(D[1][2], r[9], r[0]); cmac(D[1][3], r[10], r[0]);
+                    };
+                    pipe2<11, false, PIPE>(NB, load, fma);
                 }
+                VAEQ_STAMP(6);
                 if (gl < nq) {
 #pragma unroll
                     for (int chi = 0; chi < 2; chi++)
@@ -468,6 +581,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
             }
             sync_lds<NW>();
 
+            VAEQ_STAMP(7);
             // ============ P4a: dL/dh partial sums, lane = (j = tk, half of the tau range); acc[chi][nu]
             step += 1;
             b1t *= 0.9;
@@ -481,30 +595,48 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
             float2 hacc[2];                                    // NW > 1: this wave's part of sum e conj(U) for (chi = half, nu)
             {
                 cacc ca[2][2];
-                ca[0][0] = ca[0][1] = ca[1][0] = ca[1][1] = cacc0();
-                if (worker) {
+                {
                     // sum over tau of e[chi, 2 tau + par] conj(U[nu, tau + mh - a]); tau runs in pairs (2m, 2m+1) so that the
                     // polyphase component of every operand is a per-lane constant and only the slot advances (by one per m).
                     // Past the last valid tau the residual cells are zero (pad), so the pair loop may overrun by one.
-                    const int par = tk & 1, aa = tk >> 1;
+                    // Lanes beyond the M taps shadow tap 0 (no divergence; their sums are never read).
+                    const int tkc = worker ? tk : 0, par = tkc & 1, aa = tkc >> 1;
                     const int T = (nm - par + 1) >> 1, Th = ((T + 2 * NP - 1) / (2 * NP)) << 1;   // even split points
                     const int ma = (part * Th) >> 1, mb = (min(T, part * Th + Th) + 1) >> 1;
                     const int ceA = par + Mh, ceB = par + Mh + 2, npA = mh - aa, npB = mh - aa + 1;
-                    const float2 *eA = Es + (ceA & 3) * Lph + (ceA >> 2), *eB = Es + (ceB & 3) * Lph + (ceB >> 2);
-                    const float2 *uA = Us + (npA & 1) * Uph + (npA >> 1), *uB = Us + (npB & 1) * Uph + (npB >> 1);
-#pragma unroll 2
-                    for (int m = ma; m < mb; m++) {
-                        const v2f e0 = lds2(eA + m), e1 = lds2(eA + 4 * Lph + m), u0 = lds2(uA + m), u1 = lds2(uA + 2 * Uph + m);
-                        const v2f f0 = lds2(eB + m), f1 = lds2(eB + 4 * Lph + m), w0 = lds2(uB + m), w1 = lds2(uB + 2 * Uph + m);
-                        cmac(ca[0][0], u0, e0);
-                        cmac(ca[0][1], u1, e0);
-                        cmac(ca[1][0], u0, e1);
-                        cmac(ca[1][1], u1, e1);
-                        cmac(ca[0][0], w0, f0);
-                        cmac(ca[0][1], w1, f0);
-                        cmac(ca[1][0], w0, f1);
-                        cmac(ca[1][1], w1, f1);
+                    const float2 *eA = Es + (ceA & 3) * Lph + (ceA >> 2) + ma, *eB = Es + (ceB & 3) * Lph + (ceB >> 2) + ma;
+                    const float2 *uA = Us + (npA & 1) * Uph + (npA >> 1) + ma, *uB = Us + (npB & 1) * Uph + (npB >> 1) + ma;
+                    // stage = two pairs (m = 2i, 2i+1): 16 independent LDS reads feeding 32 packed FMAs (a one-pair stage's 16 FMAs are too short
+                    // to cover the next stage's LDS latency); an odd last pair is handled after the pipeline
+                    auto load1 = [&](int m, v2f *r) {
+                        r[0] = lds2(eA + m); r[1] = lds2(eA + 4 * Lph + m); r[2] = lds2(uA + m); r[3] = lds2(uA + 2 * Uph + m);
+                        r[4] = lds2(eB + m); r[5] = lds2(eB + 4 * Lph + m); r[6] = lds2(uB + m); r[7] = lds2(uB + 2 * Uph + m);
+                    };
+                    cacc cb[2][2];                             // the odd tau of every pair sum here: 16 independent chains (see pair_fir)
+                    auto fma1 = [&](const v2f *r, auto first) {
+                        constexpr bool F = decltype(first)::value;
+                        cmacf<F>(ca[0][0], r[2], r[0]); cmacf<F>(ca[0][1], r[3], r[0]); cmacf<F>(ca[1][0], r[2], r[1]); cmacf<F>(ca[1][1], r[3], r[1]);
+                        cmacf<F>(cb[0][0], r[6], r[4]); cmacf<F>(cb[0][1], r[7], r[4]); cmacf<F>(cb[1][0], r[6], r[5]); cmacf<F>(cb[1][1], r[7], r[5]);
+                    };
+                    auto load = [&](int i, v2f (&r)[16]) { load1(2 * i, r); load1(2 * i + 1, r + 8); };
+                    auto fma = [&](int, const v2f (&r)[16], auto first) { fma1(r, first); fma1(r + 8, std::false_type{}); };
+                    int n = mb - ma;
+                    if constexpr (UNI) {                       // baked shape: every part has the same number (>= 2) of pairs
+                        n = __builtin_amdgcn_readfirstlane(n);
+                        pipe2<16, true, PIPE>(n >> 1, load, fma);
+                    } else {
+                        ca[0][0] = ca[0][1] = ca[1][0] = ca[1][1] = cb[0][0] = cb[0][1] = cb[1][0] = cb[1][1] = cacc0();
+                        pipe2<16, false, PIPE>(n >> 1, load, fma);
                     }
+                    if (n & 1) {
+                        v2f r[8];
+                        load1(n - 1, r);
+                        fma1(r, std::false_type{});
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; i++)
+#pragma unroll
+                        for (int j = 0; j < 2; j++) { ca[i][j].a += cb[i][j].a; ca[i][j].b += cb[i][j].b; }
                 }
                 float2 acc[2][2];
 #pragma unroll
@@ -540,8 +672,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
                         ghi[v] = g * (-2.0f * ac.y + 2.0f * hh.y * vs);
                         hnew[v] = hh;
                         if (!a.no_update) {
-                            adam_update_fast(hnew[v].x, mHr[v], vHr[v], ghr[v], ssH, bc2s);
-                            adam_update_fast(hnew[v].y, mHi[v], vHi[v], ghi[v], ssH, bc2s);
+                            adam_update_fast(hnew[v].x, mHr(v), vHr(v), ghr[v], ssH, bc2s);
+                            adam_update_fast(hnew[v].y, mHi(v), vHi(v), ghi[v], ssH, bc2s);
                         }
                     }
                 }
@@ -555,18 +687,18 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
                 const bool last_s = s + 1 == a.steps;
                 if (!(last_s && f + 1 == a.n_frames)) fetch(last_s ? f + 1 : f, last_s ? 0 : s + 1);
             }
+            VAEQ_STAMP(8);
             // ============ P4b: dL/dU for the lane's symbol pair (same shape as the FIR, on e with conj(h)), then dL/dy
             float2 gy[2][2];                                   // [sym][nu]
             {
                 float2 au0[2][2], au1[2][2];                   // chi = 0 / 1: [sym][nu]
                 {
-                    cacc c0[2][2], c1[2][2];
-                    pair_fir<M, true, true>(c0, Ea, Lph, nullptr, Ht + 0 * MP, Ht + 1 * MP);
-                    pair_fir<M, true, true>(c1, Ea + 4 * Lph, Lph, nullptr, Ht + 2 * MP, Ht + 3 * MP);
+                    cacc cu[2][2][2];                          // [chi][sym][nu]
+                    pair_du<M, PIPE_DU>(cu, Ea, Lph, Ht, MP);
 #pragma unroll
                     for (int sy = 0; sy < 2; sy++)
 #pragma unroll
-                        for (int v = 0; v < 2; v++) { au0[sy][v] = cfinc(c0[sy][v]); au1[sy][v] = cfinc(c1[sy][v]); }   // e * conj(h)
+                        for (int v = 0; v < 2; v++) { au0[sy][v] = cfinc(cu[0][sy][v]); au1[sy][v] = cfinc(cu[1][sy][v]); }   // e * conj(h)
                 }
 #pragma unroll
                 for (int sy = 0; sy < 2; sy++) {
@@ -583,6 +715,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
                     }
                 }
             }
+            VAEQ_STAMP(9);
             sync_lds<NW>();                                   // every read of U / old h is done (GY aliases U)
             if constexpr (NW > 1) {
                 if (owner) {
@@ -601,8 +734,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
                         ghi[v] = g * (-2.0f * ac.y + 2.0f * hh.y * vs);
                         hnew[v] = hh;
                         if (!a.no_update) {
-                            adam_update_fast(hnew[v].x, mHr[v], vHr[v], ghr[v], ssH, bc2s);
-                            adam_update_fast(hnew[v].y, mHi[v], vHi[v], ghi[v], ssH, bc2s);
+                            adam_update_fast(hnew[v].x, mHr(v), vHr(v), ghr[v], ssH, bc2s);
+                            adam_update_fast(hnew[v].y, mHi(v), vHi(v), ghi[v], ssH, bc2s);
                         }
                     }
                 }
@@ -620,31 +753,48 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
             }
             sync_lds<NW>();
 
+            VAEQ_STAMP(10);
             // ============ P5: dL/dw partial sums, lane = (k = tk, half of the symbol range); acc[o][p]
             float gwr[2] = {0, 0}, gwi[2] = {0, 0};
             {
                 cacc ca[2][2];
-                ca[0][0] = ca[0][1] = ca[1][0] = ca[1][1] = cacc0();
-                if (worker) {
+                {
                     // sum over n of gy[o, n] conj(x[p, 2n + k]); n runs in pairs (2m, 2m+1): x phase fixed per lane, gy pair = 16 bytes
+                    const int tkc = worker ? tk : 0;           // lanes beyond the M taps shadow tap 0
                     const int Bq = ((B + 2 * NP - 1) / (2 * NP)) << 1;                   // even split points (B is even)
                     const int ma = (part * Bq) >> 1, mb = min(B, part * Bq + Bq) >> 1;
-                    const int cA = tk, cB = tk + 2;
-                    const float2 *xA = Xs + (cA & 3) * Lph + (cA >> 2), *xB = Xs + (cB & 3) * Lph + (cB >> 2);
-                    const float2 *G0 = GY, *G1 = GY + B;
-#pragma unroll 2
-                    for (int m = ma; m < mb; m++) {
-                        const v2f ga = lds2(G0 + 2 * m), gc = lds2(G0 + 2 * m + 1), gb = lds2(G1 + 2 * m), gd = lds2(G1 + 2 * m + 1);   // gy[o][2m], gy[o][2m+1]
-                        const v2f x0 = lds2(xA + m), x1 = lds2(xA + 4 * Lph + m), z0 = lds2(xB + m), z1 = lds2(xB + 4 * Lph + m);
-                        cmac(ca[0][0], x0, ga);
-                        cmac(ca[0][1], x1, ga);
-                        cmac(ca[1][0], x0, gb);
-                        cmac(ca[1][1], x1, gb);
-                        cmac(ca[0][0], z0, gc);
-                        cmac(ca[0][1], z1, gc);
-                        cmac(ca[1][0], z0, gd);
-                        cmac(ca[1][1], z1, gd);
+                    const int cA = tkc, cB = tkc + 2;
+                    const float2 *xA = Xs + (cA & 3) * Lph + (cA >> 2) + ma, *xB = Xs + (cB & 3) * Lph + (cB >> 2) + ma;
+                    const float2 *G0 = GY + 2 * ma, *G1 = GY + B + 2 * ma;
+                    auto load1 = [&](int m, v2f *r) {
+                        r[0] = lds2(G0 + 2 * m); r[1] = lds2(G0 + 2 * m + 1); r[2] = lds2(G1 + 2 * m); r[3] = lds2(G1 + 2 * m + 1);   // gy[o][2m], gy[o][2m+1]
+                        r[4] = lds2(xA + m); r[5] = lds2(xA + 4 * Lph + m); r[6] = lds2(xB + m); r[7] = lds2(xB + 4 * Lph + m);
+                    };
+                    cacc cb[2][2];                             // the odd symbols of every pair sum here: 16 independent chains
+                    auto fma1 = [&](const v2f *r, auto first) {
+                        constexpr bool F = decltype(first)::value;
+                        cmacf<F>(ca[0][0], r[4], r[0]); cmacf<F>(ca[0][1], r[5], r[0]); cmacf<F>(ca[1][0], r[4], r[2]); cmacf<F>(ca[1][1], r[5], r[2]);
+                        cmacf<F>(cb[0][0], r[6], r[1]); cmacf<F>(cb[0][1], r[7], r[1]); cmacf<F>(cb[1][0], r[6], r[3]); cmacf<F>(cb[1][1], r[7], r[3]);
+                    };
+                    auto load = [&](int i, v2f (&r)[16]) { load1(2 * i, r); load1(2 * i + 1, r + 8); };       // stage = two symbol pairs (see dL/dh)
+                    auto fma = [&](int, const v2f (&r)[16], auto first) { fma1(r, first); fma1(r + 8, std::false_type{}); };
+                    int n = mb - ma;
+                    if constexpr (UNI) {
+                        n = __builtin_amdgcn_readfirstlane(n);
+                        pipe2<16, true, PIPE>(n >> 1, load, fma);
+                    } else {
+                        ca[0][0] = ca[0][1] = ca[1][0] = ca[1][1] = cb[0][0] = cb[0][1] = cb[1][0] = cb[1][1] = cacc0();
+                        pipe2<16, false, PIPE>(n >> 1, load, fma);
                     }
+                    if (n & 1) {
+                        v2f r[8];
+                        load1(n - 1, r);
+                        fma1(r, std::false_type{});
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; i++)
+#pragma unroll
+                        for (int j = 0; j < 2; j++) { ca[i][j].a += cb[i][j].a; ca[i][j].b += cb[i][j].b; }
                 }
                 float2 acc[2][2];
 #pragma unroll
@@ -685,8 +835,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
                         if (!a.no_update) {
                             float *wq = reinterpret_cast<float *>(&Wt[p * M + tk]) + half * 2;
                             float wr = wq[0], wi = wq[1];
-                            adam_update_fast(wr, mWr[p], vWr[p], gwr[p], ssW, bc2s);
-                            adam_update_fast(wi, mWi[p], vWi[p], gwi[p], ssW, bc2s);
+                            adam_update_fast(wr, mWr(p), vWr(p), gwr[p], ssW, bc2s);
+                            adam_update_fast(wi, mWi(p), vWi(p), gwi[p], ssW, bc2s);
                             wq[0] = wr;
                             wq[1] = wi;
                         }
@@ -703,8 +853,13 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
                 }
             }
             sync_lds<NW>();
+            VAEQ_STAMP(11);
         }
     }
+#ifdef VAEQ_PHASE_STAMPS
+    if (gl == 0 && run == (int)gridDim.x / 2 && a.loss)
+        for (int i = 0; i + 1 < VAEQ_NSTAMP; i++) a.loss[i] = (float)(tst[i + 1] - tst[i]);
+#endif
 
     // ---- state out
     if (owner && !a.no_update) {
@@ -713,16 +868,24 @@ __global__ __launch_bounds__(64 * NW, 2) void dp_wave_kernel(const vaeq_dp_args 
             const size_t ir = gbase + (half * 4 + p) * M + tk, ii = gbase + (half * 4 + 2 + p) * M + tk;
             const float *wq = reinterpret_cast<const float *>(&Wt[p * M + tk]) + half * 2;
             a.W[ir] = wq[0]; a.W[ii] = wq[1];
-            a.adam_mW[ir] = mWr[p]; a.adam_mW[ii] = mWi[p];
-            a.adam_vW[ir] = vWr[p]; a.adam_vW[ii] = vWi[p];
+            a.adam_mW[ir] = mWr(p); a.adam_mW[ii] = mWi(p);
+            a.adam_vW[ir] = vWr(p); a.adam_vW[ii] = vWi(p);
             const size_t hr = gbase + ((half * 2 + p) * 2 + 0) * M + tk, hi = hr + M;
             const float2 hh = Ht[(half * 2 + p) * MP + tk];
             a.h[hr] = hh.x; a.h[hi] = hh.y;
-            a.adam_mh[hr] = mHr[p]; a.adam_mh[hi] = mHi[p];
-            a.adam_vh[hr] = vHr[p]; a.adam_vh[hi] = vHi[p];
+            a.adam_mh[hr] = mHr(p); a.adam_mh[hi] = mHi(p);
+            a.adam_vh[hr] = vHr(p); a.adam_vh[hi] = vHi(p);
         }
     }
     if (gl == 0 && !a.no_update) a.step[run] = step;
+#undef mWr
+#undef mWi
+#undef vWr
+#undef vWi
+#undef mHr
+#undef mHi
+#undef vHr
+#undef vHi
 }
 
 

@@ -1,6 +1,8 @@
 // vaeq_wave.h -- building blocks shared by the wave-per-run kernels (vaeq_dp_wave.hip, vaeq_awgn_wave.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
 
 namespace vaeq {
 
@@ -77,6 +79,73 @@ typedef const volatile __attribute__((address_space(3))) v2f lds_cv2f;
 __device__ __forceinline__ v2f lds2(const float2 *p) { return *(lds_cv2f *)p; }
 __device__ __forceinline__ v2f lds2(const float *p) { return *(lds_cv2f *)p; }
 __device__ __forceinline__ float2 f2(v2f v) { return make_float2(v.x, v.y); }
+
+// Buffer addressing for the streamed rows: address = base (4 SGPRs, one descriptor per array and frame) + a per-lane byte offset (VGPR) + a
+// per-row byte offset (SGPR, folded into the instruction): NO vector ALU work per store / load, no 64-bit row pointers to keep (or spill) in
+// scalar registers.  A lane that must not store / load passes OOB as its offset: the access is dropped by the range check (loads return 0).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);   // raw buffer, gfx9 dword 3
+}
+__device__ __forceinline__ void bst64(v2f v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void bst32(float v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void bst16(unsigned short v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b16(v, r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void bst8(unsigned char v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b8(v, r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ float4 bld128(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return __builtin_bit_cast(float4, v);
+}
+
+// Two-deep software pipeline over n >= 1 stages: load(i, r) issues stage i's NR independent 8-byte LDS reads, fma(i, r, first) consumes them.
+// Stage i + 1 is in flight while stage i computes (register sets A / B alternate, no copies), so a wave hides its own LDS latency instead of
+// relying on the one other wave of its SIMD to be in an FMA burst at that moment.  Loads run up to two stages past the end (never consumed):
+// the caller's load(i) must stay inside the LDS allocation for i < n + 2 -- that keeps the loop body free of conditional loads.
+// PIPE = false: plain loop (load, compute, load, compute ...) for phases that cannot spare the second register set.
+template <int NR, bool INIT, bool PIPE = true, class L, class F>
+__device__ __forceinline__ void pipe2(int n, L load, F fma)
+{
+    if (!INIT && n <= 0) return;                       // (INIT: the caller guarantees n >= 1, stage 0 starts the accumulators)
+    if constexpr (!PIPE) {
+        v2f A[NR];
+        load(0, A);
+        fma(0, A, std::integral_constant<bool, INIT>{});
+#pragma unroll 1
+        for (int i = 1; i < n; i++) {
+            load(i, A);
+            fma(i, A, std::false_type{});
+        }
+        return;
+    }
+    v2f A[NR], B[NR];
+    load(0, A);
+    load(1, B);
+    fma(0, A, std::integral_constant<bool, INIT>{});
+    int i = 1;
+#pragma unroll 1
+    for (; i + 1 < n; i += 2) {                        // B holds stage i
+        load(i + 1, A);
+        fma(i, B, std::false_type{});
+        load(i + 2, B);
+        fma(i + 1, A, std::false_type{});
+    }
+    if (i < n) fma(i, B, std::false_type{});
+}
 
 __device__ __forceinline__ float2 cfin(const cacc &c) { return make_float2(c.a.x - c.b.y, c.a.y + c.b.x); }    // sum t * v
 __device__ __forceinline__ float2 cfinc(const cacc &c) { return make_float2(c.a.x + c.b.y, c.a.y - c.b.x); }   // sum v * conj(t)
