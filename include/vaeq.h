@@ -242,7 +242,10 @@ int vaeq_gen_dp_finish(int32_t R, int32_t N, int32_t sps, int32_t Ls, int32_t Lr
                        const float *sig_complex, float *power_ws, float *rx, float *sigma_out, void *stream);
 
 /* The three stages and both transforms of one DP frame in ONE call (hipFFT in place on sig_ws[R][2][Lrow] complex64, plans cached
- * per (Lrow, R)); same arguments as the stage entry points, e_k = exp(-j phiIQ[k]), fs = symb_rate * sps. */
+ * per (Lrow, R)); same arguments as the stage entry points, e_k = exp(-j phiIQ[k]), fs = symb_rate * sps.
+ * power_ws: [R][2 * ceil(Lrow / 2048)] floats -- for sps == 2 stage 1 leaves its tiles' sums of |sig|^2 there and the noise level (:83) is derived
+ * from them: the fibre's transfer matrix is unitary at every frequency (:38-54), the dispersed signal has the power of the undispersed one,
+ * so no pass over the dispersed signal is spent on it (other sps: the first R floats, filled by a power pass as in vaeq_gen_dp_finish). */
 int vaeq_gen_dp_frame(int32_t R, int32_t N, int32_t N_conv, int32_t sps, int32_t n_lev, int32_t Lg, int32_t Ls, int32_t Lrow,
                       int32_t ref_offset, const float *amp, const float *cdf, const float *g_complex, const float *snr_db,
                       const float *theta, double fs, double tau_cd, double tau_pmd, float e0_re, float e0_im, float e1_re, float e1_im,

@@ -31,7 +31,8 @@ def test_bench_line_contract():
     assert p["ok"] and p["elbo_rel_max"] <= p["tol"] == 1e-5 and p["taps_abs_max"] <= 1e-5 and p["ser_abs_max"] <= 2e-3 and p["runs"] >= 8 and p["steps"] == 10
     rf = d["roofline"]
     assert rf["kernel"] == "vaeq::dp_wave_kernel<25, 8, 100, true, 1, 1>"          # what vaeq_dp_train launched, not a literal in bench.py
-    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / 8000.0) < 1e-12 and rf["kernel_ms"] <= d["ms_per_step"] * 1.001
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / 8000.0) < 1e-12 and rf["kernel_ms_median"] <= d["ms_per_step"] * 1.001
+    assert rf["kernel_ms_minmax"][0] <= rf["kernel_ms_median"] <= rf["kernel_ms"] * 1.2 and rf["kernel_ms"] <= rf["kernel_ms_minmax"][1]
     assert abs(rf["achieved"] - 176 * 512 * 10000 / (rf["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
     assert 0 < rf["flop_frac"] < 1 and abs(rf["flop_frac"] - 5043.0 * 512 * 10000 / (rf["kernel_ms"] * 1e-3) / 157.3e12) < 1e-9
     assert 2000 < rf["peak_measured_copy"] < 8000 and rf["frac_of_measured_copy"] > rf["frac"]

@@ -33,7 +33,7 @@ for k in sorted(m): print(f"{k:28s} n={len(acc[k])} mean={m[k]:.4g}")
 ws = m.get("SQ_WAVES", 0) * $STEPS
 if ws:
     g = lambda k: m.get(k, float("nan"))
-    print(f"# derived: per wave-step ({g('SQ_WAVES'):.0f} waves x $STEPS steps): VALU {g('SQ_INSTS_VALU') / ws:.0f} instr (trans {g('SQ_INSTS_VALU_TRANS') / ws:.0f}), SALU {g('SQ_INSTS_SALU') / ws:.0f}, "
+    print(f"# derived: per wave-step ({g('SQ_WAVES'):.0f} waves x $STEPS steps): VALU {g('SQ_INSTS_VALU') / ws:.0f} instr, SALU {g('SQ_INSTS_SALU') / ws:.0f}, "
           f"LDS {g('SQ_INSTS_LDS') / ws:.0f} instr = {g('SQ_LDS_IDX_ACTIVE') / ws:.0f} LDS cycles, VMEM wr {g('SQ_INSTS_VMEM_WR') / ws:.1f} rd {g('SQ_INSTS_VMEM_RD') / ws:.1f}")
     print(f"# derived: VALU active / wave cycles {g('SQ_ACTIVE_INST_VALU') / g('SQ_WAVE_CYCLES'):.3f} (x waves per SIMD = SIMD VALU busy); waves waiting (s_waitcnt) {g('SQ_WAIT_ANY') / g('SQ_WAVE_CYCLES'):.3f}, "
           f"issue-stalled {g('SQ_WAIT_INST_ANY') / g('SQ_WAVE_CYCLES'):.3f}; LDS bank conflicts / LDS cycles {g('SQ_LDS_BANK_CONFLICT') / g('SQ_LDS_IDX_ACTIVE'):.3f}")

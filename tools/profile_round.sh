@@ -6,7 +6,7 @@
 OUT=/root/repo/gpurun_out/${1:-prof_round}
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 /root/repo/bench.py --steps 5 --warmup 1 --min-seconds 0 --no-parity --no-extras --no-cpu-baseline > $OUT/bench.log 2>&1 || { echo bench failed; tail -5 $OUT/bench.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 /root/repo/bench.py --steps 20 --warmup 2 --min-seconds 0 --no-parity --no-extras --no-cpu-baseline > $OUT/bench.log 2>&1 || { echo bench failed; tail -5 $OUT/bench.log; exit 1; }
 tail -1 $OUT/bench.log
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/awgn -o awgn -- python3 /root/repo/tools/probe_awgn_pipeline.py 8192 > $OUT/awgn.log 2>&1 || { echo awgn failed; tail -5 $OUT/awgn.log; exit 1; }
 grep "R=" $OUT/awgn.log

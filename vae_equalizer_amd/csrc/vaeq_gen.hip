@@ -65,7 +65,10 @@ constexpr int TX_TILE = 2048, TX_NT = 256, TX_MAXG = 96, TX_SYMPH = (TX_TILE / 2
 // (4-way polyphase) and -- for the symbols the tile owns -- written out as the TX reference data[r][p][c][n - ref_lo] (fp16).
 // Thread t computes the 8 consecutive samples 8t..8t+7: per symbol one LDS read feeds 8 complex MACs; the taps g[kb-6 .. kb+7] of
 // four consecutive symbols come from 14 broadcast reads.
-// MODE 0: write sig (the DP path: the FFT needs it).  Single-polarisation path without any sig round trip through HBM:
+// MODE 0: write sig (the DP path: the FFT needs it); with fz.part != NULL also the tile's sum |sig|^2 -> part[run][pol][tile]: the fibre's
+//         transfer matrix is unitary at every frequency (shared_funcs.py:38-54: rotations, PMD and CD phases), so the mean power the noise level is
+//         derived from after the dispersion (:83) IS the power before it -- no extra pass over the dispersed signal.
+//         Single-polarisation path without any sig round trip through HBM:
 // MODE 1: only the tile's sum |sig|^2 -> part[run][tile] (fixed-order block reduction);
 // MODE 2: sigma from the tile sums (or sigma_fixed), noise added in registers (same Philox words as gen_finish_kernel), planar rx out.
 struct TxFuse {
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(TX_NT) void gen_tx_kernel(int N_conv, int n_lev, in
     }
     __syncthreads();
     const int sb = s0 + 8 * tid;
-    if (MODE == 0 && sb >= Lrow) return;
+    if (MODE == 0 && sb >= Lrow && !fz.part) return;
     cacc acc[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) acc[i] = cacc0();
@@ -136,14 +139,22 @@ __global__ __launch_bounds__(TX_NT) void gen_tx_kernel(int N_conv, int n_lev, in
             for (int i = 0; i < 8; i++) cmac(acc[i], tp[6 - 2 * mm + i].x, tp[6 - 2 * mm + i].y, sv);
         }
     }
+    __shared__ float red[64];
     if (MODE == 0) {
         float2 *o = sig + ((size_t)run * npol + pol) * Lrow + sb;
+        float pw = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; i++)
-            if (sb + i < Lrow) o[i] = sb + i < Ls ? cfin(acc[i]) : make_float2(0.f, 0.f);
+        for (int i = 0; i < 8; i++) {
+            const float2 v = sb + i < Ls ? cfin(acc[i]) : make_float2(0.f, 0.f);
+            if (sb + i < Lrow) o[i] = v;
+            pw += v.x * v.x + v.y * v.y;
+        }
+        if (fz.part) {                                         // fixed-order block sum: bitwise reproducible
+            block_reduce3<TX_NT>(pw, 0.f, 0.f, red);
+            if (tid == 0) fz.part[((size_t)run * npol + pol) * gridDim.x + blockIdx.x] = red[0];
+        }
         return;
     }
-    __shared__ float red[64];
     if (MODE == 1) {
         float pw = 0.f;
 #pragma unroll
@@ -269,13 +280,22 @@ __global__ __launch_bounds__(256) void gen_power_kernel(int Ls, int Lrow, int np
 
 // stage 3b: AWGN + planar split: rx[r][p][0/1][s] = Re/Im(sig + sigma_n (n1 + j n2)), s < Lout = sps*N (even)   (:84-88)
 // one Philox call -> two Box-Muller pairs -> the noise of two consecutive samples
+// n_parts == 0: power[run] = the mean power (gen_power_kernel); n_parts > 0: power[run][n_parts] = partial sums of |sig|^2 from stage 1 over
+// all polarisations and tiles (summed here in a fixed order), Ls samples per polarisation
 __global__ __launch_bounds__(256) void gen_finish_kernel(int Lrow, int Lout, int sps, const float *__restrict__ snr_db, const float *__restrict__ power,
                                                          uint64_t seed, uint32_t frame, int npol, const float2 *__restrict__ sig,
                                                          float *__restrict__ rx, float *__restrict__ sigma_out,
-                                                         const float *__restrict__ sigma_fixed)
+                                                         const float *__restrict__ sigma_fixed, int n_parts, int Ls)
 {
     const int run = blockIdx.z, pol = blockIdx.y;
-    const float sigma = sigma_fixed ? sigma_fixed[run] : sqrtf(power[run] * (float)sps * 0.5f / exp10f(snr_db[run] * 0.1f));
+    float pmean = 0.f;
+    if (!sigma_fixed) {
+        if (n_parts > 0) {
+            for (int t = 0; t < n_parts; t++) pmean += power[(size_t)run * n_parts + t];
+            pmean /= (float)(npol * Ls);
+        } else pmean = power[run];
+    }
+    const float sigma = sigma_fixed ? sigma_fixed[run] : sqrtf(pmean * (float)sps * 0.5f / exp10f(snr_db[run] * 0.1f));
     if (sigma_out && pol == 0 && blockIdx.x == 0 && threadIdx.x == 0) sigma_out[run] = sigma;
     const float2 *s = sig + ((size_t)run * npol + pol) * Lrow;
     float *rI = rx + ((size_t)(run * npol + pol) * 2 + 0) * Lout, *rQ = rI + Lout;
@@ -296,12 +316,16 @@ __global__ __launch_bounds__(256) void gen_finish_kernel(int Lrow, int Lout, int
 }
 
 // launches of stage 1 / stage 3 shared by the DP and the AWGN entry points
+// power_parts (sps == 2 only, nullable): [R][npol][ceil(Lrow / TX_TILE)] partial sums of |sig|^2 written by stage 1
 static void launch_tx(int R, int npol, int N, int N_conv, int sps, int n_lev, int Lg, int Ls, int Lrow, int ref_offset, const float *amp,
-                      const float *cdf, const float2 *g, uint64_t seed, uint32_t frame, float2 *sig, __half *data, hipStream_t st)
+                      const float *cdf, const float2 *g, uint64_t seed, uint32_t frame, float2 *sig, __half *data, hipStream_t st,
+                      float *power_parts = nullptr)
 {
     if (sps == 2) {
+        TxFuse fz{};
+        fz.part = power_parts;
         hipLaunchKernelGGL(gen_tx_kernel<0>, dim3((Lrow + TX_TILE - 1) / TX_TILE, npol, R), dim3(TX_NT), 0, st, N_conv, n_lev, Lg, Ls, Lrow, amp, cdf,
-                           g, seed, frame, npol, sig, N, ref_offset, data, TxFuse{});
+                           g, seed, frame, npol, sig, N, ref_offset, data, fz);
         return;
     }
     hipLaunchKernelGGL(gen_tx_generic_kernel, dim3((Lrow + 255) / 256 > 64 ? 64 : (Lrow + 255) / 256, npol, R), dim3(256), 0, st, N_conv, sps, n_lev,
@@ -312,12 +336,13 @@ static void launch_tx(int R, int npol, int N, int N_conv, int sps, int n_lev, in
 }
 
 static void launch_finish(int R, int npol, int N, int sps, int Ls, int Lrow, const float *snr_db, uint64_t seed, uint32_t frame,
-                          const float2 *sig, float *power_ws, float *rx, float *sigma_out, hipStream_t st, const float *sigma_fixed = nullptr)
+                          const float2 *sig, float *power_ws, float *rx, float *sigma_out, hipStream_t st, const float *sigma_fixed = nullptr,
+                          int n_parts = 0)
 {
     const int Lout = sps * N, nj = (Lout + 1) / 2;
-    if (!sigma_fixed) hipLaunchKernelGGL(gen_power_kernel, dim3(R), dim3(256), 0, st, Ls, Lrow, npol, sig, power_ws);
+    if (!sigma_fixed && n_parts == 0) hipLaunchKernelGGL(gen_power_kernel, dim3(R), dim3(256), 0, st, Ls, Lrow, npol, sig, power_ws);
     hipLaunchKernelGGL(gen_finish_kernel, dim3((nj + 255) / 256 > 64 ? 64 : (nj + 255) / 256, npol, R), dim3(256), 0, st, Lrow, Lout, sps, snr_db,
-                       power_ws, seed, frame, npol, sig, rx, sigma_out, sigma_fixed);
+                       power_ws, seed, frame, npol, sig, rx, sigma_out, sigma_fixed, n_parts, Ls);
 }
 
 }  // namespace vaeq
@@ -430,14 +455,16 @@ extern "C" int vaeq_gen_dp_frame(int32_t R, int32_t N, int32_t N_conv, int32_t s
     const int rc = vaeq::get_plan(Lrow, 2 * R, &plan);
     if (rc != VAEQ_OK) return rc;
     if (hipfftSetStream(plan, st) != HIPFFT_SUCCESS) return VAEQ_ERR_DEVICE;
+    // sps == 2: stage 1 also leaves the tiles' sums of |sig|^2 in power_ws (the dispersion is unitary: no power pass after it)
+    const int n_parts = sps == 2 ? 2 * ((Lrow + vaeq::TX_TILE - 1) / vaeq::TX_TILE) : 0;
     vaeq::launch_tx(R, 2, N, N_conv, sps, n_lev, Lg, Ls, Lrow, ref_offset, amp, cdf, reinterpret_cast<const float2 *>(g_complex), seed, frame, sig,
-                    reinterpret_cast<__half *>(data_f16), st);
+                    reinterpret_cast<__half *>(data_f16), st, n_parts ? power_ws : nullptr);
     if (hipfftExecC2C(plan, reinterpret_cast<hipfftComplex *>(sig), reinterpret_cast<hipfftComplex *>(sig), HIPFFT_FORWARD) != HIPFFT_SUCCESS)
         return VAEQ_ERR_LAUNCH;
     hipLaunchKernelGGL(vaeq::gen_disperse_kernel, dim3((Lrow + 255) / 256, R), dim3(256), 0, st, Lrow, fs / (double)Lrow, tau_cd, tau_pmd,
                        make_float2(e0_re, e0_im), make_float2(e1_re, e1_im), 1.0f / (float)Lrow, theta, sig);
     if (hipfftExecC2C(plan, reinterpret_cast<hipfftComplex *>(sig), reinterpret_cast<hipfftComplex *>(sig), HIPFFT_BACKWARD) != HIPFFT_SUCCESS)
         return VAEQ_ERR_LAUNCH;
-    vaeq::launch_finish(R, 2, N, sps, Ls, Lrow, snr_db, seed, frame, sig, power_ws, rx, sigma_out, st);
+    vaeq::launch_finish(R, 2, N, sps, Ls, Lrow, snr_db, seed, frame, sig, power_ws, rx, sigma_out, st, nullptr, n_parts);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
