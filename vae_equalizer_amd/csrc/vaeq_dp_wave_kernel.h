@@ -82,9 +82,11 @@ __host__ __device__ inline WaveLayout wave_layout(int B, int M, int NW = 1)
 // tools/ubench/coissue.hip), and with 2 waves per SIMD a wave is often alone in its FMA burst -- so every convolution-shaped phase keeps 16
 // independent chains: here the even taps accumulate into acc, the odd taps into acc2 (the caller adds them once at the end).
 // INIT: the first taps start the accumulators (no zeroing); else they are added to.
-template <int M, bool INIT, bool PIPE = true>
-__device__ __forceinline__ void pair_fir(cacc (&acc)[2][2], cacc (&acc2)[2][2], const float2 *xp, int Lph, const float4 *wq)
+// SPLIT = false (shapes not baked into the kernel, where run-time strides already cost registers): all taps into acc, acc2 untouched.
+template <int M, bool INIT, bool PIPE = true, bool SPLIT = true>
+__device__ __forceinline__ void pair_fir(cacc (&acc)[2][2], cacc (&accx)[2][2], const float2 *xp, int Lph, const float4 *wq)
 {
+    cacc (&acc2)[2][2] = SPLIT ? accx : acc;
     auto tapA = [&](int k) -> v2f { return lds2(reinterpret_cast<const float2 *>(wq + k)); };       // (re, im) of o = 0
     auto tapB = [&](int k) -> v2f { return lds2(reinterpret_cast<const float2 *>(wq + k) + 1); };   // (re, im) of o = 1
     constexpr int G = M / 4;
@@ -98,7 +100,8 @@ __device__ __forceinline__ void pair_fir(cacc (&acc)[2][2], cacc (&acc2)[2][2], 
     auto fma = [&](int, const v2f (&r)[14], auto first) {
         constexpr bool F = decltype(first)::value;     // the very first taps start the accumulators (cmul): nothing to zero
         cmacf<F>(acc[0][0], r[6], r[0]); cmacf<F>(acc[0][1], r[7], r[0]); cmacf<F>(acc[1][0], r[6], r[2]); cmacf<F>(acc[1][1], r[7], r[2]);
-        cmacf<F>(acc2[0][0], r[8], r[1]); cmacf<F>(acc2[0][1], r[9], r[1]); cmacf<F>(acc2[1][0], r[8], r[3]); cmacf<F>(acc2[1][1], r[9], r[3]);
+        cmacf<F && SPLIT>(acc2[0][0], r[8], r[1]); cmacf<F && SPLIT>(acc2[0][1], r[9], r[1]);
+        cmacf<F && SPLIT>(acc2[1][0], r[8], r[3]); cmacf<F && SPLIT>(acc2[1][1], r[9], r[3]);
         cmac(acc[0][0], r[10], r[2]); cmac(acc[0][1], r[11], r[2]); cmac(acc[1][0], r[10], r[4]); cmac(acc[1][1], r[11], r[4]);
         cmac(acc2[0][0], r[12], r[3]); cmac(acc2[0][1], r[13], r[3]); cmac(acc2[1][0], r[12], r[5]); cmac(acc2[1][1], r[13], r[5]);
     };
@@ -115,38 +118,42 @@ __device__ __forceinline__ void pair_fir(cacc (&acc)[2][2], cacc (&acc2)[2][2], 
 // dL/dU for the lane's symbol pair: the FIR's shape on the residual e with conjugated channel taps, acc[chi][sym][nu] += e[chi] * conj(h[chi][nu]),
 // BOTH chi in one loop (16 independent accumulator chains, see pair_fir).  ep = phase-0 pointer of the lane into e[chi = 0] (chi = 1: + 4 Lph);
 // ht[chi * 2 + nu] = the tap rows (float2, MP apart).  Runs at the kernel's register peak (the demapper's moments are live): one operand set.
-template <int M, bool PIPE = false>
+template <int M, bool PIPE = false, bool MERGE = true>
 __device__ __forceinline__ void pair_du(cacc (&acc)[2][2][2], const float2 *ep, int Lph, const float2 *ht, int MP)
 {
     constexpr int G = M / 4;
-    // stage g: taps 4g..4g+3 of the 4 rows, samples c' = 4g..4g+5 of both chi -- 28 independent LDS reads feeding 64 packed FMAs
-    auto load = [&](int g, v2f (&r)[28]) {
+    // operands of one chi for taps 4g..4g+3: 6 samples c' = 4g..4g+5 and the 4 taps of the rows nu = 0, 1 -- 14 independent LDS reads, 32 packed FMAs
+    auto load1 = [&](int chi, int g, v2f *x) {
+        const float2 *xg = ep + chi * 4 * Lph + g;
+        x[0] = lds2(xg); x[1] = lds2(xg + Lph); x[2] = lds2(xg + 2 * Lph); x[3] = lds2(xg + 3 * Lph); x[4] = lds2(xg + 1); x[5] = lds2(xg + Lph + 1);
 #pragma unroll
-        for (int chi = 0; chi < 2; chi++) {
-            const float2 *xg = ep + chi * 4 * Lph + g;
-            v2f *x = r + chi * 14;
-            x[0] = lds2(xg); x[1] = lds2(xg + Lph); x[2] = lds2(xg + 2 * Lph); x[3] = lds2(xg + 3 * Lph); x[4] = lds2(xg + 1); x[5] = lds2(xg + Lph + 1);
-#pragma unroll
-            for (int t = 0; t < 4; t++) { x[6 + 2 * t] = lds2(ht + (chi * 2 + 0) * MP + 4 * g + t); x[7 + 2 * t] = lds2(ht + (chi * 2 + 1) * MP + 4 * g + t); }
-        }
+        for (int t = 0; t < 4; t++) { x[6 + 2 * t] = lds2(ht + (chi * 2 + 0) * MP + 4 * g + t); x[7 + 2 * t] = lds2(ht + (chi * 2 + 1) * MP + 4 * g + t); }
     };
-    auto fma = [&](int, const v2f (&r)[28], auto first) {
+    auto fma1 = [&](int chi, const v2f *x, int t, auto first) {                // tap 4g + t of both rows on both symbols
         constexpr bool F = decltype(first)::value;
+        cmacf<F>(acc[chi][0][0], x[6 + 2 * t], x[t]); cmacf<F>(acc[chi][0][1], x[7 + 2 * t], x[t]);
+        cmacf<F>(acc[chi][1][0], x[6 + 2 * t], x[t + 2]); cmacf<F>(acc[chi][1][1], x[7 + 2 * t], x[t + 2]);
+    };
+    if constexpr (MERGE) {                             // both chi per stage: 28 reads feeding 64 FMAs on 16 chains
+        auto load = [&](int g, v2f (&r)[28]) { load1(0, g, r); load1(1, g, r + 14); };
+        auto fma = [&](int, const v2f (&r)[28], auto first) {
+            fma1(0, r, 0, first); fma1(1, r + 14, 0, first);
+#pragma unroll
+            for (int t = 1; t < 4; t++) { fma1(0, r, t, std::false_type{}); fma1(1, r + 14, t, std::false_type{}); }
+        };
+        pipe2<28, true, PIPE>(G, load, fma);
+    } else {                                           // one chi after the other (half the operand registers)
 #pragma unroll
         for (int chi = 0; chi < 2; chi++) {
-            const v2f *x = r + chi * 14;
-            cmacf<F>(acc[chi][0][0], x[6], x[0]); cmacf<F>(acc[chi][0][1], x[7], x[0]); cmacf<F>(acc[chi][1][0], x[6], x[2]); cmacf<F>(acc[chi][1][1], x[7], x[2]);
+            auto load = [&](int g, v2f (&r)[14]) { load1(chi, g, r); };
+            auto fma = [&](int, const v2f (&r)[14], auto first) {
+                fma1(chi, r, 0, first);
+#pragma unroll
+                for (int t = 1; t < 4; t++) fma1(chi, r, t, std::false_type{});
+            };
+            pipe2<14, true, PIPE>(G, load, fma);
         }
-#pragma unroll
-        for (int t = 1; t < 4; t++)
-#pragma unroll
-            for (int chi = 0; chi < 2; chi++) {
-                const v2f *x = r + chi * 14;
-                cmac(acc[chi][0][0], x[6 + 2 * t], x[t]); cmac(acc[chi][0][1], x[7 + 2 * t], x[t]);
-                cmac(acc[chi][1][0], x[6 + 2 * t], x[t + 2]); cmac(acc[chi][1][1], x[7 + 2 * t], x[t + 2]);
-            }
-    };
-    pipe2<28, true, PIPE>(G, load, fma);
+    }
 #pragma unroll
     for (int k = 4 * G; k < M; k++)                    // remaining 1 or 3 taps
 #pragma unroll
@@ -203,7 +210,8 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
 #ifndef VAEQ_PIPE
 #define VAEQ_PIPE 1
 #endif
-    constexpr bool PIPE = VAEQ_PIPE;
+    constexpr bool PIPE = VAEQ_PIPE && BT > 0;             // run-time minibatch lengths keep more addresses live: there one operand set,
+    constexpr bool WIDE = BT > 0;                          // ... 8 accumulator chains and one chi at a time in dL/dU (fits the register file)
     constexpr bool PIPE_DU = VAEQ_PIPE_DU;                 // dL/dU runs at the kernel's register peak (moments of the demapper still live): no second operand set there
     const int B = BT ? BT : a.B;
     const int L = 2 * B, nm = L - Mh, P2 = B / 2;
@@ -282,8 +290,8 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
     const bool ldl = gl < L / 4;
     float4 pf[4];
     const uint32_t S4 = (uint32_t)a.S * 4u;                    // bytes per received row; a frame of a run = 4 rows
-    auto fetch = [&](int f, int s) {
-        const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.rx + ((size_t)run * a.n_frames + f) * 4 * (size_t)a.S, 4u * S4);
+    auto frame_rsrc = [&](int f) { return make_rsrc(a.rx + ((size_t)run * a.n_frames + f) * 4 * (size_t)a.S, 4u * S4); };
+    auto fetch = [&](const __amdgpu_buffer_rsrc_t xr, int s) {
         const uint32_t vo = ldl ? ((uint32_t)s * (uint32_t)a.stride_sym * 2u + 4u * gl) * 4u : OOB;   // lanes beyond the window read zeros
 #pragma unroll
         for (int r = 0; r < 4; r++) pf[r] = bld128(xr, vo, (uint32_t)r * S4);
@@ -291,8 +299,9 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
 #ifdef VAEQ_PHASE_STAMPS
     long long tst[VAEQ_NSTAMP];
 #endif
-    fetch(0, 0);
+    fetch(frame_rsrc(0), 0);
     for (int f = 0; f < a.n_frames; f++) {
+        const __amdgpu_buffer_rsrc_t xr = frame_rsrc(f), xn = frame_rsrc(f + 1 < a.n_frames ? f + 1 : f);   // this frame's rows, the next frame's
         // one buffer descriptor per output array and frame; rows are addressed by scalar offsets (row * No4) folded into the stores
         const bool qf = OUT != 2 && a.q_out, yf = a.y_out, ef = OUT != 1 && a.eq_out, df = OUT != 1 && a.dec_out;
         const uint32_t No4 = (uint32_t)No * 4u;
@@ -324,14 +333,16 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
             float2 y[2][2];                                    // [sym][o]
             {
                 cacc ya[2][2], yb[2][2];                       // lanes without a symbol pair recompute lane 0's (Xa): no divergence, nothing to zero
-                pair_fir<M, true, PIPE>(ya, yb, Xa, Lph, Wt);
-                pair_fir<M, false, PIPE>(ya, yb, Xa + 4 * Lph, Lph, Wt + M);
+                pair_fir<M, true, PIPE, WIDE>(ya, yb, Xa, Lph, Wt);
+                pair_fir<M, false, PIPE, WIDE>(ya, yb, Xa + 4 * Lph, Lph, Wt + M);
 #pragma unroll
                 for (int sy = 0; sy < 2; sy++)
 #pragma unroll
                     for (int o = 0; o < 2; o++) {
-                        ya[sy][o].a += yb[sy][o].a;
-                        ya[sy][o].b += yb[sy][o].b;
+                        if constexpr (WIDE) {
+                            ya[sy][o].a += yb[sy][o].a;
+                            ya[sy][o].b += yb[sy][o].b;
+                        }
                         y[sy][o] = cfin(ya[sy][o]);
                     }
             }
@@ -612,11 +623,12 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                         r[0] = lds2(eA + m); r[1] = lds2(eA + 4 * Lph + m); r[2] = lds2(uA + m); r[3] = lds2(uA + 2 * Uph + m);
                         r[4] = lds2(eB + m); r[5] = lds2(eB + 4 * Lph + m); r[6] = lds2(uB + m); r[7] = lds2(uB + 2 * Uph + m);
                     };
-                    cacc cb[2][2];                             // the odd tau of every pair sum here: 16 independent chains (see pair_fir)
+                    cacc cbx[2][2];                            // the odd tau of every pair sum here: 16 independent chains (see pair_fir) (WIDE)
+                    cacc (&cb)[2][2] = WIDE ? cbx : ca;
                     auto fma1 = [&](const v2f *r, auto first) {
                         constexpr bool F = decltype(first)::value;
                         cmacf<F>(ca[0][0], r[2], r[0]); cmacf<F>(ca[0][1], r[3], r[0]); cmacf<F>(ca[1][0], r[2], r[1]); cmacf<F>(ca[1][1], r[3], r[1]);
-                        cmacf<F>(cb[0][0], r[6], r[4]); cmacf<F>(cb[0][1], r[7], r[4]); cmacf<F>(cb[1][0], r[6], r[5]); cmacf<F>(cb[1][1], r[7], r[5]);
+                        cmacf<F && WIDE>(cb[0][0], r[6], r[4]); cmacf<F && WIDE>(cb[0][1], r[7], r[4]); cmacf<F && WIDE>(cb[1][0], r[6], r[5]); cmacf<F && WIDE>(cb[1][1], r[7], r[5]);
                     };
                     auto load = [&](int i, v2f (&r)[16]) { load1(2 * i, r); load1(2 * i + 1, r + 8); };
                     auto fma = [&](int, const v2f (&r)[16], auto first) { fma1(r, first); fma1(r + 8, std::false_type{}); };
@@ -625,7 +637,7 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                         n = __builtin_amdgcn_readfirstlane(n);
                         pipe2<16, true, PIPE>(n >> 1, load, fma);
                     } else {
-                        ca[0][0] = ca[0][1] = ca[1][0] = ca[1][1] = cb[0][0] = cb[0][1] = cb[1][0] = cb[1][1] = cacc0();
+                        ca[0][0] = ca[0][1] = ca[1][0] = ca[1][1] = cbx[0][0] = cbx[0][1] = cbx[1][0] = cbx[1][1] = cacc0();
                         pipe2<16, false, PIPE>(n >> 1, load, fma);
                     }
                     if (n & 1) {
@@ -633,10 +645,12 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                         load1(n - 1, r);
                         fma1(r, std::false_type{});
                     }
+                    if constexpr (WIDE) {
 #pragma unroll
-                    for (int i = 0; i < 2; i++)
+                        for (int i = 0; i < 2; i++)
 #pragma unroll
-                        for (int j = 0; j < 2; j++) { ca[i][j].a += cb[i][j].a; ca[i][j].b += cb[i][j].b; }
+                            for (int j = 0; j < 2; j++) { ca[i][j].a += cbx[i][j].a; ca[i][j].b += cbx[i][j].b; }
+                    }
                 }
                 float2 acc[2][2];
 #pragma unroll
@@ -685,7 +699,7 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
             // for these loads at the top of the next step does not also wait for fresh stores (vmcnt retires in order)
             {
                 const bool last_s = s + 1 == a.steps;
-                if (!(last_s && f + 1 == a.n_frames)) fetch(last_s ? f + 1 : f, last_s ? 0 : s + 1);
+                if (!(last_s && f + 1 == a.n_frames)) fetch(last_s ? xn : xr, last_s ? 0 : s + 1);
             }
             VAEQ_STAMP(8);
             // ============ P4b: dL/dU for the lane's symbol pair (same shape as the FIR, on e with conj(h)), then dL/dy
@@ -694,7 +708,7 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                 float2 au0[2][2], au1[2][2];                   // chi = 0 / 1: [sym][nu]
                 {
                     cacc cu[2][2][2];                          // [chi][sym][nu]
-                    pair_du<M, PIPE_DU>(cu, Ea, Lph, Ht, MP);
+                    pair_du<M, PIPE_DU, WIDE>(cu, Ea, Lph, Ht, MP);
 #pragma unroll
                     for (int sy = 0; sy < 2; sy++)
 #pragma unroll
@@ -770,11 +784,12 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                         r[0] = lds2(G0 + 2 * m); r[1] = lds2(G0 + 2 * m + 1); r[2] = lds2(G1 + 2 * m); r[3] = lds2(G1 + 2 * m + 1);   // gy[o][2m], gy[o][2m+1]
                         r[4] = lds2(xA + m); r[5] = lds2(xA + 4 * Lph + m); r[6] = lds2(xB + m); r[7] = lds2(xB + 4 * Lph + m);
                     };
-                    cacc cb[2][2];                             // the odd symbols of every pair sum here: 16 independent chains
+                    cacc cbx[2][2];                            // the odd symbols of every pair sum here: 16 independent chains (WIDE)
+                    cacc (&cb)[2][2] = WIDE ? cbx : ca;
                     auto fma1 = [&](const v2f *r, auto first) {
                         constexpr bool F = decltype(first)::value;
                         cmacf<F>(ca[0][0], r[4], r[0]); cmacf<F>(ca[0][1], r[5], r[0]); cmacf<F>(ca[1][0], r[4], r[2]); cmacf<F>(ca[1][1], r[5], r[2]);
-                        cmacf<F>(cb[0][0], r[6], r[1]); cmacf<F>(cb[0][1], r[7], r[1]); cmacf<F>(cb[1][0], r[6], r[3]); cmacf<F>(cb[1][1], r[7], r[3]);
+                        cmacf<F && WIDE>(cb[0][0], r[6], r[1]); cmacf<F && WIDE>(cb[0][1], r[7], r[1]); cmacf<F && WIDE>(cb[1][0], r[6], r[3]); cmacf<F && WIDE>(cb[1][1], r[7], r[3]);
                     };
                     auto load = [&](int i, v2f (&r)[16]) { load1(2 * i, r); load1(2 * i + 1, r + 8); };       // stage = two symbol pairs (see dL/dh)
                     auto fma = [&](int, const v2f (&r)[16], auto first) { fma1(r, first); fma1(r + 8, std::false_type{}); };
@@ -783,7 +798,7 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                         n = __builtin_amdgcn_readfirstlane(n);
                         pipe2<16, true, PIPE>(n >> 1, load, fma);
                     } else {
-                        ca[0][0] = ca[0][1] = ca[1][0] = ca[1][1] = cb[0][0] = cb[0][1] = cb[1][0] = cb[1][1] = cacc0();
+                        ca[0][0] = ca[0][1] = ca[1][0] = ca[1][1] = cbx[0][0] = cbx[0][1] = cbx[1][0] = cbx[1][1] = cacc0();
                         pipe2<16, false, PIPE>(n >> 1, load, fma);
                     }
                     if (n & 1) {
@@ -791,10 +806,12 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                         load1(n - 1, r);
                         fma1(r, std::false_type{});
                     }
+                    if constexpr (WIDE) {
 #pragma unroll
-                    for (int i = 0; i < 2; i++)
+                        for (int i = 0; i < 2; i++)
 #pragma unroll
-                        for (int j = 0; j < 2; j++) { ca[i][j].a += cb[i][j].a; ca[i][j].b += cb[i][j].b; }
+                            for (int j = 0; j < 2; j++) { ca[i][j].a += cbx[i][j].a; ca[i][j].b += cbx[i][j].b; }
+                    }
                 }
                 float2 acc[2][2];
 #pragma unroll

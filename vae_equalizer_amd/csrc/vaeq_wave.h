@@ -147,8 +147,22 @@ __device__ __forceinline__ void pipe2(int n, L load, F fma)
     if (i < n) fma(i, B, std::false_type{});
 }
 
-__device__ __forceinline__ float2 cfin(const cacc &c) { return make_float2(c.a.x - c.b.y, c.a.y + c.b.x); }    // sum t * v
-__device__ __forceinline__ float2 cfinc(const cacc &c) { return make_float2(c.a.x + c.b.y, c.a.y - c.b.x); }   // sum v * conj(t)
+// Final combine of the two packed partial sums, ONE v_pk_add_f32 each: the swap of b's halves and the sign ride on op_sel / neg (the backend
+// does not find this form: it shuffles the halves with v_mov and adds them as scalars).
+__device__ __forceinline__ v2f cfin2(const cacc &c)                                    // sum t * v = (a.x - b.y, a.y + b.x)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(c.a), "v"(c.b));
+    return r;
+}
+__device__ __forceinline__ v2f cfinc2(const cacc &c)                                   // sum v * conj(t) = (a.x + b.y, a.y - b.x)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(c.a), "v"(c.b));
+    return r;
+}
+__device__ __forceinline__ float2 cfin(const cacc &c) { const v2f r = cfin2(c); return make_float2(r.x, r.y); }
+__device__ __forceinline__ float2 cfinc(const cacc &c) { const v2f r = cfinc2(c); return make_float2(r.x, r.y); }
 
 __device__ __forceinline__ float wave_incl_scan(float v, int lane)                    // inclusive prefix sum over lanes
 {
