@@ -18,3 +18,6 @@ names = ["P0 window->LDS", "P1 FIR", "P1 y stores", "P2 demap + q stores", "P2 s
 for n, v in zip(names, t):
     print(f"{n:20s} {v:9.0f} cycles  {100 * v / t.sum():5.1f} %")
 print("sum", t.sum(), "cycles per step")
+x = out["loss"].reshape(-1)[16:23].cpu().numpy()
+for n, v in zip(["dh: tap loop", "dh: combine + cross-half shuffle", "dh: Adam(h) + window prefetch issue", "(dU .. gy -> LDS)", "dw: tap loop", "dw: combine + cross-half shuffle", "dw: Adam(w)"], x):
+    print(f"   {n:40s} {v:9.0f} cycles")

@@ -36,8 +36,10 @@
 // (tools/probe_dp_phases.py reads them; the build is for that probe only: tools/snap_variant.sh stamps -DVAEQ_PHASE_STAMPS).
 #ifdef VAEQ_PHASE_STAMPS
 #define VAEQ_STAMP(i) do { if (s == a.steps - 1) tst[i] = __builtin_readcyclecounter(); } while (0)
+#define VAEQ_XSTAMP(i) do { if (s == a.steps - 1) tsx[i] = __builtin_readcyclecounter(); } while (0)   // inside the two tap-gradient phases
 #else
 #define VAEQ_STAMP(i) do { } while (0)
+#define VAEQ_XSTAMP(i) do { } while (0)
 #endif
 #define VAEQ_NSTAMP 12
 #ifndef VAEQ_WPS
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
     constexpr bool PIPE_DU = VAEQ_PIPE_DU;                 // dL/dU runs at the kernel's register peak (moments of the demapper still live): no second operand set there
     const int B = BT ? BT : a.B;
     const int L = 2 * B, nm = L - Mh, P2 = B / 2;
+    const float rnm = 1.0f / (float)nm;
     const WaveLayout lay = wave_layout(B, M, NW);
     const int Lph = lay.Lph, Uph = lay.Uph;
     float2 *Xs = reinterpret_cast<float2 *>(sm + lay.X), *Es = reinterpret_cast<float2 *>(sm + lay.E);
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
         for (int r = 0; r < 4; r++) pf[r] = bld128(xr, vo, (uint32_t)r * S4);
     };
 #ifdef VAEQ_PHASE_STAMPS
-    long long tst[VAEQ_NSTAMP];
+    long long tst[VAEQ_NSTAMP], tsx[8];
 #endif
     fetch(frame_rsrc(0), 0);
     for (int f = 0; f < a.n_frames; f++) {
@@ -310,6 +313,8 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
         const __amdgpu_buffer_rsrc_t yr = make_rsrc(yf ? a.y_out + fr * 4 * No : nullptr, yf ? 4u * No4 : 0u);
         const __amdgpu_buffer_rsrc_t er = make_rsrc(ef ? a.eq_out + fr * 2 * No : nullptr, ef ? 2u * No4 : 0u);
         const __amdgpu_buffer_rsrc_t dr = make_rsrc(df ? a.dec_out + fr * 4 * No : nullptr, df ? (uint32_t)(4 * No) : 0u);
+        const __amdgpu_buffer_rsrc_t lr_ = make_rsrc(a.loss ? a.loss + fr * a.steps : nullptr, a.loss ? (uint32_t)a.steps * 4u : 0u);
+        const __amdgpu_buffer_rsrc_t vr_ = make_rsrc(a.var_est ? a.var_est + fr * 2 * a.steps : nullptr, a.var_est ? (uint32_t)a.steps * 8u : 0u);
 #pragma unroll 1
         for (int s = 0; s < a.steps; s++) {
             VAEQ_STAMP(0);
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
             {
                 float inc[2];
 #pragma unroll
-                for (int o = 0; o < 2; o++) inc[o] = wave_incl_scan(vv[o][0] + vv[o][1], lane);
+                for (int o = 0; o < 2; o++) inc[o] = wave_incl_scan_dpp(vv[o][0] + vv[o][1]);
                 if constexpr (NW > 1) {                        // add the totals of the waves below (fixed order)
                     if (lane == 63) { RED[wv] = inc[0]; RED[NW + wv] = inc[1]; }
                     sync_lds<NW>();
@@ -490,6 +495,14 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
             // ============ P3: residual e = x - D for the quad t = 4l'..4l'+3, both chi.
             //   D[chi, 2 tau + par] = sum_nu sum_a h[chi,nu,2a+par] U[nu, tau + mh - a],   tau in {2l', 2l'+1}, a = 0..mh
             float se0 = 0.f, se1 = 0.f;
+            // |h|^2 and VS of this lane's (j, nu) for C and the G_V prefix sums: read now, so that their LDS latency hides behind the D loop
+            float hq0 = 0.f, hq1 = 0.f;
+            if (worker) {
+                const float2 h0 = Ht[(0 * 2 + half) * MP + tk], h1 = Ht[(1 * 2 + half) * MP + tk];
+                hq0 = h0.x * h0.x + h0.y * h0.y;
+                hq1 = h1.x * h1.x + h1.y * h1.y;
+            }
+            const float vsl = worker ? VS[half * M + tk] : 0.f;
             {
                 cacc D[2][4];                                  // [chi][i], i = 2*dl + par; lanes without a quad shadow lane 0 (no divergence, unused)
                 constexpr int NA = mh + 1, NB = NA / 2;        // a = 0..mh; pairs (2b, 2b+1)
@@ -550,9 +563,9 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                         }
                 }
             }
-            se0 = wave_sum(se0);
-            se1 = wave_sum(se1);
-            klsum = wave_sum(klsum);
+            se0 = wave_sum_dpp(se0);
+            se1 = wave_sum_dpp(se1);
+            klsum = wave_sum_dpp(klsum);
             if constexpr (NW > 1) {                            // totals over the run's waves, same order in every wave
                 if (lane == 0) { RED[16 + wv] = se0; RED[16 + NW + wv] = se1; RED[16 + 2 * NW + wv] = klsum; }
                 sync_lds<NW>();
@@ -560,33 +573,22 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
 #pragma unroll
                 for (int w = 1; w < NW; w++) { se0 += RED[16 + w]; se1 += RED[16 + NW + w]; klsum += RED[16 + 2 * NW + w]; }
             }
-            // C[chi] = sum|e|^2 + sum_{nu,j} |h|^2 VS   (lanes (j, nu) hold one term each for both chi)
-            float hq0 = 0.f, hq1 = 0.f;
-            if (worker) {
-                const float2 h0 = Ht[(0 * 2 + half) * MP + tk], h1 = Ht[(1 * 2 + half) * MP + tk];
-                hq0 = h0.x * h0.x + h0.y * h0.y;
-                hq1 = h1.x * h1.x + h1.y * h1.y;
-            }
-            const float vsl = worker ? VS[half * M + tk] : 0.f;
-            const float C0 = se0 + wave_sum(hq0 * vsl), C1 = se1 + wave_sum(hq1 * vsl);
-            const float gC0 = (float)nm / C0, gC1 = (float)nm / C1;
-            if (gl == 0) {
-                const size_t li = ((size_t)run * a.n_frames + f) * a.steps + s;
-                if (a.loss) a.loss[li] = (float)nm * (logf(C0) + logf(C1)) + klsum;
+            // C[chi] = sum|e|^2 + sum_{nu,j} |h|^2 VS   (lanes (j, nu) hold one term each for both chi; hq, vsl were read before the D loop)
+            const float C0 = se0 + wave_sum_dpp(hq0 * vsl), C1 = se1 + wave_sum_dpp(hq1 * vsl);
+            // C is uniform: hardware reciprocal / log2 (1 ulp: 6e-8 on the gradients' common scale, 1e-7 relative on the ELBO) instead of the IEEE
+            // division and logf expansions (~60 instructions per step that every lane would execute for lane 0's two stores)
+            const float gC0 = (float)nm * __builtin_amdgcn_rcpf(C0), gC1 = (float)nm * __builtin_amdgcn_rcpf(C1);
+            {
+                const uint32_t vo = gl == 0 ? 0u : OOB;        // lane 0 stores; row offsets ride in the scalar offset
+                if (a.loss) bst32((float)nm * LN2 * (__builtin_amdgcn_logf(C0) + __builtin_amdgcn_logf(C1)) + klsum, lr_, vo, (uint32_t)s * 4u);
                 if (a.var_est) {
-                    const size_t vi = ((size_t)run * a.n_frames + f) * 2 * a.steps + s;
-                    a.var_est[vi] = C0 / (float)nm;
-                    a.var_est[vi + a.steps] = C1 / (float)nm;
+                    bst32(C0 * rnm, vr_, vo, (uint32_t)s * 4u);
+                    bst32(C1 * rnm, vr_, vo, ((uint32_t)a.steps + (uint32_t)s) * 4u);
                 }
             }
             // prefix sums over j of H2[nu][j] = sum_chi gC[chi] |h[chi,nu,j]|^2  -> G_V by two lookups per symbol
             {
-                float inc = gC0 * hq0 + gC1 * hq1;             // inclusive scan within each 32-lane half
-#pragma unroll
-                for (int d = 1; d < 32; d <<= 1) {
-                    const float t = __shfl_up(inc, d, 32);
-                    if (tk >= d) inc += t;
-                }
+                const float inc = half_incl_scan_dpp(gC0 * hq0 + gC1 * hq1);   // inclusive scan within each 32-lane half
                 if (owner) PSh[half * MP + tk + 1] = inc;
                 if (tk == 0) PSh[half * MP] = 0.f;
             }
@@ -605,6 +607,17 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
             float ghr[2] = {0, 0}, ghi[2] = {0, 0};
             float2 hacc[2];                                    // NW > 1: this wave's part of sum e conj(U) for (chi = half, nu)
             {
+                // what the owner lane's Adam(h) update reads of the taps and VS is fetched from LDS BEFORE the tap loop, so that the
+                // update after the loop starts with fewer exposed LDS round trips (wave 0 only)
+                float2 ph_h[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+                float ph_vs[2] = {0.f, 0.f};                   // (the moments stay in LDS until the update: this phase cannot spare eight more registers)
+                if (NW == 1 && owner) {
+#pragma unroll
+                    for (int v = 0; v < 2; v++) {
+                        ph_h[v] = Ht[(half * 2 + v) * MP + tk];
+                        ph_vs[v] = VS[v * M + tk];
+                    }
+                }
                 cacc ca[2][2];
                 {
                     // sum over tau of e[chi, 2 tau + par] conj(U[nu, tau + mh - a]); tau runs in pairs (2m, 2m+1) so that the
@@ -633,6 +646,7 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                     auto load = [&](int i, v2f (&r)[16]) { load1(2 * i, r); load1(2 * i + 1, r + 8); };
                     auto fma = [&](int, const v2f (&r)[16], auto first) { fma1(r, first); fma1(r + 8, std::false_type{}); };
                     int n = mb - ma;
+                    VAEQ_XSTAMP(0);
                     if constexpr (UNI) {                       // baked shape: every part has the same number (>= 2) of pairs
                         n = __builtin_amdgcn_readfirstlane(n);
                         pipe2<16, true, PIPE>(n >> 1, load, fma);
@@ -652,6 +666,7 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                             for (int j = 0; j < 2; j++) { ca[i][j].a += cbx[i][j].a; ca[i][j].b += cbx[i][j].b; }
                     }
                 }
+                VAEQ_XSTAMP(1);
                 float2 acc[2][2];
 #pragma unroll
                 for (int chi = 0; chi < 2; chi++)
@@ -675,13 +690,14 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                         }
                     }
                 }
+                VAEQ_XSTAMP(2);
                 if (NW == 1 && owner) {
                     const float g = half ? gC1 : gC0;
 #pragma unroll
                     for (int v = 0; v < 2; v++) {
                         const float2 ac = half ? acc[1][v] : acc[0][v];
-                        const float2 hh = Ht[(half * 2 + v) * MP + tk];
-                        const float vs = VS[v * M + tk];
+                        const float2 hh = ph_h[v];
+                        const float vs = ph_vs[v];
                         ghr[v] = g * (-2.0f * ac.x + 2.0f * hh.x * vs);
                         ghi[v] = g * (-2.0f * ac.y + 2.0f * hh.y * vs);
                         hnew[v] = hh;
@@ -701,6 +717,7 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                 const bool last_s = s + 1 == a.steps;
                 if (!(last_s && f + 1 == a.n_frames)) fetch(last_s ? xn : xr, last_s ? 0 : s + 1);
             }
+            VAEQ_XSTAMP(3);
             VAEQ_STAMP(8);
             // ============ P4b: dL/dU for the lane's symbol pair (same shape as the FIR, on e with conj(h)), then dL/dy
             float2 gy[2][2];                                   // [sym][nu]
@@ -771,6 +788,16 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
             // ============ P5: dL/dw partial sums, lane = (k = tk, half of the symbol range); acc[o][p]
             float gwr[2] = {0, 0}, gwi[2] = {0, 0};
             {
+                float pw_w[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, pw_m[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, pw_v[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // as for Adam(h)
+                if (owner) {
+#pragma unroll
+                    for (int p = 0; p < 2; p++) {
+                        const float *wq = reinterpret_cast<const float *>(&Wt[p * M + tk]) + half * 2;
+                        pw_w[p][0] = wq[0]; pw_w[p][1] = wq[1];
+                        pw_m[p][0] = mWr(p); pw_m[p][1] = mWi(p);
+                        pw_v[p][0] = vWr(p); pw_v[p][1] = vWi(p);
+                    }
+                }
                 cacc ca[2][2];
                 {
                     // sum over n of gy[o, n] conj(x[p, 2n + k]); n runs in pairs (2m, 2m+1): x phase fixed per lane, gy pair = 16 bytes
@@ -794,6 +821,7 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                     auto load = [&](int i, v2f (&r)[16]) { load1(2 * i, r); load1(2 * i + 1, r + 8); };       // stage = two symbol pairs (see dL/dh)
                     auto fma = [&](int, const v2f (&r)[16], auto first) { fma1(r, first); fma1(r + 8, std::false_type{}); };
                     int n = mb - ma;
+                    VAEQ_XSTAMP(4);
                     if constexpr (UNI) {
                         n = __builtin_amdgcn_readfirstlane(n);
                         pipe2<16, true, PIPE>(n >> 1, load, fma);
@@ -813,6 +841,7 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                             for (int j = 0; j < 2; j++) { ca[i][j].a += cbx[i][j].a; ca[i][j].b += cbx[i][j].b; }
                     }
                 }
+                VAEQ_XSTAMP(5);
                 float2 acc[2][2];
 #pragma unroll
                 for (int o = 0; o < 2; o++)
@@ -836,6 +865,7 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                     }
                     sync_lds<NW>();
                 }
+                VAEQ_XSTAMP(6);
                 if (owner) {
 #pragma unroll
                     for (int p = 0; p < 2; p++) {
@@ -851,11 +881,13 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                         gwi[p] = ac.y;
                         if (!a.no_update) {
                             float *wq = reinterpret_cast<float *>(&Wt[p * M + tk]) + half * 2;
-                            float wr = wq[0], wi = wq[1];
-                            adam_update_fast(wr, mWr(p), vWr(p), gwr[p], ssW, bc2s);
-                            adam_update_fast(wi, mWi(p), vWi(p), gwi[p], ssW, bc2s);
+                            float wr = pw_w[p][0], wi = pw_w[p][1];
+                            adam_update_fast(wr, pw_m[p][0], pw_v[p][0], gwr[p], ssW, bc2s);
+                            adam_update_fast(wi, pw_m[p][1], pw_v[p][1], gwi[p], ssW, bc2s);
                             wq[0] = wr;
                             wq[1] = wi;
+                            mWr(p) = pw_m[p][0]; mWi(p) = pw_m[p][1];
+                            vWr(p) = pw_v[p][0]; vWi(p) = pw_v[p][1];
                         }
                     }
                 }
@@ -870,12 +902,15 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                 }
             }
             sync_lds<NW>();
+            VAEQ_XSTAMP(7);
             VAEQ_STAMP(11);
         }
     }
 #ifdef VAEQ_PHASE_STAMPS
     if (gl == 0 && run == (int)gridDim.x / 2 && a.loss)
         for (int i = 0; i + 1 < VAEQ_NSTAMP; i++) a.loss[i] = (float)(tst[i + 1] - tst[i]);
+    if (gl == 0 && run == (int)gridDim.x / 2 && a.loss)
+        for (int i = 0; i < 7; i++) a.loss[16 + i] = (float)(tsx[i + 1] - tsx[i]);
 #endif
 
     // ---- state out

@@ -164,6 +164,46 @@ __device__ __forceinline__ v2f cfinc2(const cacc &c)                            
 __device__ __forceinline__ float2 cfin(const cacc &c) { const v2f r = cfin2(c); return make_float2(r.x, r.y); }
 __device__ __forceinline__ float2 cfinc(const cacc &c) { const v2f r = cfinc2(c); return make_float2(r.x, r.y); }
 
+// Cross-lane sums on the vector ALU (DPP), no LDS round trips: a ds_bpermute butterfly costs six dependent LDS latencies (~100 cycles each under
+// load) during which the wave issues nothing; the DP kernel has five such sums and three scans per step.  Fixed order => bitwise reproducible.
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float v)           // lanes the masks switch off (or whose source lies outside the row) contribute 0
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v)    // sum over the 64 lanes, result in every lane (uniform)
+{
+    v += dpp_f<0xB1>(v);                                   // quad_perm:[1,0,3,2]
+    v += dpp_f<0x4E>(v);                                   // quad_perm:[2,3,0,1]
+    v += dpp_f<0x141>(v);                                  // row_half_mirror
+    v += dpp_f<0x140>(v);                                  // row_mirror: every lane of a 16-lane row holds the row's sum
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ float row_incl_scan_dpp(float v)   // inclusive prefix sum inside each 16-lane row
+{
+    float s = v + dpp_f<0x111>(v);                         // row_shr:1
+    s += dpp_f<0x112>(v);                                  // row_shr:2
+    s += dpp_f<0x113>(v);                                  // row_shr:3   -> sums of (up to) 4
+    s += dpp_f<0x114, 0xF, 0xE>(s);                        // row_shr:4 into banks 1..3
+    s += dpp_f<0x118, 0xF, 0xC>(s);                        // row_shr:8 into banks 2, 3
+    return s;
+}
+__device__ __forceinline__ float half_incl_scan_dpp(float v)  // inclusive prefix sum inside each 32-lane half
+{
+    float s = row_incl_scan_dpp(v);
+    s += dpp_f<0x142, 0xA>(s);                             // row_bcast:15 into rows 1 and 3
+    return s;
+}
+__device__ __forceinline__ float wave_incl_scan_dpp(float v)  // inclusive prefix sum over the 64 lanes
+{
+    float s = half_incl_scan_dpp(v);
+    s += dpp_f<0x143, 0xC>(s);                             // row_bcast:31 into rows 2 and 3
+    return s;
+}
+
 __device__ __forceinline__ float wave_incl_scan(float v, int lane)                    // inclusive prefix sum over lanes
 {
 #pragma unroll
