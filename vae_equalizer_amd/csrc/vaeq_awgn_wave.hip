@@ -22,7 +22,7 @@ namespace vaeq {
 
 struct AwgnWaveLayout {
     int Lph, Uph;
-    int X, E, U, PSv, W, H, PSh, VS, RED, XG, total;   // byte offsets (the dL/dy buffer aliases U)
+    int X, E, U, PSv, W, H, PSh, VS, XP, RED, XG, total;   // byte offsets (the dL/dy buffer aliases U)
 };
 
 __host__ __device__ inline AwgnWaveLayout awgn_wave_layout(int B, int M, int NW = 1)
@@ -41,6 +41,7 @@ __host__ __device__ inline AwgnWaveLayout awgn_wave_layout(int B, int M, int NW 
     l.H = take((M + 1) * 8);                           // one zero pad tap: j = M
     l.PSh = take((M + 1) * 4);
     l.VS = take(M * 4);
+    l.XP = take(NW == 1 ? 256 * 8 : 0);               // NW == 1: partial tap-gradient sums [group][tap in group][part] (complex): 4 per lane
     l.RED = take(NW > 1 ? 64 * 4 : 0);                 // NW > 1: cross-wave sums and scan offsets
     l.XG = take((NW - 1) * 2 * 64 * 4);                // ... and the tap-gradient partial sums of waves 1..NW-1
     l.total = o;
@@ -76,6 +77,18 @@ __device__ __forceinline__ void wave_fir(cacc (&acc)[NR][2], const float2 *(&xp)
     }
 }
 
+// Blocked tap-gradient sums of the single-wave kernel (NW == 1).  A lane = (group of 4 taps, part of the sum range): per pair of terms it
+// reads 7 (dL/dh) / 8 (dL/dw) operands for 8 complex MACs -- the (tap, half) mapping of the DP kernel feeds ONE MAC per operand pair here
+// (one polarisation), i.e. one LDS read per packed FMA and 4 x the loop trips.  NG groups x PARTS parts <= 64 lanes; trip counts are uniform
+// (a scalar loop), terms past the end of a part's range are masked.  The partial sums go through LDS (XP); the tap's owner lane adds its
+// PARTS partials in a fixed order: bitwise reproducible.
+template <int M> struct TapBlocks {
+    static constexpr int mh = M / 2;
+    static constexpr int NG0 = (mh + 1 + 3) / 4, NG1 = (mh + 3) / 4;     // dL/dh: groups of even taps (a = 0..mh) / odd taps (a = 0..mh-1)
+    static constexpr int NGH = NG0 + NG1, PH = 64 / NGH;                 // parts per group
+    static constexpr int NGW = (M + 3) / 4, PW = 64 / NGW;               // dL/dw: groups of 4 consecutive taps
+};
+
 __device__ __forceinline__ void amsgrad_fast(float &p, float &m, float &v, float &vmax, float g, float step_size, float rbc2s)
 {
     m = fmaf(g - m, 0.1f, m);
@@ -98,6 +111,7 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
     const int l0 = lane + 64 * NR * wv;                       // first pair of this lane
     constexpr int NT = 64 * NW, NP = 2 * NW;
     const int B = a.B, L = 2 * B, nm = L - Mh, P2 = B / 2, nq = (nm + 3) / 4;
+    const float rB = 1.0f / (float)B;
     const AwgnWaveLayout lay = awgn_wave_layout(B, M, NW);
     const int Lph = lay.Lph, Uph = lay.Uph;
     float2 *Xs = reinterpret_cast<float2 *>(sm + lay.X), *Es = reinterpret_cast<float2 *>(sm + lay.E);
@@ -213,10 +227,11 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
                 *reinterpret_cast<float2 *>(rI + No) = make_float2(y[r][0].y, y[r][1].y);
             }
         }
-        float sav[2] = {wave_sum(sa0), wave_sum(sa1)};
+        float sav[2] = {wave_sum_dpp(sa0), wave_sum_dpp(sa1)};     // DPP sums / scans: no LDS round trips (see vaeq_wave.h)
         waves_sum<NW, 2>(sav, RED, lane, wv);
-        const float m0 = sav[0] / (float)B, m1 = sav[1] / (float)B;
-        const float sc0 = A / m0, sc1 = A / m1;
+        // uniform scalars: hardware reciprocals (1 ulp) instead of IEEE division sequences executed by every lane
+        const float m0 = sav[0] * rB, m1 = sav[1] * rB;
+        const float sc0 = A * __builtin_amdgcn_rcpf(m0), sc1 = A * __builtin_amdgcn_rcpf(m1);
 
         // ============ P2: soft demap + moments (registers), mu -> LDS, prefix sums of the variances
         float mv[NR][2][2], mt3[NR][2][2], mkc[NR][2][2];      // [round][sym][c]
@@ -289,8 +304,8 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
             float carry = 0.f, inc[NR];
 #pragma unroll
             for (int r = 0; r < NR; r++) {
-                inc[r] = wave_incl_scan(vv[r][0] + vv[r][1], lane) + carry;
-                carry = __shfl(inc[r], 63, 64);
+                inc[r] = wave_incl_scan_dpp(vv[r][0] + vv[r][1]) + carry;
+                carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inc[r]), 63));
             }
             float base = 0.f;
             if constexpr (NW > 1) {                            // totals of the waves below (fixed order)
@@ -364,7 +379,7 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
                 }
         }
         {
-            float sk[2] = {wave_sum(se), wave_sum(klsum)};
+            float sk[2] = {wave_sum_dpp(se), wave_sum_dpp(klsum)};
             waves_sum<NW, 2>(sk, RED + 16, lane, wv);
             se = sk[0]; klsum = sk[1];
         }
@@ -374,16 +389,11 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
             hq = hc.x * hc.x + hc.y * hc.y;
         }
         const float vsl = worker ? VS[tk] : 0.f;
-        const float C = se + wave_sum(half ? 0.f : hq * vsl);
-        const float gC = (float)nm / C;
-        if (gl == 0 && a.loss) a.loss[(size_t)run * a.steps + s] = (float)nm * logf(C) + klsum;
+        const float C = se + wave_sum_dpp(half ? 0.f : hq * vsl);
+        const float gC = (float)nm * __builtin_amdgcn_rcpf(C);
+        if (gl == 0 && a.loss) a.loss[(size_t)run * a.steps + s] = (float)nm * LN2 * __builtin_amdgcn_logf(C) + klsum;
         {
-            float inc = gC * hq;                               // inclusive scan within each 32-lane half
-#pragma unroll
-            for (int d = 1; d < 32; d <<= 1) {
-                const float t = __shfl_up(inc, d, 32);
-                if (tk >= d) inc += t;
-            }
+            const float inc = half_incl_scan_dpp(gC * hq);     // inclusive scan within each 32-lane half
             if (wown) PSh[tk + 1] = inc;
             if (gl == 0) PSh[0] = 0.f;
         }
@@ -398,24 +408,64 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
         float gh0 = 0.f, gh1 = 0.f;
         float2 hacc;                                           // NW > 1: this wave's part of sum e conj(U)
         {
-            cacc ca = cacc0();
-            if (worker) {
-                const int par = tk & 1, aa = tk >> 1;
-                const int T = (nm - par + 1) >> 1, Th = ((T + 2 * NP - 1) / (2 * NP)) << 1;
-                const int ma = (part * Th) >> 1, mb = (min(T, part * Th + Th) + 1) >> 1;
-                const int ceA = par + Mh, ceB = par + Mh + 2, npA = mh - aa, npB = mh - aa + 1;
-                const float2 *eA = Es + (ceA & 3) * Lph + (ceA >> 2), *eB = Es + (ceB & 3) * Lph + (ceB >> 2);
-                const float2 *uA = Us + (npA & 1) * Uph + (npA >> 1), *uB = Us + (npB & 1) * Uph + (npB >> 1);
-#pragma unroll 4
-                for (int m = ma; m < mb; m++) {
-                    const float2 e0 = eA[m], u0 = uA[m], f0 = eB[m], w0 = uB[m];
-                    cmac(ca, u0.x, u0.y, e0);
-                    cmac(ca, w0.x, w0.y, f0);
+            float2 acc;
+            if constexpr (NW == 1) {
+                using TB = TapBlocks<M>;
+                const int grp = lane / TB::PH, prt = lane - grp * TB::PH;
+                const bool gv = grp < TB::NGH;                             // lanes beyond NGH * PH idle (they shadow group 0)
+                const int g = gv ? grp : 0, par = g >= TB::NG0 ? 1 : 0, a0 = 4 * (par ? g - TB::NG0 : g);
+                const int T = nm >> 1, Tm = (T + 1) >> 1, nit = (Tm + TB::PH - 1) / TB::PH;   // terms per tap (nm is even: both parities alike), tau pairs, pairs per part
+                const int m0 = prt * nit;
+                const int ceA = par + Mh, ceB = par + Mh + 2, n0 = mh - a0 - 3;                            // U window of the 4 taps: n0 + 2m + (0..4)
+                const float2 *eA = Es + (ceA & 3) * Lph + (ceA >> 2) + m0, *eB = Es + (ceB & 3) * Lph + (ceB >> 2) + m0;
+                const int d = n0 & 1;
+                const float2 *uE = Us + d * Uph + (n0 >> 1) + m0, *uO = Us + (d ^ 1) * Uph + (n0 >> 1) + d + m0;   // k = 0, 2, 4 / k = 1, 3
+                cacc c4[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) c4[i] = cacc0();
+#pragma unroll 1
+                for (int m = 0; m < nit; m++) {                // uniform trip count: a scalar loop
+                    const bool in = m0 + m < Tm;
+                    v2f e0 = lds2(eA + m), f0 = lds2(eB + m);
+                    const v2f w0 = lds2(uE + m), w1 = lds2(uO + m), w2 = lds2(uE + m + 1), w3 = lds2(uO + m + 1), w4 = lds2(uE + m + 2);
+                    if (!in) { e0 = v2f{0.f, 0.f}; f0 = v2f{0.f, 0.f}; }
+                    if (2 * (m0 + m) + 1 >= T) f0 = v2f{0.f, 0.f};         // odd T: the last pair has one term
+                    cmac(c4[0], w3, e0); cmac(c4[1], w2, e0); cmac(c4[2], w1, e0); cmac(c4[3], w0, e0);   // tau = 2m  : tap a0 + i <- U[n0 + 2m + 3 - i]
+                    cmac(c4[0], w4, f0); cmac(c4[1], w3, f0); cmac(c4[2], w2, f0); cmac(c4[3], w1, f0);   // tau = 2m+1: U[n0 + 2m + 4 - i]
                 }
+                float2 *XP = reinterpret_cast<float2 *>(sm + lay.XP);
+                if (gv) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) XP[(g * 4 + i) * TB::PH + prt] = cfinc(c4[i]);            // e * conj(U), this part
+                }
+                wave_lds_sync();
+                acc = make_float2(0.f, 0.f);
+                if (hown) {                                                // owner of h[j = tk]: add the parts in a fixed order
+                    const int par_ = tk & 1, aa = tk >> 1, go = (par_ ? TB::NG0 : 0) + (aa >> 2);
+                    const float2 *xp_ = XP + (go * 4 + (aa & 3)) * TB::PH;
+#pragma unroll
+                    for (int q = 0; q < TB::PH; q++) { const float2 v = xp_[q]; acc.x += v.x; acc.y += v.y; }
+                }
+            } else {
+                cacc ca = cacc0();
+                if (worker) {
+                    const int par = tk & 1, aa = tk >> 1;
+                    const int T = (nm - par + 1) >> 1, Th = ((T + 2 * NP - 1) / (2 * NP)) << 1;
+                    const int ma = (part * Th) >> 1, mb = (min(T, part * Th + Th) + 1) >> 1;
+                    const int ceA = par + Mh, ceB = par + Mh + 2, npA = mh - aa, npB = mh - aa + 1;
+                    const float2 *eA = Es + (ceA & 3) * Lph + (ceA >> 2), *eB = Es + (ceB & 3) * Lph + (ceB >> 2);
+                    const float2 *uA = Us + (npA & 1) * Uph + (npA >> 1), *uB = Us + (npB & 1) * Uph + (npB >> 1);
+#pragma unroll 4
+                    for (int m = ma; m < mb; m++) {
+                        const float2 e0 = eA[m], u0 = uA[m], f0 = eB[m], w0 = uB[m];
+                        cmac(ca, u0.x, u0.y, e0);
+                        cmac(ca, w0.x, w0.y, f0);
+                    }
+                }
+                acc = cfinc(ca);                               // e * conj(U)
+                acc.x += __shfl_xor(acc.x, 32, 64);
+                acc.y += __shfl_xor(acc.y, 32, 64);
             }
-            float2 acc = cfinc(ca);                            // e * conj(U)
-            acc.x += __shfl_xor(acc.x, 32, 64);
-            acc.y += __shfl_xor(acc.y, 32, 64);
             hacc = acc;
             if constexpr (NW > 1) {                            // waves 1.. hand their parts to wave 0 (read after the next barrier)
                 if (wv > 0) { XG[((wv - 1) * 2 + 0) * 64 + lane] = acc.x; XG[((wv - 1) * 2 + 1) * 64 + lane] = acc.y; }
@@ -459,11 +509,11 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
                     }
             }
             {
-                float dv[2] = {wave_sum(dt0), wave_sum(dt1)};
+                float dv[2] = {wave_sum_dpp(dt0), wave_sum_dpp(dt1)};
                 waves_sum<NW, 2>(dv, RED + 24, lane, wv);
                 dt0 = dv[0]; dt1 = dv[1];
             }
-            const float k0_ = dt0 * A / (m0 * m0) / (float)B, k1_ = dt1 * A / (m1 * m1) / (float)B;
+            const float k0_ = dt0 * A * __builtin_amdgcn_rcpf(m0 * m0) * rB, k1_ = dt1 * A * __builtin_amdgcn_rcpf(m1 * m1) * rB;
 #pragma unroll
             for (int r = 0; r < NR; r++)
 #pragma unroll
@@ -500,24 +550,58 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
         // ============ P5: dL/dw, lane = (k = tk, half of the symbol range)
         float gw0 = 0.f, gw1 = 0.f;
         {
-            cacc ca = cacc0();
-            if (worker) {
-                const int Bq = ((B + 2 * NP - 1) / (2 * NP)) << 1;
-                const int ma = (part * Bq) >> 1, mb = min(B, part * Bq + Bq) >> 1;
-                const int cA = tk, cB = tk + 2;
-                const float2 *xA = Xs + (cA & 3) * Lph + (cA >> 2), *xB = Xs + (cB & 3) * Lph + (cB >> 2);
-                const float4 *G = reinterpret_cast<const float4 *>(GY);
-#pragma unroll 4
-                for (int m = ma; m < mb; m++) {
-                    const float4 g = G[m];                     // (gy[2m], gy[2m+1])
-                    const float2 x0 = xA[m], z0 = xB[m];
-                    cmac(ca, x0.x, x0.y, make_float2(g.x, g.y));
-                    cmac(ca, z0.x, z0.y, make_float2(g.z, g.w));
+            float2 acc;
+            if constexpr (NW == 1) {
+                using TB = TapBlocks<M>;
+                const int grp = lane / TB::PW, prt = lane - grp * TB::PW;
+                const bool gv = grp < TB::NGW;
+                const int k0 = 4 * (gv ? grp : 0);                         // taps k0 .. k0 + 3: x[4m + k0 + (0..5)] for the symbol pair (2m, 2m+1)
+                const int Bp = B >> 1, nit = (Bp + TB::PW - 1) / TB::PW, m0 = prt * nit;
+                const float2 *xw = Xs + (k0 >> 2) + m0;                    // sample c = 4m + k0 + j sits at [(j & 3) Lph + m + (k0 >> 2) + (j >> 2)]
+                cacc c4[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) c4[i] = cacc0();
+#pragma unroll 1
+                for (int m = 0; m < nit; m++) {                // uniform trip count: a scalar loop
+                    v2f g0_ = lds2(GY + 2 * (m0 + m)), g1_ = lds2(GY + 2 * (m0 + m) + 1);                  // gy[2m], gy[2m+1]
+                    const v2f x0 = lds2(xw + m), x1 = lds2(xw + Lph + m), x2 = lds2(xw + 2 * Lph + m), x3 = lds2(xw + 3 * Lph + m);
+                    const v2f x4 = lds2(xw + m + 1), x5 = lds2(xw + Lph + m + 1);
+                    if (m0 + m >= Bp) { g0_ = v2f{0.f, 0.f}; g1_ = v2f{0.f, 0.f}; }
+                    cmac(c4[0], x0, g0_); cmac(c4[1], x1, g0_); cmac(c4[2], x2, g0_); cmac(c4[3], x3, g0_);   // n = 2m  : x[2n + k0 + i]
+                    cmac(c4[0], x2, g1_); cmac(c4[1], x3, g1_); cmac(c4[2], x4, g1_); cmac(c4[3], x5, g1_);   // n = 2m+1: two samples on
                 }
+                float2 *XP = reinterpret_cast<float2 *>(sm + lay.XP);
+                if (gv) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) XP[(grp * 4 + i) * TB::PW + prt] = cfinc(c4[i]);          // gy * conj(x), this part
+                }
+                wave_lds_sync();
+                acc = make_float2(0.f, 0.f);
+                if (wown) {
+                    const float2 *xp_ = XP + ((tk >> 2) * 4 + (tk & 3)) * TB::PW;
+#pragma unroll
+                    for (int q = 0; q < TB::PW; q++) { const float2 v = xp_[q]; acc.x += v.x; acc.y += v.y; }
+                }
+            } else {
+                cacc ca = cacc0();
+                if (worker) {
+                    const int Bq = ((B + 2 * NP - 1) / (2 * NP)) << 1;
+                    const int ma = (part * Bq) >> 1, mb = min(B, part * Bq + Bq) >> 1;
+                    const int cA = tk, cB = tk + 2;
+                    const float2 *xA = Xs + (cA & 3) * Lph + (cA >> 2), *xB = Xs + (cB & 3) * Lph + (cB >> 2);
+                    const float4 *G = reinterpret_cast<const float4 *>(GY);
+#pragma unroll 4
+                    for (int m = ma; m < mb; m++) {
+                        const float4 g = G[m];                 // (gy[2m], gy[2m+1])
+                        const float2 x0 = xA[m], z0 = xB[m];
+                        cmac(ca, x0.x, x0.y, make_float2(g.x, g.y));
+                        cmac(ca, z0.x, z0.y, make_float2(g.z, g.w));
+                    }
+                }
+                acc = cfinc(ca);                               // gy * conj(x) = (dL/dW0, -dL/dW1)
+                acc.x += __shfl_xor(acc.x, 32, 64);
+                acc.y += __shfl_xor(acc.y, 32, 64);
             }
-            float2 acc = cfinc(ca);                            // gy * conj(x) = (dL/dW0, -dL/dW1)
-            acc.x += __shfl_xor(acc.x, 32, 64);
-            acc.y += __shfl_xor(acc.y, 32, 64);
             if constexpr (NW > 1) {                            // as for dL/dh: wave 0 adds the other waves' parts after the barrier
                 if (wv > 0) { XG[((wv - 1) * 2 + 0) * 64 + lane] = acc.x; XG[((wv - 1) * 2 + 1) * 64 + lane] = acc.y; }
                 sync_lds<NW>();
