@@ -6,8 +6,8 @@
 //     rounds; the convolution-shaped phases walk the taps once and feed all rounds from each tap read;
 //   * the equaliser output is normalised to the constellation's mean amplitude before the demapper (:228), which adds a
 //     wave-wide sum of |y| on the way forward and its Jacobian (one more dot product) on the way back.
-// Lane (tap k, half) computes one half of the sum of dL/dw[k] and dL/dh[k]; after the cross-half shuffle, half 0 owns w[k] and
-// half 1 owns h[k]: parameter, Adam first/second moment and AMSGrad maximum all live in that lane's registers.
+// The tap gradients dL/dw[k], dL/dh[j] are summed by threads = (group of 4 taps, part of the sum range) (TapBlocks below); lane (k, half 0) of
+// wave 0 owns w[k], lane (j, half 1) owns h[j]: parameter, Adam first/second moment and AMSGrad maximum all live in that lane's registers.
 //
 // Supported here: sps == 2, B even, 2*(M/2)+2 <= B <= 1024, M in {9, 17, 25}; everything else takes the generic kernel.
 // B <= 384: one wavefront per run (NR <= 3 rounds; more rounds spill); 384 < B <= 1024: two to four wavefronts x two rounds.
@@ -22,7 +22,7 @@ namespace vaeq {
 
 struct AwgnWaveLayout {
     int Lph, Uph;
-    int X, E, U, PSv, W, H, PSh, VS, XP, RED, XG, total;   // byte offsets (the dL/dy buffer aliases U)
+    int X, E, U, PSv, W, H, PSh, VS, XP, RED, total;   // byte offsets (the dL/dy buffer aliases U)
 };
 
 __host__ __device__ inline AwgnWaveLayout awgn_wave_layout(int B, int M, int NW = 1)
@@ -41,9 +41,8 @@ __host__ __device__ inline AwgnWaveLayout awgn_wave_layout(int B, int M, int NW 
     l.H = take((M + 1) * 8);                           // one zero pad tap: j = M
     l.PSh = take((M + 1) * 4);
     l.VS = take(M * 4);
-    l.XP = take(NW == 1 ? 256 * 8 : 0);               // NW == 1: partial tap-gradient sums [group][tap in group][part] (complex): 4 per lane
+    l.XP = take(256 * NW * 8);                         // partial tap-gradient sums [group][tap in group][part] (complex): 4 per thread
     l.RED = take(NW > 1 ? 64 * 4 : 0);                 // NW > 1: cross-wave sums and scan offsets
-    l.XG = take((NW - 1) * 2 * 64 * 4);                // ... and the tap-gradient partial sums of waves 1..NW-1
     l.total = o;
     return l;
 }
@@ -77,16 +76,16 @@ __device__ __forceinline__ void wave_fir(cacc (&acc)[NR][2], const float2 *(&xp)
     }
 }
 
-// Blocked tap-gradient sums of the single-wave kernel (NW == 1).  A lane = (group of 4 taps, part of the sum range): per pair of terms it
+// Blocked tap-gradient sums.  A thread = (group of 4 taps, part of the sum range): per pair of terms it
 // reads 7 (dL/dh) / 8 (dL/dw) operands for 8 complex MACs -- the (tap, half) mapping of the DP kernel feeds ONE MAC per operand pair here
-// (one polarisation), i.e. one LDS read per packed FMA and 4 x the loop trips.  NG groups x PARTS parts <= 64 lanes; trip counts are uniform
+// (one polarisation), i.e. one LDS read per packed FMA and 4 x the loop trips.  NG groups x PARTS parts <= 64 NW threads; trip counts are uniform
 // (a scalar loop), terms past the end of a part's range are masked.  The partial sums go through LDS (XP); the tap's owner lane adds its
 // PARTS partials in a fixed order: bitwise reproducible.
-template <int M> struct TapBlocks {
+template <int M, int NW> struct TapBlocks {
     static constexpr int mh = M / 2;
     static constexpr int NG0 = (mh + 1 + 3) / 4, NG1 = (mh + 3) / 4;     // dL/dh: groups of even taps (a = 0..mh) / odd taps (a = 0..mh-1)
-    static constexpr int NGH = NG0 + NG1, PH = 64 / NGH;                 // parts per group
-    static constexpr int NGW = (M + 3) / 4, PW = 64 / NGW;               // dL/dw: groups of 4 consecutive taps
+    static constexpr int NGH = NG0 + NG1, PH = 64 * NW / NGH;            // parts per group (all NW waves of the run take part)
+    static constexpr int NGW = (M + 3) / 4, PW = 64 * NW / NGW;          // dL/dw: groups of 4 consecutive taps
 };
 
 __device__ __forceinline__ void amsgrad_fast(float &p, float &m, float &v, float &vmax, float g, float step_size, float rbc2s)
@@ -109,7 +108,7 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
     char *sm = reinterpret_cast<char *>(smem4);
     const int gl = threadIdx.x, lane = NW > 1 ? (gl & 63) : gl, wv = NW > 1 ? (gl >> 6) : 0, run = blockIdx.x;
     const int l0 = lane + 64 * NR * wv;                       // first pair of this lane
-    constexpr int NT = 64 * NW, NP = 2 * NW;
+    constexpr int NT = 64 * NW;
     const int B = a.B, L = 2 * B, nm = L - Mh, P2 = B / 2, nq = (nm + 3) / 4;
     const float rB = 1.0f / (float)B;
     const AwgnWaveLayout lay = awgn_wave_layout(B, M, NW);
@@ -121,7 +120,7 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
     float *PSv = reinterpret_cast<float *>(sm + lay.PSv);      // [B+1] exclusive prefix sums of v_I + v_Q
     float *PSh = reinterpret_cast<float *>(sm + lay.PSh);      // [M+1] exclusive prefix sums of gC |h_j|^2
     float *VS = reinterpret_cast<float *>(sm + lay.VS);        // [M]
-    float *RED = reinterpret_cast<float *>(sm + lay.RED), *XG = reinterpret_cast<float *>(sm + lay.XG);   // NW > 1 only
+    float *RED = reinterpret_cast<float *>(sm + lay.RED);      // NW > 1 only
 
     float amp[NLEV], nlogP[NLEV];
 #pragma unroll
@@ -138,7 +137,6 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
     __syncthreads();
     const int tk = lane & 31, half = lane >> 5;
     const bool worker = tk < M, owner = worker && wv == 0, wown = owner && half == 0, hown = owner && half == 1;
-    const int part = wv * 2 + half;
     const size_t g0 = (size_t)run * 2 * M + tk, g1 = g0 + M;
     float p0 = 0.f, p1 = 0.f, am0 = 0.f, am1 = 0.f, av0 = 0.f, av1 = 0.f, ax0 = 0.f, ax1 = 0.f;   // parameter pair + Adam state
     {
@@ -406,12 +404,11 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
         const float ss = lr * __builtin_amdgcn_rcpf((float)(1.0 - b1t));
         const float rbc2s = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf((float)(1.0 - b2t)));
         float gh0 = 0.f, gh1 = 0.f;
-        float2 hacc;                                           // NW > 1: this wave's part of sum e conj(U)
         {
             float2 acc;
-            if constexpr (NW == 1) {
-                using TB = TapBlocks<M>;
-                const int grp = lane / TB::PH, prt = lane - grp * TB::PH;
+            {
+                using TB = TapBlocks<M, NW>;
+                const int grp = gl / TB::PH, prt = gl - grp * TB::PH;
                 const bool gv = grp < TB::NGH;                             // lanes beyond NGH * PH idle (they shadow group 0)
                 const int g = gv ? grp : 0, par = g >= TB::NG0 ? 1 : 0, a0 = 4 * (par ? g - TB::NG0 : g);
                 const int T = nm >> 1, Tm = (T + 1) >> 1, nit = (Tm + TB::PH - 1) / TB::PH;   // terms per tap (nm is even: both parities alike), tau pairs, pairs per part
@@ -438,7 +435,7 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
 #pragma unroll
                     for (int i = 0; i < 4; i++) XP[(g * 4 + i) * TB::PH + prt] = cfinc(c4[i]);            // e * conj(U), this part
                 }
-                wave_lds_sync();
+                sync_lds<NW>();
                 acc = make_float2(0.f, 0.f);
                 if (hown) {                                                // owner of h[j = tk]: add the parts in a fixed order
                     const int par_ = tk & 1, aa = tk >> 1, go = (par_ ? TB::NG0 : 0) + (aa >> 2);
@@ -446,31 +443,8 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
 #pragma unroll
                     for (int q = 0; q < TB::PH; q++) { const float2 v = xp_[q]; acc.x += v.x; acc.y += v.y; }
                 }
-            } else {
-                cacc ca = cacc0();
-                if (worker) {
-                    const int par = tk & 1, aa = tk >> 1;
-                    const int T = (nm - par + 1) >> 1, Th = ((T + 2 * NP - 1) / (2 * NP)) << 1;
-                    const int ma = (part * Th) >> 1, mb = (min(T, part * Th + Th) + 1) >> 1;
-                    const int ceA = par + Mh, ceB = par + Mh + 2, npA = mh - aa, npB = mh - aa + 1;
-                    const float2 *eA = Es + (ceA & 3) * Lph + (ceA >> 2), *eB = Es + (ceB & 3) * Lph + (ceB >> 2);
-                    const float2 *uA = Us + (npA & 1) * Uph + (npA >> 1), *uB = Us + (npB & 1) * Uph + (npB >> 1);
-#pragma unroll 4
-                    for (int m = ma; m < mb; m++) {
-                        const float2 e0 = eA[m], u0 = uA[m], f0 = eB[m], w0 = uB[m];
-                        cmac(ca, u0.x, u0.y, e0);
-                        cmac(ca, w0.x, w0.y, f0);
-                    }
-                }
-                acc = cfinc(ca);                               // e * conj(U)
-                acc.x += __shfl_xor(acc.x, 32, 64);
-                acc.y += __shfl_xor(acc.y, 32, 64);
             }
-            hacc = acc;
-            if constexpr (NW > 1) {                            // waves 1.. hand their parts to wave 0 (read after the next barrier)
-                if (wv > 0) { XG[((wv - 1) * 2 + 0) * 64 + lane] = acc.x; XG[((wv - 1) * 2 + 1) * 64 + lane] = acc.y; }
-            }
-            if (NW == 1 && hown) {
+            if (hown) {
                 gh0 = gC * (-2.0f * acc.x + 2.0f * p0 * vsl);
                 gh1 = gC * (-2.0f * acc.y + 2.0f * p1 * vsl);
                 if (!a.no_update) {
@@ -525,19 +499,6 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
                 }
         }
         sync_lds<NW>();                                       // every read of U / old h is done (GY aliases U)
-        if constexpr (NW > 1) {
-            if (hown) {
-                float2 acc = hacc;
-#pragma unroll
-                for (int w = 0; w < NW - 1; w++) { acc.x += XG[(w * 2 + 0) * 64 + lane]; acc.y += XG[(w * 2 + 1) * 64 + lane]; }
-                gh0 = gC * (-2.0f * acc.x + 2.0f * p0 * vsl);
-                gh1 = gC * (-2.0f * acc.y + 2.0f * p1 * vsl);
-                if (!a.no_update) {
-                    amsgrad_fast(p0, am0, av0, ax0, gh0, ss, rbc2s);
-                    amsgrad_fast(p1, am1, av1, ax1, gh1, ss, rbc2s);
-                }
-            }
-        }
 #pragma unroll
         for (int r = 0; r < NR; r++)
             if (act[r]) {
@@ -551,9 +512,9 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
         float gw0 = 0.f, gw1 = 0.f;
         {
             float2 acc;
-            if constexpr (NW == 1) {
-                using TB = TapBlocks<M>;
-                const int grp = lane / TB::PW, prt = lane - grp * TB::PW;
+            {
+                using TB = TapBlocks<M, NW>;
+                const int grp = gl / TB::PW, prt = gl - grp * TB::PW;
                 const bool gv = grp < TB::NGW;
                 const int k0 = 4 * (gv ? grp : 0);                         // taps k0 .. k0 + 3: x[4m + k0 + (0..5)] for the symbol pair (2m, 2m+1)
                 const int Bp = B >> 1, nit = (Bp + TB::PW - 1) / TB::PW, m0 = prt * nit;
@@ -575,39 +536,12 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
 #pragma unroll
                     for (int i = 0; i < 4; i++) XP[(grp * 4 + i) * TB::PW + prt] = cfinc(c4[i]);          // gy * conj(x), this part
                 }
-                wave_lds_sync();
+                sync_lds<NW>();
                 acc = make_float2(0.f, 0.f);
                 if (wown) {
                     const float2 *xp_ = XP + ((tk >> 2) * 4 + (tk & 3)) * TB::PW;
 #pragma unroll
                     for (int q = 0; q < TB::PW; q++) { const float2 v = xp_[q]; acc.x += v.x; acc.y += v.y; }
-                }
-            } else {
-                cacc ca = cacc0();
-                if (worker) {
-                    const int Bq = ((B + 2 * NP - 1) / (2 * NP)) << 1;
-                    const int ma = (part * Bq) >> 1, mb = min(B, part * Bq + Bq) >> 1;
-                    const int cA = tk, cB = tk + 2;
-                    const float2 *xA = Xs + (cA & 3) * Lph + (cA >> 2), *xB = Xs + (cB & 3) * Lph + (cB >> 2);
-                    const float4 *G = reinterpret_cast<const float4 *>(GY);
-#pragma unroll 4
-                    for (int m = ma; m < mb; m++) {
-                        const float4 g = G[m];                 // (gy[2m], gy[2m+1])
-                        const float2 x0 = xA[m], z0 = xB[m];
-                        cmac(ca, x0.x, x0.y, make_float2(g.x, g.y));
-                        cmac(ca, z0.x, z0.y, make_float2(g.z, g.w));
-                    }
-                }
-                acc = cfinc(ca);                               // gy * conj(x) = (dL/dW0, -dL/dW1)
-                acc.x += __shfl_xor(acc.x, 32, 64);
-                acc.y += __shfl_xor(acc.y, 32, 64);
-            }
-            if constexpr (NW > 1) {                            // as for dL/dh: wave 0 adds the other waves' parts after the barrier
-                if (wv > 0) { XG[((wv - 1) * 2 + 0) * 64 + lane] = acc.x; XG[((wv - 1) * 2 + 1) * 64 + lane] = acc.y; }
-                sync_lds<NW>();
-                if (wown) {
-#pragma unroll
-                    for (int w = 0; w < NW - 1; w++) { acc.x += XG[(w * 2 + 0) * 64 + lane]; acc.y += XG[(w * 2 + 1) * 64 + lane]; }
                 }
             }
             if (wown) {
