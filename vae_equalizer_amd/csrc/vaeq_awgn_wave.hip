@@ -13,6 +13,7 @@
 // B <= 384: one wavefront per run (NR <= 3 rounds; more rounds spill); 384 < B <= 1024: two to four wavefronts x two rounds.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "vaeq.h"
 #include "vaeq_common.h"
@@ -47,31 +48,64 @@ __host__ __device__ inline AwgnWaveLayout awgn_wave_layout(int B, int M, int NW 
     return l;
 }
 
-// acc[r][sym] += sum_k taps[k] (x) x_r[2*sym + k] for the symbol pair of every round; xp[r] = the lane's phase-0 pointer in round r.
+// acc[r][sym] = sum_k taps[k] (x) x_r[2*sym + k] for the symbol pair of every round; xp[r] = the lane's phase-0 pointer in round r.
+// With up to two rounds per lane: the first tap group starts the accumulators and the 8-byte LDS reads stay ds_read_b64 (lds2): +4 % at B = 512.  With
+// three rounds the kernel is register-starved and that form costs more in spills than it saves (43 spilled dwords, -8 % at B = 350): round 1's form there.
 template <int M, int NR>
 __device__ __forceinline__ void wave_fir(cacc (&acc)[NR][2], const float2 *(&xp)[NR], int Lph, const float2 *taps)
 {
-    constexpr int G = M / 4;
-#pragma unroll 1
-    for (int g = 0; g < G; g++) {                      // taps 4g..4g+3, samples c' = 4g..4g+5
-        const float2 t0 = taps[4 * g], t1 = taps[4 * g + 1], t2 = taps[4 * g + 2], t3 = taps[4 * g + 3];
+    if constexpr (NR >= 3) {                           // register-starved (three rounds per lane): zeroed accumulators, ordinary loads
 #pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const float2 *xg = xp[r] + g;
-            const float2 x0 = xg[0], x1 = xg[Lph], x2 = xg[2 * Lph], x3 = xg[3 * Lph], x4 = xg[1], x5 = xg[Lph + 1];
-            cmac(acc[r][0], t0.x, t0.y, x0); cmac(acc[r][1], t0.x, t0.y, x2);
-            cmac(acc[r][0], t1.x, t1.y, x1); cmac(acc[r][1], t1.x, t1.y, x3);
-            cmac(acc[r][0], t2.x, t2.y, x2); cmac(acc[r][1], t2.x, t2.y, x4);
-            cmac(acc[r][0], t3.x, t3.y, x3); cmac(acc[r][1], t3.x, t3.y, x5);
+        for (int r = 0; r < NR; r++) acc[r][0] = acc[r][1] = cacc0();
+        constexpr int G = M / 4;
+    #pragma unroll 1
+        for (int g = 0; g < G; g++) {                      // taps 4g..4g+3, samples c' = 4g..4g+5
+            const float2 t0 = taps[4 * g], t1 = taps[4 * g + 1], t2 = taps[4 * g + 2], t3 = taps[4 * g + 3];
+    #pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const float2 *xg = xp[r] + g;
+                const float2 x0 = xg[0], x1 = xg[Lph], x2 = xg[2 * Lph], x3 = xg[3 * Lph], x4 = xg[1], x5 = xg[Lph + 1];
+                cmac(acc[r][0], t0.x, t0.y, x0); cmac(acc[r][1], t0.x, t0.y, x2);
+                cmac(acc[r][0], t1.x, t1.y, x1); cmac(acc[r][1], t1.x, t1.y, x3);
+                cmac(acc[r][0], t2.x, t2.y, x2); cmac(acc[r][1], t2.x, t2.y, x4);
+                cmac(acc[r][0], t3.x, t3.y, x3); cmac(acc[r][1], t3.x, t3.y, x5);
+            }
         }
-    }
-#pragma unroll
-    for (int k = 4 * G; k < M; k++) {                  // remaining 1 or 3 taps
-        const float2 t = taps[k];
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            cmac(acc[r][0], t.x, t.y, xp[r][(k & 3) * Lph + (k >> 2)]);
-            cmac(acc[r][1], t.x, t.y, xp[r][((k + 2) & 3) * Lph + ((k + 2) >> 2)]);
+    #pragma unroll
+        for (int k = 4 * G; k < M; k++) {                  // remaining 1 or 3 taps
+            const float2 t = taps[k];
+    #pragma unroll
+            for (int r = 0; r < NR; r++) {
+                cmac(acc[r][0], t.x, t.y, xp[r][(k & 3) * Lph + (k >> 2)]);
+                cmac(acc[r][1], t.x, t.y, xp[r][((k + 2) & 3) * Lph + ((k + 2) >> 2)]);
+            }
+        }
+    } else {
+        constexpr int G = M / 4;
+        auto group = [&](int g, auto first) {              // taps 4g..4g+3, samples c' = 4g..4g+5
+            constexpr bool F = decltype(first)::value;
+            const v2f t0 = lds2(taps + 4 * g), t1 = lds2(taps + 4 * g + 1), t2 = lds2(taps + 4 * g + 2), t3 = lds2(taps + 4 * g + 3);
+    #pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const float2 *xg = xp[r] + g;
+                const v2f x0 = lds2(xg), x1 = lds2(xg + Lph), x2 = lds2(xg + 2 * Lph), x3 = lds2(xg + 3 * Lph), x4 = lds2(xg + 1), x5 = lds2(xg + Lph + 1);
+                cmacf<F>(acc[r][0], t0, x0); cmacf<F>(acc[r][1], t0, x2);
+                cmac(acc[r][0], t1, x1); cmac(acc[r][1], t1, x3);
+                cmac(acc[r][0], t2, x2); cmac(acc[r][1], t2, x4);
+                cmac(acc[r][0], t3, x3); cmac(acc[r][1], t3, x5);
+            }
+        };
+        group(0, std::true_type{});
+    #pragma unroll 1
+        for (int g = 1; g < G; g++) group(g, std::false_type{});
+    #pragma unroll
+        for (int k = 4 * G; k < M; k++) {                  // remaining 1 or 3 taps
+            const v2f t = lds2(taps + k);
+    #pragma unroll
+            for (int r = 0; r < NR; r++) {
+                cmac(acc[r][0], t, lds2(xp[r] + (k & 3) * Lph + (k >> 2)));
+                cmac(acc[r][1], t, lds2(xp[r] + ((k + 2) & 3) * Lph + ((k + 2) >> 2)));
+            }
         }
     }
 }
@@ -202,8 +236,6 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
         float2 y[NR][2];
         {
             cacc ya[NR][2];
-#pragma unroll
-            for (int r = 0; r < NR; r++) ya[r][0] = ya[r][1] = cacc0();
             wave_fir<M, NR>(ya, xp, Lph, Wt);
 #pragma unroll
             for (int r = 0; r < NR; r++)
@@ -335,33 +367,66 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
         float se = 0.f;
         {
             cacc D[NR][4];
-#pragma unroll
-            for (int r = 0; r < NR; r++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) D[r][i] = cacc0();
-            auto step_a = [&](int r, float2 he, float2 ho, float2 ulo, float2 uhi) {
-                cmac(D[r][0], he.x, he.y, ulo); cmac(D[r][1], ho.x, ho.y, ulo);
-                cmac(D[r][2], he.x, he.y, uhi); cmac(D[r][3], ho.x, ho.y, uhi);
-            };
-            constexpr int NA = mh + 1, NB = NA / 2;
-#pragma unroll 1
-            for (int b = 0; b < NB; b++) {                     // a = 2b, 2b+1;  d = mh - 2b: samples d+1, d, d-1
-                const float2 he0 = Ht[4 * b], ho0 = Ht[4 * b + 1], he1 = Ht[4 * b + 2], ho1 = Ht[4 * b + 3];
-                constexpr int ph = mh & 1;
-                const int sl = (mh >> 1) - b;
-#pragma unroll
-                for (int r = 0; r < NR; r++) {
-                    const float2 ud = up[r][ph * Uph + sl];
-                    const float2 udp = up[r][(ph ^ 1) * Uph + sl + ph];
-                    const float2 udm = up[r][(ph ^ 1) * Uph + sl + ph - 1];
-                    step_a(r, he0, ho0, ud, udp);
-                    step_a(r, he1, ho1, udm, ud);
+            if constexpr (NR >= 3) {                           // (see wave_fir)
+    #pragma unroll
+                for (int r = 0; r < NR; r++)
+    #pragma unroll
+                    for (int i = 0; i < 4; i++) D[r][i] = cacc0();
+                auto step_a = [&](int r, float2 he, float2 ho, float2 ulo, float2 uhi) {
+                    cmac(D[r][0], he.x, he.y, ulo); cmac(D[r][1], ho.x, ho.y, ulo);
+                    cmac(D[r][2], he.x, he.y, uhi); cmac(D[r][3], ho.x, ho.y, uhi);
+                };
+                constexpr int NA = mh + 1, NB = NA / 2;
+    #pragma unroll 1
+                for (int b = 0; b < NB; b++) {                     // a = 2b, 2b+1;  d = mh - 2b: samples d+1, d, d-1
+                    const float2 he0 = Ht[4 * b], ho0 = Ht[4 * b + 1], he1 = Ht[4 * b + 2], ho1 = Ht[4 * b + 3];
+                    constexpr int ph = mh & 1;
+                    const int sl = (mh >> 1) - b;
+    #pragma unroll
+                    for (int r = 0; r < NR; r++) {
+                        const float2 ud = up[r][ph * Uph + sl];
+                        const float2 udp = up[r][(ph ^ 1) * Uph + sl + ph];
+                        const float2 udm = up[r][(ph ^ 1) * Uph + sl + ph - 1];
+                        step_a(r, he0, ho0, ud, udp);
+                        step_a(r, he1, ho1, udm, ud);
+                    }
                 }
-            }
-            if (NA & 1) {                                      // a = mh: d = 0
-                const float2 he = Ht[2 * mh], ho = Ht[2 * mh + 1];
-#pragma unroll
-                for (int r = 0; r < NR; r++) step_a(r, he, ho, up[r][0], up[r][Uph]);
+                if (NA & 1) {                                      // a = mh: d = 0
+                    const float2 he = Ht[2 * mh], ho = Ht[2 * mh + 1];
+    #pragma unroll
+                    for (int r = 0; r < NR; r++) step_a(r, he, ho, up[r][0], up[r][Uph]);
+                }
+            } else {
+                auto step_a = [&](int r, v2f he, v2f ho, v2f ulo, v2f uhi, auto first) {
+                    constexpr bool F = decltype(first)::value;
+                    cmacf<F>(D[r][0], he, ulo); cmacf<F>(D[r][1], ho, ulo);
+                    cmacf<F>(D[r][2], he, uhi); cmacf<F>(D[r][3], ho, uhi);
+                };
+                constexpr int NA = mh + 1, NB = NA / 2;
+                if (NA & 1) {                                      // a = mh: d = 0 (first: it starts the accumulators)
+                    const v2f he = lds2(Ht + 2 * mh), ho = lds2(Ht + 2 * mh + 1);
+    #pragma unroll
+                    for (int r = 0; r < NR; r++) step_a(r, he, ho, lds2(up[r]), lds2(up[r] + Uph), std::true_type{});
+                } else {
+    #pragma unroll
+                    for (int r = 0; r < NR; r++)
+    #pragma unroll
+                        for (int i = 0; i < 4; i++) D[r][i] = cacc0();
+                }
+    #pragma unroll 1
+                for (int b = 0; b < NB; b++) {                     // a = 2b, 2b+1;  d = mh - 2b: samples d+1, d, d-1
+                    const v2f he0 = lds2(Ht + 4 * b), ho0 = lds2(Ht + 4 * b + 1), he1 = lds2(Ht + 4 * b + 2), ho1 = lds2(Ht + 4 * b + 3);
+                    constexpr int ph = mh & 1;
+                    const int sl = (mh >> 1) - b;
+    #pragma unroll
+                    for (int r = 0; r < NR; r++) {
+                        const v2f ud = lds2(up[r] + ph * Uph + sl);
+                        const v2f udp = lds2(up[r] + (ph ^ 1) * Uph + sl + ph);
+                        const v2f udm = lds2(up[r] + (ph ^ 1) * Uph + sl + ph - 1);
+                        step_a(r, he0, ho0, ud, udp, std::false_type{});
+                        step_a(r, he1, ho1, udm, ud, std::false_type{});
+                    }
+                }
             }
 #pragma unroll
             for (int r = 0; r < NR; r++)
@@ -462,8 +527,6 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
             float dt0 = 0.f, dt1 = 0.f;
             {
                 cacc cu[NR][2];
-#pragma unroll
-                for (int r = 0; r < NR; r++) cu[r][0] = cu[r][1] = cacc0();
                 wave_fir<M, NR>(cu, ep, Lph, Ht);
 #pragma unroll
                 for (int r = 0; r < NR; r++)
@@ -591,7 +654,7 @@ static int launch_awgn_wave_r(const vaeq_awgn_args &a, hipStream_t st)
     switch ((a.B / 2 + 63) / 64) {
     case 1: return launch_awgn_wave_k<M, NLEV, 1>(a, st);
     case 2: return launch_awgn_wave_k<M, NLEV, 2>(a, st);
-    case 3: return launch_awgn_wave_k<M, NLEV, 3>(a, st);
+    case 3: return launch_awgn_wave_k<M, NLEV, 3>(a, st);       // (three waves x one round would need <= 128 VGPRs to keep the runs per CU: 79 spilled dwords)
     case 4: return launch_awgn_wave_k<M, NLEV, 2, 2>(a, st);   // B <= 512: two wavefronts x two rounds
     case 5:
     case 6: return launch_awgn_wave_k<M, NLEV, 2, 3>(a, st);   // B <= 768

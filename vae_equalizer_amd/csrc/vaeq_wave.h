@@ -79,6 +79,14 @@ typedef const volatile __attribute__((address_space(3))) v2f lds_cv2f;
 __device__ __forceinline__ v2f lds2(const float2 *p) { return *(lds_cv2f *)p; }
 __device__ __forceinline__ v2f lds2(const float *p) { return *(lds_cv2f *)p; }
 __device__ __forceinline__ float2 f2(v2f v) { return make_float2(v.x, v.y); }
+// lds2 where the kernel can afford it (V), an ordinary load (free to fuse / reorder: fewer live registers) where it is register-starved
+template <bool V>
+__device__ __forceinline__ v2f lds2_if(const float2 *p)
+{
+    if constexpr (V) return lds2(p);
+    const float2 t = *p;
+    return v2f{t.x, t.y};
+}
 
 // Buffer addressing for the streamed rows: address = base (4 SGPRs, one descriptor per array and frame) + a per-lane byte offset (VGPR) + a
 // per-row byte offset (SGPR, folded into the instruction): NO vector ALU work per store / load, no 64-bit row pointers to keep (or spill) in
