@@ -129,6 +129,34 @@ __device__ __forceinline__ bool epi_keep(int n, int N, int batch_len, int shift0
     return j < Lk && k >= EDGE && k < K - EDGE - ms;
 }
 
+// epi_keep for the symbols n = tid, tid + 256, ... of one thread without an integer division per symbol: (minibatch, offset) advance by
+// (256 / batch_len, 256 % batch_len) with one carry
+struct KeepWalk {
+    int N, batch_len, ms, Lk, K, mb, j, dq, dr;
+    __device__ __forceinline__ KeepWalk(int n0, int N_, int batch_len_, int shift0, int ms_) : N(N_), batch_len(batch_len_), ms(ms_)
+    {
+        Lk = K = mb = j = dq = dr = 0;
+        if (batch_len > 0) {
+            Lk = batch_len - shift0 - N_CUT;
+            Lk = Lk < 0 ? 0 : (Lk > batch_len ? batch_len : Lk);
+            K = (N / batch_len) * Lk;
+            mb = n0 / batch_len; j = n0 - mb * batch_len;
+            dq = EPI_NT / batch_len; dr = EPI_NT - dq * batch_len;
+        }
+    }
+    __device__ __forceinline__ bool keep(int n) const
+    {
+        if (batch_len <= 0) return n >= EDGE && n < N - EDGE - ms;
+        const int k = mb * Lk + j;
+        return j < Lk && k >= EDGE && k < K - EDGE - ms;
+    }
+    __device__ __forceinline__ void next()
+    {
+        mb += dq; j += dr;
+        if (j >= batch_len) { j -= batch_len; mb++; }
+    }
+};
+
 template <int NLEV>
 __global__ __launch_bounds__(EPI_NT, 6) void dp_epilogue_kernel(int64_t N, int batch_len, const float *__restrict__ q, const float *__restrict__ y,
                                                              const __half *__restrict__ txg, const float *__restrict__ amp_g,
@@ -191,8 +219,9 @@ __global__ __launch_bounds__(EPI_NT, 6) void dp_epilogue_kernel(int64_t N, int b
         float fac = 1.0f;
         if (path == 1) {                                        // mean radius of TX over mean radius of the aligned output (:242)
             float st = 0.f, sy = 0.f;
-            for (int n = tid; n < (int)N; n += EPI_NT) {
-                if (!epi_keep(n, (int)N, batch_len, s0, ms)) continue;
+            KeepWalk kw(tid, (int)N, batch_len, s0, ms);
+            for (int n = tid; n < (int)N; n += EPI_NT, kw.next()) {
+                if (!kw.keep(n)) continue;
 #pragma unroll
                 for (int p = 0; p < 2; p++) {
                     const int sp = (p - r) & 1;
@@ -212,8 +241,9 @@ __global__ __launch_bounds__(EPI_NT, 6) void dp_epilogue_kernel(int64_t N, int b
 #pragma unroll
         for (int i = 0; i < 16; i++) cnt[i] = 0;
         int kept = 0;
-        for (int n = tid; n < (int)N; n += EPI_NT) {
-            if (!epi_keep(n, (int)N, batch_len, s0, ms)) continue;
+        KeepWalk kw(tid, (int)N, batch_len, s0, ms);
+        for (int n = tid; n < (int)N; n += EPI_NT, kw.next()) {
+            if (!kw.keep(n)) continue;
             kept++;
 #pragma unroll
             for (int p = 0; p < 2; p++) {
