@@ -120,7 +120,7 @@ __global__ __launch_bounds__(TX_NT) void gen_tx_kernel(int N_conv, int n_lev, in
     }
     __syncthreads();
     const int sb = s0 + 8 * tid;
-    if (MODE == 0 && sb >= Lrow && !fz.part) return;
+    // (MODE 0: every thread stays for the output transpose)
     cacc acc[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) acc[i] = cacc0();
@@ -141,13 +141,22 @@ __global__ __launch_bounds__(TX_NT) void gen_tx_kernel(int N_conv, int n_lev, in
     }
     __shared__ float red[64];
     if (MODE == 0) {
-        float2 *o = sig + ((size_t)run * npol + pol) * Lrow + sb;
+        // a thread holds 8 CONSECUTIVE samples (64 bytes): written straight out, a wave's store would touch 64 separate 64-byte segments.  They
+        // go through LDS (stride 9 per thread: conflict-free both ways) and leave as rows of consecutive 8-byte words.
+        __shared__ float2 outs[TX_NT * 9];
         float pw = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const float2 v = sb + i < Ls ? cfin(acc[i]) : make_float2(0.f, 0.f);
-            if (sb + i < Lrow) o[i] = v;
+            outs[9 * tid + i] = v;
             pw += v.x * v.x + v.y * v.y;
+        }
+        __syncthreads();
+        float2 *o = sig + ((size_t)run * npol + pol) * Lrow + s0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int k = j * TX_NT + tid;
+            if (s0 + k < Lrow) o[k] = outs[9 * (k >> 3) + (k & 7)];
         }
         if (fz.part) {                                         // fixed-order block sum: bitwise reproducible
             block_reduce3<TX_NT>(pw, 0.f, 0.f, red);
