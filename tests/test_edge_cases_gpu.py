@@ -144,3 +144,27 @@ def test_nn_entry_points_reject_bad_arguments_and_accept_empty_batches():
     assert eng.train(torch.zeros(0, 2, 240, device=DEV), 60, 2, 1e-3)["loss"].shape == (0, 2)
     with pytest.raises(ValueError):
         NNEngine(1, 9, 12, 3, _amp(4), DEV)
+
+
+def test_engine_checkpoint_resume_is_bit_identical():
+    """SURVEY section 5 (checkpoint / resume, absent from the reference): a run's whole carried state is seven tensors; saving them between frames and
+    loading them into a fresh engine continues the run bit-identically."""
+    from vae_equalizer_amd.engine import DPEngine
+    rng = np.random.default_rng(3)
+    R, B, M, steps = 5, 100, 25, 6
+    amp = (np.arange(-7, 8, 2) / np.sqrt(42.0)).astype(np.float32)
+    mk = lambda: DPEngine(R, M, amp, np.full(8, 1 / 8, np.float32), [0.0025, 0.003], 0.0, "cuda:0", 2)
+    rx = torch.from_numpy((0.4 * rng.standard_normal((R, 2, 2, 2, steps * B * 2))).astype(np.float32)).cuda()
+    a, b = mk(), mk()
+    ra = a.train(rx, B, steps, 2.5e-3)                                                  # two frames in one go
+    b.train(rx[:, :1].contiguous(), B, steps, 2.5e-3)
+    sd = b.state_dict()
+    assert all(not t.is_cuda for t in sd.values()) and int(sd["step"][0]) == steps
+    c = mk()
+    c.load_state_dict(sd)
+    rc = c.train(rx[:, 1:].contiguous(), B, steps, 2.5e-3)
+    torch.cuda.synchronize()
+    assert torch.equal(ra["loss"][:, 1], rc["loss"][:, 0]) and torch.equal(a.W, c.W) and torch.equal(a.h, c.h) and torch.equal(a.vh, c.vh)
+    assert torch.equal(a.step, c.step)
+    with pytest.raises(ValueError):
+        c.load_state_dict({**sd, "W": sd["W"][:2]})

@@ -61,6 +61,20 @@ class DPEngine:
         if h is not None:
             self.h.copy_(_f32(h, self.device).expand_as(self.h))
 
+    _STATE = ("W", "h", "mW", "vW", "mh", "vh", "step")
+
+    def state_dict(self):
+        """Everything a run carries from one minibatch to the next (taps, channel estimate, both Adam groups' moments, step counts), on the
+        CPU: a sweep can be checkpointed between frames and resumed bit-identically (the reference persists nothing mid-run)."""
+        return {k: getattr(self, k).detach().cpu().clone() for k in self._STATE}
+
+    def load_state_dict(self, sd):
+        for k in self._STATE:
+            t = getattr(self, k)
+            if tuple(sd[k].shape) != tuple(t.shape) or sd[k].dtype != t.dtype:
+                raise ValueError(f"state {k!r}: expected {tuple(t.shape)} {t.dtype}, got {tuple(sd[k].shape)} {sd[k].dtype}")
+            t.copy_(sd[k].to(self.device))
+
     def train(self, rx, B, steps, lr_W, lr_h=None, stride=None, keep_off=0, keep_len=None, want_q=True, want_y=True,
               want_loss=True, debug_grads=False, no_update=False, want_compact=False):
         """Run ``steps`` minibatch steps per frame on rx[R, n_frames, 2, 2, S] (or [R, 2, 2, S]).
