@@ -289,22 +289,27 @@ __global__ __launch_bounds__(256) void gen_power_kernel(int Ls, int Lrow, int np
 
 // stage 3b: AWGN + planar split: rx[r][p][0/1][s] = Re/Im(sig + sigma_n (n1 + j n2)), s < Lout = sps*N (even)   (:84-88)
 // one Philox call -> two Box-Muller pairs -> the noise of two consecutive samples
-// n_parts == 0: power[run] = the mean power (gen_power_kernel); n_parts > 0: power[run][n_parts] = partial sums of |sig|^2 from stage 1 over
-// all polarisations and tiles (summed here in a fixed order), Ls samples per polarisation
+// stage 1's partial sums of |sig|^2 (all polarisations and tiles of a run, Ls samples per polarisation) -> the run's noise level (:83), in a fixed order;
+// the result replaces the run's first partial
+__global__ __launch_bounds__(256) void gen_sigma_kernel(int R, int n_parts, int npol, int Ls, int sps, const float *__restrict__ snr_db, float *__restrict__ power)
+{
+    const int run = blockIdx.x * blockDim.x + threadIdx.x;
+    if (run >= R) return;
+    float pw = 0.f;
+    for (int t = 0; t < n_parts; t++) pw += power[(size_t)run * n_parts + t];
+    power[(size_t)run * n_parts] = sqrtf(pw / (float)(npol * Ls) * (float)sps * 0.5f / exp10f(snr_db[run] * 0.1f));
+}
+
+// n_parts == 0: power[run] = the mean power (gen_power_kernel); n_parts > 0: power[run * n_parts] = sigma_n (gen_sigma_kernel)
 __global__ __launch_bounds__(256) void gen_finish_kernel(int Lrow, int Lout, int sps, const float *__restrict__ snr_db, const float *__restrict__ power,
                                                          uint64_t seed, uint32_t frame, int npol, const float2 *__restrict__ sig,
                                                          float *__restrict__ rx, float *__restrict__ sigma_out,
                                                          const float *__restrict__ sigma_fixed, int n_parts, int Ls)
 {
     const int run = blockIdx.z, pol = blockIdx.y;
-    float pmean = 0.f;
-    if (!sigma_fixed) {
-        if (n_parts > 0) {
-            for (int t = 0; t < n_parts; t++) pmean += power[(size_t)run * n_parts + t];
-            pmean /= (float)(npol * Ls);
-        } else pmean = power[run];
-    }
-    const float sigma = sigma_fixed ? sigma_fixed[run] : sqrtf(pmean * (float)sps * 0.5f / exp10f(snr_db[run] * 0.1f));
+    // n_parts > 0: gen_sigma_kernel has already turned the run's partial sums into its noise level, left in power[run * n_parts]
+    const float sigma = sigma_fixed ? sigma_fixed[run]
+                                    : n_parts > 0 ? power[(size_t)run * n_parts] : sqrtf(power[run] * (float)sps * 0.5f / exp10f(snr_db[run] * 0.1f));
     if (sigma_out && pol == 0 && blockIdx.x == 0 && threadIdx.x == 0) sigma_out[run] = sigma;
     const float2 *s = sig + ((size_t)run * npol + pol) * Lrow;
     float *rI = rx + ((size_t)(run * npol + pol) * 2 + 0) * Lout, *rQ = rI + Lout;
@@ -350,6 +355,7 @@ static void launch_finish(int R, int npol, int N, int sps, int Ls, int Lrow, con
 {
     const int Lout = sps * N, nj = (Lout + 1) / 2;
     if (!sigma_fixed && n_parts == 0) hipLaunchKernelGGL(gen_power_kernel, dim3(R), dim3(256), 0, st, Ls, Lrow, npol, sig, power_ws);
+    if (!sigma_fixed && n_parts > 0) hipLaunchKernelGGL(gen_sigma_kernel, dim3((R + 255) / 256), dim3(256), 0, st, R, n_parts, npol, Ls, sps, snr_db, power_ws);
     hipLaunchKernelGGL(gen_finish_kernel, dim3((nj + 255) / 256 > 64 ? 64 : (nj + 255) / 256, npol, R), dim3(256), 0, st, Lrow, Lout, sps, snr_db,
                        power_ws, seed, frame, npol, sig, rx, sigma_out, sigma_fixed, n_parts, Ls);
 }
