@@ -6,17 +6,20 @@
 //   * lane l owns the symbol pair (2l, 2l+1) of the minibatch (B <= 128): FIR, soft demap, the per-symbol moments
 //     (kept in registers until the backward pass) and dL/dy are all done by the owning lane; q and y leave as one
 //     8-byte store per lane and row (400 contiguous bytes per row and step at B = 100).
-//   * every convolution-shaped phase is register-blocked over that pair and over both outputs: a tap quad is read once
-//     (LDS broadcast) and feeds 16 FMAs
+//   * every convolution-shaped phase is register-blocked over that pair and over both outputs: the taps of a group of four are read once
+//     (LDS broadcasts) and feed 32 packed FMAs
 //     (FIR:  y[n]      = sum_k w[k] x[2n+k],
-//      dL/dU[n]        = sum_j e[2n+j] conj(h[j])    -- the same shape on the residual e,
+//      dL/dU[n]        = sum_j e[2n+j] conj(h[j])    -- the same shape on the residual e, both chi in one loop,
 //      D[t], t=4l..4l+3: the zero-stuffed convolution, written as two polyphase symbol-rate FIRs on mu).
 //   * sample-rate arrays (x, e) are stored 4-way polyphase in LDS (index c -> [c & 3][c >> 2]) and the symbol-rate mu
 //     2-way, so that the stride-4 / stride-2 accesses of consecutive lanes hit consecutive 8-byte LDS words.
 //   * the two correlation-shaped gradients (dL/dh: 100 outputs x 88 terms, dL/dw: 100 x 100) are laid out as
 //     lane = (tap, half of the sum range); halves are combined with one cross-half shuffle; the lane that ends up
-//     with a gradient also owns that parameter's Adam moments (registers) and writes the updated tap to LDS.
-//   * reductions (sum |e|^2, KL) are fixed-order xor butterflies: bitwise reproducible.
+//     with a gradient also owns that parameter's Adam moments (LDS rows of their own) and writes the updated tap to LDS.
+//   * every 8-byte LDS read is pinned to one ds_read_b64 (lds2), the tap loops are two-deep software pipelines (pipe2) whose first
+//     term starts the accumulators; streamed rows go through buffer descriptors (scalar row offsets, out-of-range offsets as masks).
+//   * wave sums and prefix scans run on DPP in a fixed order: bitwise reproducible, no LDS round trips.
+//   (DESIGN.md section 5 has the measurements behind each of these.)
 //
 // Supported here: sps == 2, B even, 2*(M/2)+2 <= B <= 1024, M in {9, 13, 17, 21, 25, 31}; everything else takes the
 // generic kernel of vaeq_dp.hip.  BT > 0 bakes the minibatch length into the kernel (all LDS offsets immediate).
@@ -42,6 +45,13 @@
 #define VAEQ_XSTAMP(i) do { } while (0)
 #endif
 #define VAEQ_NSTAMP 12
+// Experiment knobs of tools/snap_variant.sh builds (the defaults are what ships): software pipelining of the tap loops / of dL/dU
+#ifndef VAEQ_PIPE
+#define VAEQ_PIPE 1
+#endif
+#ifndef VAEQ_PIPE_DU
+#define VAEQ_PIPE_DU 0
+#endif
 #ifndef VAEQ_WPS
 #define VAEQ_WPS 2                                     // workgroups per SIMD the register budget is sized for (3 would need <= 168 VGPRs: it spills)
 #endif
@@ -206,12 +216,6 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
     constexpr int NT = 64 * NW, NP = 2 * NW;              // threads per run; parts a tap-gradient sum is split into
     // baked shape whose tap-gradient sums split into NP equal, non-empty parts: their loops run on a scalar trip count and start from the first term
     constexpr bool UNI = BT > 0 && uniform_parts(BT, M, NP);
-#ifndef VAEQ_PIPE_DU
-#define VAEQ_PIPE_DU 0
-#endif
-#ifndef VAEQ_PIPE
-#define VAEQ_PIPE 1
-#endif
     constexpr bool PIPE = VAEQ_PIPE && BT > 0;             // run-time minibatch lengths keep more addresses live: there one operand set,
     constexpr bool WIDE = BT > 0;                          // ... 8 accumulator chains and one chi at a time in dL/dU (fits the register file)
     constexpr bool PIPE_DU = VAEQ_PIPE_DU;                 // dL/dU runs at the kernel's register peak (moments of the demapper still live): no second operand set there
