@@ -41,6 +41,8 @@ def test_bench_line_contract():
     c4, c2 = e["configs"]["config4_vaeflex"], e["configs"]["config2_awgn"]
     assert c4["kernel"].startswith("vaeq::dp_wave_kernel<25, 8, ") and c4["value"] > 0 and 0 < c4["flop_frac"] < 1
     assert c2["kernel"].startswith("vaeq::awgn_wave_kernel<25, 8, 3, 1>") and c2["value"] > 0 and 0 < c2["flop_frac"] < 1
+    ep = c2["epoch_pipeline"]
+    assert ep["ms_train_part"] > 0 and ep["ms_validation_part"] > ep["ms_train_part"] and ep["run_epochs_per_s_epe2"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "2170" in cb["sample"] and cb["reference_dp_symbols_per_s"] == 2170.0
 
