@@ -241,11 +241,18 @@ int vaeq_gen_dp_disperse(int32_t R, int32_t Ls, double fs, double tau_cd, double
 int vaeq_gen_dp_finish(int32_t R, int32_t N, int32_t sps, int32_t Ls, int32_t Lrow, const float *snr_db, uint64_t seed, uint32_t frame,
                        const float *sig_complex, float *power_ws, float *rx, float *sigma_out, void *stream);
 
-/* The three stages and both transforms of one DP frame in ONE call (hipFFT in place on sig_ws[R][2][Lrow] complex64, plans cached
- * per (Lrow, R)); same arguments as the stage entry points, e_k = exp(-j phiIQ[k]), fs = symb_rate * sps.
- * power_ws: [R][2 * ceil(Lrow / 2048)] floats -- for sps == 2 stage 1 leaves its tiles' sums of |sig|^2 there and the noise level (:83) is derived
- * from them: the fibre's transfer matrix is unitary at every frequency (:38-54), the dispersed signal has the power of the undispersed one,
- * so no pass over the dispersed signal is spent on it (other sps: the first R floats, filled by a power pass as in vaeq_gen_dp_finish). */
+/* One DP frame in ONE call; same arguments as the stage entry points, e_k = exp(-j phiIQ[k]), fs = symb_rate * sps.  sig_ws[R][2][Lrow]
+ * complex64 is scratch.  Two implementations of the same model, same Philox words (results agree to transform rounding):
+ *   fused   sps == 2 and Lrow = N1 * 1024 with N1 in {4, 5, 8, 10, 16, 20} (the default frame pads to 20 * 1024): three passes over the signal --
+ *           pulse shaping + the N1-point outer DFT stage in registers; per (run, k1) one wavefront: 1024-point FFT, fibre matrix, inverse FFT
+ *           (rows through LDS, in place); inverse outer stage + noise + planar split.  No hipFFT.  Twiddles and the per-frequency phases of the
+ *           fibre live in library-owned device tables, built once per (device, Lrow, fs, tau_cd, tau_pmd) and immutable afterwards.
+ *   staged  any other shape (or env VAEQ_GEN_STAGED=1): the three stage kernels around in-place hipFFT transforms, plans cached per (Lrow, R).
+ * power_ws: [R][vaeq_gen_dp_power_parts(Lrow)] floats -- for sps == 2 the first pass leaves partial sums of |sig|^2 there and the noise level
+ * (:83) is derived from them: the fibre's transfer matrix is unitary at every frequency (:38-54), the dispersed signal has the power of the
+ * undispersed one, so no pass over the dispersed signal is spent on it (other sps: the first R floats, filled by a power pass as in
+ * vaeq_gen_dp_finish). */
+int32_t vaeq_gen_dp_power_parts(int32_t Lrow);               /* max(8, 2 * ceil(Lrow / 2048)) */
 int vaeq_gen_dp_frame(int32_t R, int32_t N, int32_t N_conv, int32_t sps, int32_t n_lev, int32_t Lg, int32_t Ls, int32_t Lrow,
                       int32_t ref_offset, const float *amp, const float *cdf, const float *g_complex, const float *snr_db,
                       const float *theta, double fs, double tau_cd, double tau_pmd, float e0_re, float e0_im, float e1_re, float e1_im,

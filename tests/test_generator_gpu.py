@@ -1,5 +1,7 @@
 """HIP channel generator (vaeq_gen_dp_*, row f1) against the numpy restatement of the reference's generator chain, fed with the
 same Philox symbol stream (reproduced on the host), plus noise statistics."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -101,6 +103,59 @@ def test_hip_generator_padded_fft_differs_only_at_the_frame_edges():
     assert np.max(np.abs(e - p)[..., 64:-64]) < 1e-3 * scale                   # interior: equal up to the tails of the response
     assert np.max(np.abs(e - p)) < 0.5 * scale                                 # edges: wrapped-around vs. absent neighbours
     assert ch.fast_fft_len(20034 + 64) == 20480 and ch.fast_fft_len(1024) == 1024 and ch.fast_fft_len(1025) == 1280
+
+
+@pytest.mark.parametrize("n1", [4, 5, 8, 10, 16, 20])
+def test_fused_frame_matches_staged_chain(n1, monkeypatch):
+    """vaeq_gen_dp_frame's three-pass form (pulse shaping + outer DFT stage | per-row 1024-point FFT, fibre matrix, inverse FFT | inverse outer
+    stage + noise) against the five-pass hipFFT chain it replaces: same symbols and TX reference bit for bit, the same noise words, the clean
+    signal to transform rounding -- for every row length N1 * 1024 the fused form covers, with per-run rotation angles, SNRs and shaping."""
+    sps, seed, frame, R = 2, 5, 3, 6
+    h_est, h_ch, P, amp_levels, amps, pol, nu_sc, var, pow_mean = sfun.init("h1", "64-QAM", "cpu", 0.0270955, sps, 25, 23)
+    N = (1024 * n1 - 64 - ch.dp_frame_geometry(100, h_ch, sps)["Ls"] + 200) // 2       # the longest frame whose padded row is N1 * 1024
+    geo = ch.dp_frame_geometry(N, h_ch, sps)
+    assert ch.fast_fft_len(geo["Ls"] + 64) == 1024 * n1 and geo["Ls"] + 64 >= 1024 * n1 - 1
+    Pr = np.stack([P if r % 2 == 0 else np.full_like(P, 1 / len(P)) for r in range(R)])
+    theta = np.linspace(-1.2, 2.9, R)
+    SNR = np.linspace(14.0, 30.0, R).astype(np.float32)
+    args = (R, N, amps, Pr, SNR, h_ch, DP["symb_rate"], sps, DP["tau_cd"], DP["tau_pmd"], DP["phiIQ"], theta, "cuda:0", seed, frame)
+    monkeypatch.delenv("VAEQ_GEN_STAGED", raising=False)
+    rxf, df, sf = ch.generate_batch_hip(*args, return_sigma=True)
+    rxf2, _ = ch.generate_batch_hip(*args)
+    assert torch.equal(rxf, rxf2)                                              # deterministic
+    monkeypatch.setenv("VAEQ_GEN_STAGED", "1")
+    rxs, ds, ss = ch.generate_batch_hip(*args, return_sigma=True)
+    assert torch.equal(df, ds)
+    assert torch.allclose(sf, ss, rtol=2e-6, atol=0)
+    scale = float(rxs.abs().max())
+    assert float((rxf - rxs).abs().max()) < 1e-5 * scale
+    # noiseless: the clean signals alone agree to transform rounding
+    args200 = args[:4] + (200.0,) + args[5:]
+    clean_s, _ = ch.generate_batch_hip(*args200)
+    monkeypatch.delenv("VAEQ_GEN_STAGED")
+    clean_f, _ = ch.generate_batch_hip(*args200)
+    assert float((clean_f - clean_s).abs().max()) < 1e-5 * float(clean_s.abs().max())
+    assert float((clean_f - clean_s).abs().mean()) < 1e-6 * float(clean_s.abs().max())
+
+
+def test_fused_frame_long_pulse_and_last_stripe_ownership():
+    """A combined pulse longer than 64 taps: symbols past Lrow / 2 exist and are owned by the last stripe's halo; chunked runs keep their streams."""
+    sps, seed, frame, R = 2, 9, 1, 3
+    h_est, h_ch, P, amp_levels, amps, pol, nu_sc, var, pow_mean = sfun.init("h1", "16-QAM", "cpu", 0.0, sps, 25, 23)
+    h_long = np.concatenate([np.asarray(h_ch), 0.05 * np.exp(1j * np.arange(50))]).astype(np.complex64)
+    N = (1024 * 4 - 64 - ch.dp_frame_geometry(100, h_long, sps)["Ls"] + 200) // 2
+    geo = ch.dp_frame_geometry(N, h_long, sps)
+    assert geo["Lg"] > 64 and ch.fast_fft_len(geo["Ls"] + 64) == 4096
+    args = (R, N, amps, P, 21.0, h_long, DP["symb_rate"], sps, DP["tau_cd"], DP["tau_pmd"], DP["phiIQ"], np.array([0.1, 0.5, 2.0]), "cuda:0", seed, frame)
+    os.environ.pop("VAEQ_GEN_STAGED", None)
+    rxf, df = ch.generate_batch_hip(*args)
+    os.environ["VAEQ_GEN_STAGED"] = "1"
+    try:
+        rxs, ds = ch.generate_batch_hip(*args)
+    finally:
+        os.environ.pop("VAEQ_GEN_STAGED", None)
+    assert torch.equal(df, ds)
+    assert float((rxf - rxs).abs().max()) < 1e-5 * float(rxs.abs().max())
 
 
 def test_generated_frames_train():

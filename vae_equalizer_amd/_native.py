@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("VAEQ_LIB") or os.path.join(_PKG, "libvaeq_hip.so")   # VAEQ_LIB: A/B builds of the kernels (tools/build_variant.sh)
 SOURCES = ["vaeq_dp.hip", "vaeq_dp_wave.hip", "vaeq_dp_wave_mw.hip", "vaeq_dp_wave_mw8.hip", "vaeq_awgn.hip", "vaeq_awgn_wave.hip", "vaeq_misc.hip", "vaeq_nn.hip", "vaeq_cma.hip", "vaeq_epilogue.hip", "vaeq_gen.hip"]
-HEADERS = ["vaeq_common.h", "vaeq_wave.h", "vaeq_validate.h", "vaeq_dp_wave_kernel.h"]
+HEADERS = ["vaeq_common.h", "vaeq_wave.h", "vaeq_validate.h", "vaeq_dp_wave_kernel.h", "vaeq_gen_fused.h"]
 _LIB = None
 
 
@@ -104,7 +104,7 @@ class NNArgs(C.Structure):
 
 # every symbol include/vaeq.h declares; tests check the library exports all of them
 EXPORTS = ["vaeq_dp_train", "vaeq_dp_lds_bytes", "vaeq_dp_resident_runs", "vaeq_soft_demap", "vaeq_dp_forward", "vaeq_dp_loss", "vaeq_dp_loss_bwd", "vaeq_dp_forward_bwd", "vaeq_dp_epilogue", "vaeq_dp_epilogue_ws_bytes", "vaeq_dp_epilogue_compact", "vaeq_gen_dp_tx", "vaeq_gen_dp_disperse", "vaeq_gen_dp_finish", "vaeq_gen_dp_frame", "vaeq_awgn_train",
-           "vaeq_awgn_lds_bytes", "vaeq_awgn_forward", "vaeq_awgn_validate", "vaeq_awgn_loss", "vaeq_awgn_loss_bwd", "vaeq_awgn_forward_bwd", "vaeq_gen_awgn", "vaeq_nn_train", "vaeq_nn_param_count", "vaeq_nn_lds_bytes", "vaeq_nn_forward", "vaeq_nn_validate", "vaeq_cma", "vaeq_cpe", "vaeq_version", "vaeq_strerror", "vaeq_last_kernel", "vaeq_stream_copy"]
+           "vaeq_awgn_lds_bytes", "vaeq_awgn_forward", "vaeq_awgn_validate", "vaeq_awgn_loss", "vaeq_awgn_loss_bwd", "vaeq_awgn_forward_bwd", "vaeq_gen_awgn", "vaeq_nn_train", "vaeq_nn_param_count", "vaeq_nn_lds_bytes", "vaeq_nn_forward", "vaeq_nn_validate", "vaeq_cma", "vaeq_cpe", "vaeq_version", "vaeq_strerror", "vaeq_last_kernel", "vaeq_stream_copy", "vaeq_gen_dp_power_parts"]
 
 
 def lib():
@@ -177,6 +177,8 @@ def lib():
         L.vaeq_awgn_forward_bwd.argtypes = [C.c_int32] * 5 + [C.c_void_p] * 9
         L.vaeq_nn_validate.restype = C.c_int
         L.vaeq_nn_validate.argtypes = [C.c_int32, C.c_int64] + [C.c_int32] * 6 + [C.c_void_p] * 8
+        L.vaeq_gen_dp_power_parts.restype = C.c_int32
+        L.vaeq_gen_dp_power_parts.argtypes = [C.c_int32]
         L.vaeq_gen_dp_frame.restype = C.c_int
         L.vaeq_gen_dp_frame.argtypes = ([C.c_int32] * 9 + [C.c_void_p] * 5 + [C.c_double] * 3 + [C.c_float] * 4 + [C.c_uint64, C.c_uint32]
                                         + [C.c_void_p] * 6)

@@ -272,7 +272,7 @@ def generate_batch_hip(R, N, amps, P, SNR, h_channel, symb_rate, sps, tau_cd, ta
             r1 = min(R, r0 + chunk)
             Rc = r1 - r0
             sig = torch.empty(Rc, 2, Lrow, 2, dtype=torch.float32, device=dev)
-            pw = torch.empty(Rc, 2 * ((Lrow + 2047) // 2048), dtype=torch.float32, device=dev)   # stage 1's per-tile sums of |sig|^2
+            pw = torch.empty(Rc, L.vaeq_gen_dp_power_parts(Lrow), dtype=torch.float32, device=dev)   # the first pass's partial sums of |sig|^2
             # runs inside a chunk are told apart by the run counter word of the Philox streams, chunks by the key (_mix_seed)
             nat.check(L.vaeq_gen_dp_frame(Rc, N, geo["N_conv"], sps, n, geo["Lg"], geo["Ls"], Lrow, geo["ref_offset"], nat.ptr(amp_t),
                                           nat.ptr(cdf[r0:r1].contiguous()), nat.ptr(g_t), nat.ptr(snr[r0:r1].contiguous()),

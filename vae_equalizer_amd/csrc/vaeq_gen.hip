@@ -17,8 +17,11 @@
 #include <hipfft/hipfft.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 #include <map>
 #include <mutex>
+#include <tuple>
 #include <utility>
 
 #include "vaeq.h"
@@ -362,6 +365,8 @@ static void launch_finish(int R, int npol, int N, int sps, int Ls, int Lrow, con
 
 }  // namespace vaeq
 
+#include "vaeq_gen_fused.h"
+
 static bool tx_shape_ok(int R, int N, int N_conv, int sps, int n_lev, int Lg, int Ls, int Lrow, int ref_offset)
 {
     if (R < 0 || N <= 0 || sps <= 0 || Lg <= 0 || Lg > vaeq::TX_MAXG || !(n_lev == 2 || n_lev == 4 || n_lev == 8) || ref_offset < 0) return false;
@@ -455,6 +460,71 @@ static int get_plan(int Lrow, int batch, hipfftHandle *out)
 }
 }  // namespace vaeq
 
+// ---- the fused three-pass frame (vaeq_gen_fused.h): tables cached per (device, row length, fibre parameters), immutable once built
+namespace vaeq {
+struct FusedTables { float2 *T; float4 *H; };
+struct FusedKey {
+    int dev, Lrow;
+    double fs, tau_cd, tau_pmd;
+    bool operator<(const FusedKey &o) const { return std::tie(dev, Lrow, fs, tau_cd, tau_pmd) < std::tie(o.dev, o.Lrow, o.fs, o.tau_cd, o.tau_pmd); }
+};
+static std::mutex g_fused_mu;
+static std::map<FusedKey, FusedTables> g_fused;
+
+static bool fused_rows(int Lrow) { return Lrow == 4096 || Lrow == 5120 || Lrow == 8192 || Lrow == 10240 || Lrow == 16384 || Lrow == 20480; }
+
+static int get_fused_tables(int Lrow, double fs, double tau_cd, double tau_pmd, hipStream_t st, FusedTables *out)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return VAEQ_ERR_DEVICE;
+    std::lock_guard<std::mutex> lk(g_fused_mu);
+    const FusedKey key{dev, Lrow, fs, tau_cd, tau_pmd};
+    auto it = g_fused.find(key);
+    if (it == g_fused.end()) {
+        if (g_fused.size() >= 64) {                            // a sweep over many fibre parameter sets: start over (nothing in flight may use them)
+            if (hipDeviceSynchronize() != hipSuccess) return VAEQ_ERR_DEVICE;
+            for (auto &kv : g_fused) { (void)hipFree(kv.second.T); (void)hipFree(kv.second.H); }
+            g_fused.clear();
+        }
+        FusedTables t{nullptr, nullptr};
+        if (hipMalloc(&t.T, sizeof(float2) * Lrow) != hipSuccess || hipMalloc(&t.H, sizeof(float4) * Lrow) != hipSuccess) {
+            (void)hipFree(t.T);
+            return VAEQ_ERR_DEVICE;
+        }
+        hipLaunchKernelGGL(genf_twiddle_kernel, dim3((Lrow + 255) / 256), dim3(256), 0, st, Lrow, t.T);
+        hipLaunchKernelGGL(genf_phase_kernel, dim3((Lrow + 255) / 256), dim3(256), 0, st, Lrow, Lrow / 1024, fs / (double)Lrow, tau_cd, tau_pmd,
+                           1.0f / (float)Lrow, t.H);
+        if (hipStreamSynchronize(st) != hipSuccess) {          // from here on the tables are read-only: any stream may use them
+            (void)hipFree(t.T); (void)hipFree(t.H);
+            return VAEQ_ERR_DEVICE;
+        }
+        it = g_fused.emplace(key, t).first;
+    }
+    *out = it->second;
+    return VAEQ_OK;
+}
+
+template <int N1>
+static void launch_fused(int R, int N, int N_conv, int n_lev, int Lg, int Ls, int ref_offset, const float *amp, const float *cdf, const float2 *g,
+                         const float *snr_db, const float *theta, float2 E00, float2 E01, float2 E11, uint64_t seed, uint32_t frame, float2 *sig,
+                         float *power_ws, float *rx, __half *data, float *sigma_out, const FusedTables &tb, hipStream_t st)
+{
+    hipLaunchKernelGGL(genf_tx_kernel<N1>, dim3(4, 2, R), dim3(GF_NT), 0, st, N_conv, n_lev, Lg, Ls, amp, cdf, g, seed, frame, sig, N, ref_offset, data,
+                       power_ws);
+    hipLaunchKernelGGL(gen_sigma_kernel, dim3((R + 255) / 256), dim3(256), 0, st, R, GF_PARTS, 2, Ls, 2, snr_db, power_ws);
+    const int rpw = R >= 4096 ? 4 : R >= 1024 ? 2 : 1;       // runs per wavefront: amortises the wave's twiddle set-up once the chip is full
+    hipLaunchKernelGGL(genf_fft_kernel<N1>, dim3((R + 4 * rpw - 1) / (4 * rpw), N1), dim3(256), 0, st, R, rpw, tb.T, tb.H, E00, E01, E11, theta, sig);
+    hipLaunchKernelGGL(genf_finish_kernel<N1>, dim3(4, 2, R), dim3(GF_NT), 0, st, 2 * N, power_ws, GF_PARTS, seed, frame, sig, rx, sigma_out);
+}
+}  // namespace vaeq
+
+extern "C" int32_t vaeq_gen_dp_power_parts(int32_t Lrow)
+{
+    if (Lrow <= 0) return VAEQ_ERR_SHAPE;
+    const int staged = 2 * ((Lrow + vaeq::TX_TILE - 1) / vaeq::TX_TILE);
+    return staged > vaeq::GF_PARTS ? staged : vaeq::GF_PARTS;
+}
+
 extern "C" int vaeq_gen_dp_frame(int32_t R, int32_t N, int32_t N_conv, int32_t sps, int32_t n_lev, int32_t Lg, int32_t Ls, int32_t Lrow,
                                  int32_t ref_offset, const float *amp, const float *cdf, const float *g_complex, const float *snr_db,
                                  const float *theta, double fs, double tau_cd, double tau_pmd, float e0_re, float e0_im, float e1_re,
@@ -466,6 +536,30 @@ extern "C" int vaeq_gen_dp_frame(int32_t R, int32_t N, int32_t N_conv, int32_t s
     if (!tx_shape_ok(R, N, N_conv, sps, n_lev, Lg, Ls, Lrow, ref_offset)) return VAEQ_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     float2 *sig = reinterpret_cast<float2 *>(sig_ws);
+    const char *staged_env = getenv("VAEQ_GEN_STAGED");      // A/B switch: the five-pass hipFFT chain for every row length
+    if (sps == 2 && vaeq::fused_rows(Lrow) && !(staged_env && staged_env[0] == '1')) {
+        vaeq::FusedTables tb;
+        const int rc = vaeq::get_fused_tables(Lrow, fs, tau_cd, tau_pmd, st, &tb);
+        if (rc != VAEQ_OK) return rc;
+        // E00 = e0^2, E01 = e0 e1, E11 = e1^2: with u = c a + s b, v = c b - s a (c, s = cos, sin theta) and d = e^{j pi f tau_pmd} the fibre matrix
+        // R^T diag(d, d*) R of shared_funcs.py:47-52 applied to (a, b) is (c E00 d u - s E01 d* v,  s E01 d u + c E11 d* v)
+        const float2 e0 = make_float2(e0_re, e0_im), e1 = make_float2(e1_re, e1_im);
+        auto hmul = [](float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); };
+        const float2 E00 = hmul(e0, e0), E01 = hmul(e0, e1), E11 = hmul(e1, e1);
+        const float2 *g2 = reinterpret_cast<const float2 *>(g_complex);
+        __half *data = reinterpret_cast<__half *>(data_f16);
+#define VAEQ_FUSED(N1) vaeq::launch_fused<N1>(R, N, N_conv, n_lev, Lg, Ls, ref_offset, amp, cdf, g2, snr_db, theta, E00, E01, E11, seed, frame, sig, power_ws, rx, data, sigma_out, tb, st)
+        switch (Lrow / 1024) {
+        case 4: VAEQ_FUSED(4); break;
+        case 5: VAEQ_FUSED(5); break;
+        case 8: VAEQ_FUSED(8); break;
+        case 10: VAEQ_FUSED(10); break;
+        case 16: VAEQ_FUSED(16); break;
+        default: VAEQ_FUSED(20); break;
+        }
+#undef VAEQ_FUSED
+        return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+    }
     hipfftHandle plan;
     const int rc = vaeq::get_plan(Lrow, 2 * R, &plan);
     if (rc != VAEQ_OK) return rc;
