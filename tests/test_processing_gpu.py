@@ -396,8 +396,8 @@ def test_config5_grid_one_batch_on_one_gpu(tmp_path, monkeypatch):
     t0 = time.time()
     name, d = ev.main()
     wall = time.time() - t0
-    print(f"config 5: 300 runs x 170 frames x 10 000 symbols in {wall:.1f} s on one GPU (first call of the process: library / hipFFT plan / module loads "
-          "included; a second call takes 0.4 s = 2.3 ms per frame, tools/probe_config5_profile.py)")
+    print(f"config 5: 300 runs x 170 frames x 10 000 symbols in {wall:.1f} s on one GPU (first call of the process: library / module loads included; a second call "
+          "takes 0.4 s = 2.3 ms per frame, tools/probe_config5_profile.py)")
     m = io.loadmat(name)["dict"]
     assert m["SER"][0, 0].shape == (4, 5, 1, 4, 1, 1, 3, 1, 1, 1, 5, 170) and m["Var_est"][0, 0].shape == (2, 5, 1, 4, 1, 1, 3, 1, 1, 1, 5, 170)
     assert m["var_real"][0, 0].shape == (2, 5, 1, 4, 1, 1, 3, 1, 1, 1, 5, 1)
@@ -405,13 +405,17 @@ def test_config5_grid_one_batch_on_one_gpu(tmp_path, monkeypatch):
     S, V = d["SER"], d["Var_est"]
     assert np.isfinite(S).all() and np.isfinite(V).all() and wall < 120
     tail = lambda A, s, n: A[:, s, 0, n, 0, 0, :, 0, 0, 0, :, -30:].mean(-1)             # [rows, lr, iter]: mean over the last 30 frames
-    # light shaping locks in every run; SER falls with the SNR down to the floor the 0.06 pi/frame drift leaves (reached at ~26 dB)
+    # light shaping locks; SER falls with the SNR down to the floor the 0.06 pi/frame drift leaves (reached at ~26 dB).  About one run in a thousand
+    # ends in the blind equaliser's polarisation singularity instead (both outputs on one polarisation: one polarisation's rows stay at ~0.93) --
+    # 1 of 1200 with either form of the frame generator, at different seeds (profiles/r02_final/lock_rate_probe.txt) -- so lock is asserted for all
+    # but at most two of the 150 runs and the statistics are taken over the locked ones
+    lock = {n: np.array([(tail(S, s, n) < 0.2).all(0) for s in range(5)]) for n in (0, 1)}               # [SNR, lr, iter]
+    assert sum(int((~lock[n]).sum()) for n in (0, 1)) <= 2, {n: np.argwhere(~lock[n]) for n in (0, 1)}
     for n in (0, 1):
-        ser = np.array([tail(S, s, n).mean() for s in range(5)])
-        assert (np.array([tail(S, s, n).max() for s in range(5)]) < 0.2).all(), ser
+        ser = np.array([tail(S, s, n)[:, lock[n][s]].mean() for s in range(5)])
         assert ser[0] > 1.5 * ser[1] > 1.5 * 1.2 * ser[2] and (ser[3:] < 1.25 * ser[2]).all() and (ser[3:] > 0.3 * ser[2]).all(), ser
-        assert np.array([tail(V, s, n).mean() for s in range(5)]).argsort().tolist() == [4, 3, 2, 1, 0]      # noise estimate falls with the SNR
-    assert tail(S, 0, 1).mean() < 0.5 * tail(S, 0, 0).mean()                             # H = 5.72 bit needs fewer errors at equal SNR
+        assert np.array([tail(V, s, n)[:, lock[n][s]].mean() for s in range(5)]).argsort().tolist() == [4, 3, 2, 1, 0]      # noise estimate falls with the SNR
+    assert tail(S, 0, 1)[:, lock[1][0]].mean() < 0.5 * tail(S, 0, 0)[:, lock[0][0]].mean()       # H = 5.72 bit needs fewer errors at equal SNR
     # heavy shaping: (nearly) no run locks within the 170 frames, at any SNR -- the escape from the plateau is chaotic, one run in 150 has been seen
     # to lock (SER 0.003) with one build of the kernel and none with another, and the reference's four captured runs do not
     locked = {n: np.array([(tail(S, s, n) < 0.2).all(0).ravel() for s in range(5)]) for n in (2, 3)}     # [SNR, lr * iter]

@@ -126,14 +126,18 @@ __device__ __forceinline__ void dft_small(v2f (&x)[N])
 // W_64^{c u}, [exchange] DFT-4 over c.  xb: this wave's 1088-element LDS slice (rows of 64 padded to 68: both exchanges conflict-free);
 // LDS operations of one wave execute in order, so the exchanges need no barrier -- only the compiler must keep them in order.
 constexpr int GF_XB = 16 * 68;
+#ifndef GF_FFT_WAVES
+#define GF_FFT_WAVES 3
+#endif
 template <bool INV>
-__device__ __forceinline__ void fft1024_wave(v2f (&v)[16], const v2f (&tw1)[16], float2 *xb, const float2 *w64, int l)
+__device__ __forceinline__ void fft1024_wave(v2f (&v)[16], const float2 *tw1 /* [16][64]: W_1024^{l p} at [p][l] */, float2 *xb, const float2 *w64, int l)
 {
     dft_comp<4, 4, INV>(v);
     wave_lds_sync();
 #pragma unroll
     for (int p = 0; p < 16; p++) {
-        const v2f t = p == 0 ? v[0] : (INV ? cmulc(v[p], tw1[p]) : cmulv(v[p], tw1[p]));
+        const v2f w = lds2(tw1 + p * 64 + l);
+        const v2f t = p == 0 ? v[0] : (INV ? cmulc(v[p], w) : cmulv(v[p], w));
         xb[p * 68 + l] = make_float2(t.x, t.y);
     }
     wave_lds_sync();
@@ -197,12 +201,14 @@ __global__ __launch_bounds__(GF_NT) void genf_tx_kernel(int N_conv, int n_lev, i
     constexpr int Lrow = N1 * 1024;
     __shared__ float2 symL[N1][GF_SW];
     __shared__ float2 gl[2][GF_JT + 1];
-    __shared__ float cdf[8];
     __shared__ float amps[8];
     __shared__ float red[64];
     const int run = blockIdx.z, pol = blockIdx.y, bq = blockIdx.x, tid = threadIdx.x;
     const int JT = (Lg + 1) / 2;                                               // sample s = 2 h + par: sig[s] = sum_j sym[h + par + j] g[Lg-1-par-2j]
-    if (tid < n_lev) { cdf[tid] = cdf_g[(size_t)run * n_lev + tid]; amps[tid] = amp[tid]; }
+    if (tid < n_lev) amps[tid] = amp[tid];
+    float cdf7[7];                                                             // uniform (scalar registers): thresholds past n_lev - 1 never fire
+#pragma unroll
+    for (int i = 0; i < 7; i++) cdf7[i] = i < n_lev - 1 ? cdf_g[(size_t)run * n_lev + i] : 2.0f;
     for (int i = tid; i < 2 * (GF_JT + 1); i += GF_NT) {
         const int par = i / (GF_JT + 1), j = i - par * (GF_JT + 1), k = Lg - 1 - par - 2 * j;
         gl[par][j] = (k >= 0 && j < JT) ? g[k] : make_float2(0.f, 0.f);
@@ -210,11 +216,21 @@ __global__ __launch_bounds__(GF_NT) void genf_tx_kernel(int N_conv, int n_lev, i
     __syncthreads();
     const int cnt = 128 + JT + 1, PP = (cnt + 1) / 2;                          // symbols a stripe's 256 samples touch (<= GF_SW), in pairs
     __half *dI = data ? data + ((size_t)(run * 2 + pol) * 2 + 0) * N : nullptr, *dQ = dI ? dI + N : nullptr;
+    const float rPP = 1.0f / (float)PP;
     for (int q = tid; q < N1 * PP; q += GF_NT) {
-        const int n1 = q / PP, pi = q - n1 * PP, n = 512 * n1 + 128 * bq + 2 * pi;
+        const int n1 = (int)(((float)q + 0.5f) * rPP), pi = q - n1 * PP, n = 512 * n1 + 128 * bq + 2 * pi;   // exact: q < 2^12, PP < 2^8
         const bool last = n1 == N1 - 1 && bq == 3;
         int lv[4];
-        draw_symbol_pair(seed, frame, run, pol, (uint32_t)n, cdf, n_lev, lv);
+        {                                                                      // draw_symbol_pair, branch-free
+            const Philox4 r = philox4x32_10((uint32_t)n >> 1, run, frame, (uint32_t)(STREAM_SYMBOLS * 2 + pol), (uint32_t)seed, (uint32_t)(seed >> 32));
+            const float u[4] = {u01(r.x), u01(r.y), u01(r.z), u01(r.w)};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                lv[c] = 0;
+#pragma unroll
+                for (int i = 0; i < 7; i++) lv[c] += u[c] >= cdf7[i];
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             const int ne = n + e, m = 2 * pi + e;
@@ -263,24 +279,22 @@ __global__ __launch_bounds__(GF_NT) void genf_tx_kernel(int N_conv, int n_lev, i
 
 // ---- pass B ------------------------------------------------------------------------------------------------------------------------------
 template <int N1>
-__global__ __launch_bounds__(256) void genf_fft_kernel(int R, int rpw, const float2 *__restrict__ T, const float4 *__restrict__ H, float2 E00,
+__global__ __launch_bounds__(256, GF_FFT_WAVES) void genf_fft_kernel(int R, int rpw, const float2 *__restrict__ T, const float4 *__restrict__ H, float2 E00,
                                                        float2 E01, float2 E11, const float *__restrict__ theta, float2 *__restrict__ sig)
 {
     constexpr int Lrow = N1 * 1024;
     __shared__ float2 xbs[4][GF_XB];
     __shared__ float2 w64[64];
+    __shared__ float2 tw1[16 * 64];                                            // W_1024^{l p} at [p][l]: lane-contiguous reads
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, k1 = blockIdx.y;
     if (tid < 64) w64[tid] = T[N1 * 16 * tid];                                 // W_64^t
+    __shared__ float2 twio[16 * 64];                                           // W_L^{k1 (l + 64 r)} at [r][l]: the seam between the N1- and the 1024-point stage
+    for (int i = tid; i < 16 * 64; i += 256) {
+        tw1[i] = T[N1 * (((i & 63) * (i >> 6)) & 1023)];
+        twio[i] = T[k1 * ((i & 63) + 64 * (i >> 6))];                          // k1 * 1023 < L
+    }
     __syncthreads();
     float2 *xb = xbs[wv];
-    v2f tw1[16];                                                               // W_1024^{l p}
-#pragma unroll
-    for (int p = 0; p < 16; p++) {
-        const float2 t = T[N1 * ((l * p) & 1023)];
-        tw1[p] = v2f{t.x, t.y};
-    }
-    const float2 wlf = T[k1 * l];                                              // W_L^{k1 (l + 64 r)} = W_L^{k1 l} W_L^{64 k1 r}
-    const v2f wl = {wlf.x, wlf.y};
     const float4 *Hr = H + k1 * 1024 + l;
     const int r0 = (blockIdx.x * 4 + wv) * rpw, r1 = min(R, r0 + rpw);
     for (int run = r0; run < r1; run++) {
@@ -297,28 +311,34 @@ __global__ __launch_bounds__(256) void genf_fft_kernel(int R, int rpw, const flo
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const float2 wsf = T[64 * k1 * r];                                 // uniform: scalar loads
-            const v2f tw = cmulv(wl, v2f{wsf.x, wsf.y});
+            const v2f tw = lds2(twio + 64 * r + l);
             a[r] = cmulv(a[r], tw);
             b[r] = cmulv(b[r], tw);
         }
         fft1024_wave<false>(a, tw1, xb, w64, l);
         fft1024_wave<false>(b, tw1, xb, w64, l);
+        wave_lds_sync();                                                       // (compiler fence: the table loads below stay below the transforms)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {                                         // frequency k1 + N1 (l + 64 r)
-            const float4 h = Hr[64 * r];
-            const v2f d = {h.x, h.y}, ecd = {h.z, h.w};
-            const v2f u = ct * a[r] + st * b[r], w = ct * b[r] - st * a[r];
-            const v2f p = cmulv(u, d), q = cmulc(w, d);
-            a[r] = cmulv(cmulv(c00, p) - cmulv(c01, q), ecd);
-            b[r] = cmulv(cmulv(c01, p) + cmulv(c11, q), ecd);
+        for (int r4 = 0; r4 < 16; r4 += 4) {                                   // frequency k1 + N1 (l + 64 r), four at a time
+            float4 h[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) h[i] = Hr[64 * (r4 + i)];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = r4 + i;
+                const v2f d = {h[i].x, h[i].y}, ecd = {h[i].z, h[i].w};
+                const v2f u = ct * a[r] + st * b[r], w = ct * b[r] - st * a[r];
+                const v2f p = cmulv(u, d), q = cmulc(w, d);
+                a[r] = cmulv(cmulv(c00, p) - cmulv(c01, q), ecd);
+                b[r] = cmulv(cmulv(c01, p) + cmulv(c11, q), ecd);
+            }
+            wave_lds_sync();
         }
         fft1024_wave<true>(a, tw1, xb, w64, l);
         fft1024_wave<true>(b, tw1, xb, w64, l);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const float2 wsf = T[64 * k1 * r];
-            const v2f tw = cmulv(wl, v2f{wsf.x, wsf.y});
+            const v2f tw = lds2(twio + 64 * r + l);
             const v2f ao = cmulc(a[r], tw), bo = cmulc(b[r], tw);
             p0[64 * r] = make_float2(ao.x, ao.y);
             p1[64 * r] = make_float2(bo.x, bo.y);
