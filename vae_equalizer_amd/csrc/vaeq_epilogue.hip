@@ -15,13 +15,19 @@
 
 #include "vaeq.h"
 #include "vaeq_common.h"
+#include "vaeq_wave.h"
 
 namespace vaeq {
 
+#ifndef EPI_WAVES
+#define EPI_WAVES 6
+#endif
 constexpr int EPI_NT = 256, N_SHIFT = 21, HALF_SHIFT = 10, N_CUT = 10, EDGE = 11;
-constexpr int N_CHUNK = EPI_NT / 8;           // thread = (E-polarisation b, TX row ac = (a, c), chunk): 2 x 4 x 32
-constexpr int EPI_CH = N_SHIFT;               // symbols per chunk and tile: one full rotation of the 21-entry lag window
-constexpr int EPI_TILE = N_CHUNK * EPI_CH;    // 672 symbols staged in LDS per correlation tile
+constexpr int N_CHUNK = EPI_NT / 8;           // thread = (chunk, E-polarisation b, TX polarisation a, lag half h): 32 x 2 x 2 x 2; the I and Q rows of a ride in one packed FMA
+constexpr int EPI_CH = 22;                    // symbols per chunk (even: a thread's 32-sample lag window is 16 aligned register pairs)
+constexpr int N_LAGH = 11;                    // lags per thread: h = 0 -> lags 0..10, h = 1 -> lags 10..20 (lag 10 is computed by both, taken from h = 0)
+constexpr int EPI_TILE = N_CHUNK * EPI_CH;    // 704 symbols staged in LDS per correlation tile
+constexpr int ES_LEN = EPI_TILE + 2 * HALF_SHIFT + 4;
 
 struct EpiShared {
     float corr[2][2][2][N_SHIFT];             // [c][b][a][lag]
@@ -33,30 +39,36 @@ struct EpiShared {
     float red[64];
     union {
         struct {
-            float4 txs[EPI_TILE];                     // TX tile: (pol0 I, pol0 Q, pol1 I, pol1 Q) per symbol
-            float es[2][EPI_TILE + 2 * HALF_SHIFT];   // equaliser-side tile with a 10-symbol halo on both sides
+            float2 txs[2 * EPI_TILE];                 // TX tile: [symbol][a] = (I, Q) of polarisation a
+            float es[2][ES_LEN];                      // equaliser-side tile with a 10-symbol halo on both sides
         } t;
-        float part[N_CHUNK][2][4][N_SHIFT];           // per-chunk partial correlations (after the last tile)
+        float2 part[N_CHUNK][2][2][N_SHIFT];          // per-chunk partial correlations (after the last tile)
     } u;
 };
 
 // correlation of the TX reference with E[b][.] rolled by lag-10 (shared_funcs.py:300-304).  The symbol axis is walked in tiles staged
-// in LDS; a thread owns one (b, TX row, chunk of 21 symbols) and ALL 21 lags: per symbol one TX value and one new E sample feed 21
-// FMAs -- the lag window lives in 21 registers used as a ring whose rotation is resolved at compile time (21 unrolled steps).
+// in LDS; a thread owns one (chunk of 22 symbols, b, TX polarisation a, half of the lags) and both TX rows (I, Q) of a: its lag window
+// (32 samples of E) sits in 16 register pairs, and per symbol one 8-byte TX read feeds 11 packed FMAs whose E factor is one half of a
+// pair (picked by op_sel at compile time: no moves).
 __device__ __forceinline__ void epi_correlate(const float *__restrict__ E /*[2][N] or strided*/, int64_t estride, const __half *__restrict__ tx, int64_t N64,
                               EpiShared &sh)
 {
     const int tid = threadIdx.x, N = (int)N64;
-    const int chunk = tid >> 3, b = (tid >> 2) & 1, ac = tid & 3;
-    float acc[N_SHIFT];
+    const int chunk = tid >> 3, b = (tid >> 2) & 1, a = (tid >> 1) & 1, h = tid & 1;
+    v2f acc[N_LAGH];
 #pragma unroll
-    for (int l = 0; l < N_SHIFT; l++) acc[l] = 0.f;
+    for (int i = 0; i < N_LAGH; i++) acc[i] = v2f{0.f, 0.f};
+#ifdef EPI_SKIP_CORR
+    for (int t0 = 0; t0 < EPI_TILE; t0 += EPI_TILE) {
+#else
     for (int t0 = 0; t0 < N; t0 += EPI_TILE) {
+#endif
         const int tl = min(EPI_TILE, N - t0);
-        for (int i = tid; i < EPI_TILE; i += EPI_NT)           // symbols past the end contribute zeros
-            sh.u.t.txs[i] = i < tl ? make_float4(__half2float(tx[0 * (size_t)N + t0 + i]), __half2float(tx[1 * (size_t)N + t0 + i]),
-                                                 __half2float(tx[2 * (size_t)N + t0 + i]), __half2float(tx[3 * (size_t)N + t0 + i]))
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < EPI_TILE; i += EPI_NT) {         // symbols past the end contribute zeros
+            const bool in = i < tl;
+            sh.u.t.txs[2 * i + 0] = in ? make_float2(__half2float(tx[0 * (size_t)N + t0 + i]), __half2float(tx[1 * (size_t)N + t0 + i])) : make_float2(0.f, 0.f);
+            sh.u.t.txs[2 * i + 1] = in ? make_float2(__half2float(tx[2 * (size_t)N + t0 + i]), __half2float(tx[3 * (size_t)N + t0 + i])) : make_float2(0.f, 0.f);
+        }
         for (int i = tid; i < 2 * (EPI_TILE + 2 * HALF_SHIFT); i += EPI_NT) {     // E[b][t0 - 10 .. t0 + TILE + 10), indices mod N
             const int bb = i / (EPI_TILE + 2 * HALF_SHIFT), j = i - bb * (EPI_TILE + 2 * HALF_SHIFT);
             int m = (t0 + j - HALF_SHIFT) % N;
@@ -65,31 +77,35 @@ __device__ __forceinline__ void epi_correlate(const float *__restrict__ E /*[2][
         }
         __syncthreads();
         {
-            // roll(E, lag-10)[n] = E[n - (lag-10)] -> es index j + 20 - lag.  W[i] = es[j0 + i]; symbol j0 + s uses W[s .. s + 20];
-            // ring R[i % 21] = W[i]
-            const float *eb = sh.u.t.es[b] + chunk * EPI_CH;
-            const float *tp = reinterpret_cast<const float *>(sh.u.t.txs + chunk * EPI_CH) + ac;
-            float R[N_SHIFT];
+            // roll(E, lag-10)[n] = E[n - (lag-10)] -> es index j + 20 - lag: symbol j0 + s and lag l meet sample es[j0 + s + 20 - l].  With the
+            // thread's lags l = lb + i (lb = 10 h) and its window W[k] = es[j0 + 10 (1 - h) + k] that is W[s + 10 - i] for both halves.
+            const float *eb = sh.u.t.es[b] + chunk * EPI_CH + HALF_SHIFT * (1 - h);
+            const float2 *tp = sh.u.t.txs + 2 * (chunk * EPI_CH) + a;
+            v2f W[16];
 #pragma unroll
-            for (int i = 0; i < N_SHIFT - 1; i++) R[i] = eb[i];
-#pragma clang loop unroll(full)
+            for (int k = 0; k < 16; k++) W[k] = lds2(eb + 2 * k);
+#pragma unroll
             for (int s = 0; s < EPI_CH; s++) {
-                R[(s + N_SHIFT - 1) % N_SHIFT] = eb[s + N_SHIFT - 1];
-                const float tv = tp[4 * s];
+                const v2f tv = lds2(tp + 2 * s);
 #pragma unroll
-                for (int l = 0; l < N_SHIFT; l++) acc[l] = fmaf(tv, R[(s + 2 * HALF_SHIFT - l) % N_SHIFT], acc[l]);
+                for (int i = 0; i < N_LAGH; i++) {
+                    const int e = s + HALF_SHIFT - i;
+                    acc[i] += tv * ((e & 1) ? W[e >> 1].y : W[e >> 1].x);
+                }
             }
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int l = 0; l < N_SHIFT; l++) sh.u.part[chunk][b][ac][l] = acc[l];
+    for (int i = 0; i < N_LAGH; i++)
+        if (h == 0 || i > 0) sh.u.part[chunk][b][a][HALF_SHIFT * h + i] = make_float2(acc[i].x, acc[i].y);
     __syncthreads();
-    if (tid < 2 * 4 * N_SHIFT) {                                // fixed-order sum over chunks
-        const int l = tid % N_SHIFT, bac = tid / N_SHIFT, b2 = bac >> 2, ac2 = bac & 3, a = ac2 >> 1, c = ac2 & 1;
-        float s = 0.f;
-        for (int k = 0; k < N_CHUNK; k++) s += sh.u.part[k][b2][ac2][l];
-        sh.corr[c][b2][a][l] = fabsf(s);
+    if (tid < 2 * 2 * N_SHIFT) {                                // fixed-order sum over chunks
+        const int l = tid % N_SHIFT, ba = tid / N_SHIFT, b2 = ba >> 1, a2 = ba & 1;
+        v2f tot = {0.f, 0.f};
+        for (int k = 0; k < N_CHUNK; k++) tot += lds2(&sh.u.part[k][b2][a2][l]);
+        sh.corr[0][b2][a2][l] = fabsf(tot.x);
+        sh.corr[1][b2][a2][l] = fabsf(tot.y);
     }
     __syncthreads();
     if (tid == 0) {                                             // shared_funcs.py:303-314
@@ -158,7 +174,7 @@ struct KeepWalk {
 };
 
 template <int NLEV>
-__global__ __launch_bounds__(EPI_NT, 6) void dp_epilogue_kernel(int64_t N, int batch_len, const float *__restrict__ q, const float *__restrict__ y,
+__global__ __launch_bounds__(EPI_NT, EPI_WAVES) void dp_epilogue_kernel(int64_t N, int batch_len, const float *__restrict__ q, const float *__restrict__ y,
                                                              const __half *__restrict__ txg, const float *__restrict__ amp_g,
                                                              const float *__restrict__ var, const float *__restrict__ nu_sc,
                                                              float *__restrict__ ser, int32_t *__restrict__ shift_out,
@@ -242,7 +258,11 @@ __global__ __launch_bounds__(EPI_NT, 6) void dp_epilogue_kernel(int64_t N, int b
         for (int i = 0; i < 16; i++) cnt[i] = 0;
         int kept = 0;
         KeepWalk kw(tid, (int)N, batch_len, s0, ms);
+#ifdef EPI_SKIP_SER
+        for (int n = tid; n < (int)N / 64; n += EPI_NT, kw.next()) {
+#else
         for (int n = tid; n < (int)N; n += EPI_NT, kw.next()) {
+#endif
             if (!kw.keep(n)) continue;
             kept++;
 #pragma unroll
