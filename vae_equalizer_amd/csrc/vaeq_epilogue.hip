@@ -29,6 +29,8 @@ constexpr int N_LAGH = 11;                    // lags per thread: h = 0 -> lags 
 constexpr int EPI_TILE = N_CHUNK * EPI_CH;    // 704 symbols staged in LDS per correlation tile
 constexpr int ES_LEN = EPI_TILE + 2 * HALF_SHIFT + 4;
 
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));             // four floats at any 4-byte boundary (one global_load_dwordx4)
+
 struct EpiShared {
     float corr[2][2][2][N_SHIFT];             // [c][b][a][lag]
     int shift[2];
@@ -40,7 +42,7 @@ struct EpiShared {
     union {
         struct {
             float2 txs[2 * EPI_TILE];                 // TX tile: [symbol][a] = (I, Q) of polarisation a
-            float es[2][ES_LEN];                      // equaliser-side tile with a 10-symbol halo on both sides
+            alignas(16) float es[2][ES_LEN];          // equaliser-side tile with a 10-symbol halo on both sides
         } t;
         float2 part[N_CHUNK][2][2][N_SHIFT];          // per-chunk partial correlations (after the last tile)
     } u;
@@ -55,6 +57,7 @@ __device__ __forceinline__ void epi_correlate(const float *__restrict__ E /*[2][
 {
     const int tid = threadIdx.x, N = (int)N64;
     const int chunk = tid >> 3, b = (tid >> 2) & 1, a = (tid >> 1) & 1, h = tid & 1;
+    const bool wide_tx = (N & 3) == 0 && (reinterpret_cast<uintptr_t>(tx) & 7) == 0;
     v2f acc[N_LAGH];
 #pragma unroll
     for (int i = 0; i < N_LAGH; i++) acc[i] = v2f{0.f, 0.f};
@@ -63,17 +66,49 @@ __device__ __forceinline__ void epi_correlate(const float *__restrict__ E /*[2][
 #else
     for (int t0 = 0; t0 < N; t0 += EPI_TILE) {
 #endif
-        const int tl = min(EPI_TILE, N - t0);
-        for (int i = tid; i < EPI_TILE; i += EPI_NT) {         // symbols past the end contribute zeros
-            const bool in = i < tl;
-            sh.u.t.txs[2 * i + 0] = in ? make_float2(__half2float(tx[0 * (size_t)N + t0 + i]), __half2float(tx[1 * (size_t)N + t0 + i])) : make_float2(0.f, 0.f);
-            sh.u.t.txs[2 * i + 1] = in ? make_float2(__half2float(tx[2 * (size_t)N + t0 + i]), __half2float(tx[3 * (size_t)N + t0 + i])) : make_float2(0.f, 0.f);
+        // staging in groups of four consecutive symbols: 8- and 16-byte loads wherever the group lies inside the row, no integer division
+        for (int g = tid; g < EPI_TILE / 4; g += EPI_NT) {     // TX rows; symbols past the end contribute zeros
+            const int n = t0 + 4 * g;
+            float v[4][4];
+            if (wide_tx && n + 3 < N) {
+#pragma unroll
+                for (int row = 0; row < 4; row++) {
+                    const uint2 w = *reinterpret_cast<const uint2 *>(tx + (size_t)row * N + n);
+                    const __half2 h01 = *reinterpret_cast<const __half2 *>(&w.x), h23 = *reinterpret_cast<const __half2 *>(&w.y);
+                    v[row][0] = __low2float(h01); v[row][1] = __high2float(h01); v[row][2] = __low2float(h23); v[row][3] = __high2float(h23);
+                }
+            } else {
+#pragma unroll
+                for (int row = 0; row < 4; row++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[row][e] = n + e < N ? __half2float(tx[(size_t)row * N + n + e]) : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                sh.u.t.txs[2 * (4 * g + e) + 0] = make_float2(v[0][e], v[1][e]);
+                sh.u.t.txs[2 * (4 * g + e) + 1] = make_float2(v[2][e], v[3][e]);
+            }
         }
-        for (int i = tid; i < 2 * (EPI_TILE + 2 * HALF_SHIFT); i += EPI_NT) {     // E[b][t0 - 10 .. t0 + TILE + 10), indices mod N
-            const int bb = i / (EPI_TILE + 2 * HALF_SHIFT), j = i - bb * (EPI_TILE + 2 * HALF_SHIFT);
-            int m = (t0 + j - HALF_SHIFT) % N;
-            if (m < 0) m += N;
-            sh.u.t.es[bb][j] = E[(int64_t)bb * estride + m];
+        constexpr int EG = (EPI_TILE + 2 * HALF_SHIFT) / 4;    // E[b][t0 - 10 .. t0 + TILE + 10), indices mod N
+        for (int i = tid; i < 2 * EG; i += EPI_NT) {
+            const int bb = i >= EG, j = 4 * (i - bb * EG), m0 = t0 + j - HALF_SHIFT;
+            const float *row = E + (int64_t)bb * estride;
+            float4 v;
+            if (m0 >= 0 && m0 + 3 < N) {
+                const f4u w = *reinterpret_cast<const f4u *>(row + m0);
+                v = make_float4(w.x, w.y, w.z, w.w);
+            } else {
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    int m = m0 + e;
+                    while (m < 0) m += N;
+                    while (m >= N) m -= N;
+                    t[e] = row[m];
+                }
+                v = make_float4(t[0], t[1], t[2], t[3]);
+            }
+            *reinterpret_cast<float4 *>(&sh.u.t.es[bb][j]) = v;
         }
         __syncthreads();
         {
@@ -173,6 +208,79 @@ struct KeepWalk {
     }
 };
 
+// the same for a thread that owns groups of four consecutive symbols n0 = 4 (tid + 256 i): the group's (minibatch, offset) advance by 1024 symbols
+// per step; the members' follow with at most a few carries
+struct KeepWalk4 {
+    int N, batch_len, ms, Lk, K, mb, j, dq, dr;
+    __device__ __forceinline__ KeepWalk4(int n0, int N_, int batch_len_, int shift0, int ms_) : N(N_), batch_len(batch_len_), ms(ms_)
+    {
+        Lk = K = mb = j = dq = dr = 0;
+        if (batch_len > 0) {
+            Lk = batch_len - shift0 - N_CUT;
+            Lk = Lk < 0 ? 0 : (Lk > batch_len ? batch_len : Lk);
+            K = (N / batch_len) * Lk;
+            mb = n0 / batch_len; j = n0 - mb * batch_len;
+            dq = (4 * EPI_NT) / batch_len; dr = 4 * EPI_NT - dq * batch_len;
+        }
+    }
+    __device__ __forceinline__ void keep4(int n0, bool (&kp)[4]) const
+    {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int n = n0 + e;
+            if (batch_len <= 0) kp[e] = n >= EDGE && n < N - EDGE - ms;
+            else {
+                int je = j + e, me = mb;
+                while (je >= batch_len) { je -= batch_len; me++; }
+                const int k = me * Lk + je;
+                kp[e] = n < N && je < Lk && k >= EDGE && k < K - EDGE - ms;
+            }
+        }
+    }
+    __device__ __forceinline__ void next()
+    {
+        mb += dq; j += dr;
+        if (j >= batch_len) { j -= batch_len; mb++; }
+    }
+};
+
+
+// four consecutive elements of a row: one wide load when the group lies inside the row (and the row is aligned for it), else the kept members one by one
+// (a kept symbol's partner index n + shift never leaves the row: 11 <= n, |shift| <= 10, and the window ends 11 + max|shift| before the row does)
+__device__ __forceinline__ void epi_ld_tx(const __half *row, int n0, bool wide, const bool (&kp)[4], float (&out)[4])
+{
+    if (wide) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(row + n0);
+        const __half2 h01 = *reinterpret_cast<const __half2 *>(&w.x), h23 = *reinterpret_cast<const __half2 *>(&w.y);
+        out[0] = __low2float(h01); out[1] = __high2float(h01); out[2] = __low2float(h23); out[3] = __high2float(h23);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) out[e] = kp[e] ? __half2float(row[n0 + e]) : 0.f;
+    }
+}
+__device__ __forceinline__ void epi_ld_y(const float *row, int m0, bool wide, const bool (&kp)[4], float (&out)[4])
+{
+    if (wide) {
+        const f4u v = *reinterpret_cast<const f4u *>(row + m0);
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) out[e] = kp[e] ? row[m0 + e] : 0.f;
+    }
+}
+__device__ __forceinline__ void epi_ld_d(const int8_t *row, int m0, bool wide, const bool (&kp)[4], float (&out)[4])
+{
+    if (wide) {
+        uint32_t w;
+        __builtin_memcpy(&w, row + m0, 4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) out[e] = (float)(int8_t)(w >> (8 * e));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) out[e] = kp[e] ? (float)row[m0 + e] : 0.f;
+    }
+}
+
 template <int NLEV>
 __global__ __launch_bounds__(EPI_NT, EPI_WAVES) void dp_epilogue_kernel(int64_t N, int batch_len, const float *__restrict__ q, const float *__restrict__ y,
                                                              const __half *__restrict__ txg, const float *__restrict__ amp_g,
@@ -232,21 +340,33 @@ __global__ __launch_bounds__(EPI_NT, EPI_WAVES) void dp_epilogue_kernel(int64_t 
             shift_out[(size_t)run * 4 + path * 2 + 1] = s1;
             r_out[(size_t)run * 2 + path] = r;
         }
+        // both passes below walk the symbols in groups of four consecutive ones per thread: 8- and 16-byte loads instead of 2- and 4-byte ones
+        const bool row_wide = ((int)N & 3) == 0 && (reinterpret_cast<uintptr_t>(tx) & 7) == 0;
+        const int NG = ((int)N + 3) >> 2;
         float fac = 1.0f;
         if (path == 1) {                                        // mean radius of TX over mean radius of the aligned output (:242)
             float st = 0.f, sy = 0.f;
-            KeepWalk kw(tid, (int)N, batch_len, s0, ms);
-            for (int n = tid; n < (int)N; n += EPI_NT, kw.next()) {
-                if (!kw.keep(n)) continue;
+            KeepWalk4 kw(4 * tid, (int)N, batch_len, s0, ms);
+            for (int g = tid; g < NG; g += EPI_NT, kw.next()) {
+                const int n0 = 4 * g;
+                bool kp[4];
+                kw.keep4(n0, kp);
+                if (!(kp[0] || kp[1] || kp[2] || kp[3])) continue;
+                const bool wide = row_wide && n0 >= 12 && n0 + 14 <= (int)N;
 #pragma unroll
                 for (int p = 0; p < 2; p++) {
-                    const int sp = (p - r) & 1;
-                    int m = n + (p ? s1 : s0);
-                    if (m >= (int)N) m -= (int)N; if (m < 0) m += (int)N;
-                    const float ti = __half2float(tx[(size_t)(p * 2 + 0) * N + n]), tq = __half2float(tx[(size_t)(p * 2 + 1) * N + n]);
-                    const float yi = yr[(size_t)(sp * 2 + 0) * N + m], yq = yr[(size_t)(sp * 2 + 1) * N + m];
-                    st += sqrtf(ti * ti + tq * tq);
-                    sy += sqrtf(yi * yi + yq * yq);
+                    const int sp = (p - r) & 1, m0 = n0 + (p ? s1 : s0);
+                    float ti[4], tq[4], yi[4], yq[4];
+                    epi_ld_tx(tx + (size_t)(p * 2 + 0) * N, n0, wide, kp, ti);
+                    epi_ld_tx(tx + (size_t)(p * 2 + 1) * N, n0, wide, kp, tq);
+                    epi_ld_y(yr + (size_t)(sp * 2 + 0) * N, m0, wide, kp, yi);
+                    epi_ld_y(yr + (size_t)(sp * 2 + 1) * N, m0, wide, kp, yq);
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (kp[e]) {
+                            st += sqrtf(ti[e] * ti[e] + tq[e] * tq[e]);
+                            sy += sqrtf(yi[e] * yi[e] + yq[e] * yq[e]);
+                        }
                 }
             }
             block_reduce3<EPI_NT>(st, sy, 0.f, sh.red);
@@ -257,44 +377,61 @@ __global__ __launch_bounds__(EPI_NT, EPI_WAVES) void dp_epilogue_kernel(int64_t 
 #pragma unroll
         for (int i = 0; i < 16; i++) cnt[i] = 0;
         int kept = 0;
-        KeepWalk kw(tid, (int)N, batch_len, s0, ms);
+        KeepWalk4 kw(4 * tid, (int)N, batch_len, s0, ms);
 #ifdef EPI_SKIP_SER
-        for (int n = tid; n < (int)N / 64; n += EPI_NT, kw.next()) {
+        for (int g = tid; g < NG / 64; g += EPI_NT, kw.next()) {
 #else
-        for (int n = tid; n < (int)N; n += EPI_NT, kw.next()) {
+        for (int g = tid; g < NG; g += EPI_NT, kw.next()) {
 #endif
-            if (!kw.keep(n)) continue;
-            kept++;
+            const int n0 = 4 * g;
+            bool kp[4];
+            kw.keep4(n0, kp);
+            if (!(kp[0] || kp[1] || kp[2] || kp[3])) continue;
+            kept += (int)kp[0] + (int)kp[1] + (int)kp[2] + (int)kp[3];
+            const bool wide = row_wide && n0 >= 12 && n0 + 14 <= (int)N;
 #pragma unroll
             for (int p = 0; p < 2; p++) {
                 const int sp = (p - r) & 1;                     // roll(r, 0): row p comes from row p - r  (:71)
-                int m = n + (p ? s1 : s0);                      // roll(-shift): out[n] = in[n + shift]     (:72)
-                if (m >= (int)N) m -= (int)N; if (m < 0) m += (int)N;
-                const float dI = rintf(scale * __half2float(tx[(size_t)(p * 2 + 0) * N + n]) + scale);       // :198
-                const float dQ = rintf(scale * __half2float(tx[(size_t)(p * 2 + 1) * N + n]) + scale);
-                const float dQi = -(dQ - 2.0f * scale);         // IQ flip (:199)
+                const int m0 = n0 + (p ? s1 : s0);              // roll(-shift): out[n] = in[n + shift]     (:72)
+                float ti[4], tq[4], u0[4], u1[4];
+                epi_ld_tx(tx + (size_t)(p * 2 + 0) * N, n0, wide, kp, ti);
+                epi_ld_tx(tx + (size_t)(p * 2 + 1) * N, n0, wide, kp, tq);
                 if (path == 0) {
-                    const float a0 = (float)D[(size_t)(sp * 2 + 0) * N + m], a1 = (float)D[(size_t)(sp * 2 + 1) * N + m];
-                    // decisions under rotation by 0, pi, pi/2, 3pi/2 (:201-217)
-                    const float hI[4] = {a0, -(a0 - 2.0f * scale), -(a1 - 2.0f * scale), a1};
-                    const float hQ[4] = {a1, -(a1 - 2.0f * scale), a0, -(a0 - 2.0f * scale)};
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        cnt[(2 * k + 0) * 2 + p] += (dI != hI[k]) || (dQ != hQ[k]);
-                        cnt[(2 * k + 1) * 2 + p] += (dI != hI[k]) || (dQi != hQ[k]);
-                    }
+                    epi_ld_d(D + (size_t)(sp * 2 + 0) * N, m0, wide, kp, u0);
+                    epi_ld_d(D + (size_t)(sp * 2 + 1) * N, m0, wide, kp, u1);
                 } else {
-                    const float yi = yr[(size_t)(sp * 2 + 0) * N + m] * fac, yq = yr[(size_t)(sp * 2 + 1) * N + m] * fac;
-                    const float rI[4] = {yi, -yi, -yq, yq}, rQ[4] = {yq, -yq, yi, -yi};        // :245-262
-                    auto inside = [&](float v, float lev) {     // d_vec0[lev] <= v < d_vec1[lev]   (:267-287)
-                        const int li = min(max((int)lev, 0), NLEV - 1);
-                        return sh.lo[li] <= v && v < sh.hi[li];
-                    };
+                    epi_ld_y(yr + (size_t)(sp * 2 + 0) * N, m0, wide, kp, u0);
+                    epi_ld_y(yr + (size_t)(sp * 2 + 1) * N, m0, wide, kp, u1);
+                }
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const bool okI = inside(rI[k], dI);
-                        cnt[(2 * k + 0) * 2 + p] += !(okI && inside(rQ[k], dQ));
-                        cnt[(2 * k + 1) * 2 + p] += !(okI && inside(rQ[k], dQi));
+                for (int e = 0; e < 4; e++) {
+                    if (!kp[e]) continue;
+                    const float dI = rintf(scale * ti[e] + scale);       // :198
+                    const float dQ = rintf(scale * tq[e] + scale);
+                    const float dQi = -(dQ - 2.0f * scale);         // IQ flip (:199)
+                    if (path == 0) {
+                        const float a0 = u0[e], a1 = u1[e];
+                        // decisions under rotation by 0, pi, pi/2, 3pi/2 (:201-217)
+                        const float hI[4] = {a0, -(a0 - 2.0f * scale), -(a1 - 2.0f * scale), a1};
+                        const float hQ[4] = {a1, -(a1 - 2.0f * scale), a0, -(a0 - 2.0f * scale)};
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            cnt[(2 * k + 0) * 2 + p] += (dI != hI[k]) || (dQ != hQ[k]);
+                            cnt[(2 * k + 1) * 2 + p] += (dI != hI[k]) || (dQi != hQ[k]);
+                        }
+                    } else {
+                        const float yi = u0[e] * fac, yq = u1[e] * fac;
+                        const float rI[4] = {yi, -yi, -yq, yq}, rQ[4] = {yq, -yq, yi, -yi};        // :245-262
+                        auto inside = [&](float v, float lev) {     // d_vec0[lev] <= v < d_vec1[lev]   (:267-287)
+                            const int li = min(max((int)lev, 0), NLEV - 1);
+                            return sh.lo[li] <= v && v < sh.hi[li];
+                        };
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const bool okI = inside(rI[k], dI);
+                            cnt[(2 * k + 0) * 2 + p] += !(okI && inside(rQ[k], dQ));
+                            cnt[(2 * k + 1) * 2 + p] += !(okI && inside(rQ[k], dQi));
+                        }
                     }
                 }
             }
