@@ -61,7 +61,7 @@ def make_frames(n_frames, R, device, seed, with_data=False):
     t = sfun.qam_tables(CFG["mod"], CFG["nu"])
     h_ch = sfun.upsampled_channel(CFG["channel"], CFG["sps"])
     frames, data0 = [], None
-    for f in range(n_frames):       # HIP generator kernels + hipFFT (vaeq_gen_dp_*), Philox streams keyed by (seed, frame, run)
+    for f in range(n_frames):       # HIP generator kernels (vaeq_gen_dp_frame, three-pass form), Philox streams keyed by (seed, frame, run)
         rx, data = ch.generate_batch_hip(R, CFG["N_frame_max"], t["amps"], t["P"], CFG["SNR"], h_ch, CFG["symb_rate"], CFG["sps"], CFG["tau_cd"],
                                          CFG["tau_pmd"], CFG["phiIQ"], CFG["theta"] + f * CFG["theta_diff"], device, seed, f)
         frames.append(rx.unsqueeze(1))
@@ -430,7 +430,7 @@ def main():
         res = {
             "metric": "equalized symbols/s/GPU, DP 64-QAM VAE-LE", "value": value, "unit": "DP-symbols/s (1 DP symbol = 2 polarisation symbols)",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic (on-device DP channel simulator vaeq_gen_dp_*: Philox PCS draw, RRC, CD+PMD+rotation via hipFFT, AWGN)",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (on-device DP channel simulator vaeq_gen_dp_*: Philox PCS draw, RRC, CD+PMD+rotation in the frequency domain, AWGN)",
             "per_gpu": value / world,
             "timed_regions": len(regions), "region_ms": {"min": min(regions) * 1e3, "median": el * 1e3, "max": max(regions) * 1e3},
             "config": {"workload": "SURVEY config 3: optical DP 64-QAM VAE-LE, nu=0, SNR 23 dB, h0, 90 GBd, M_est=25, batch_len=100, "

@@ -226,7 +226,8 @@ def _dev_const(arr, dtype, device):
 
 def fast_fft_len(n):
     """Smallest m * 2^a >= n with m in {1, 3, 5}: lengths hipFFT runs as one radix-2/4/8-dominated kernel chain (measured on MI355X
-    for [2048, 2, L] c2c: L = 20480 takes 1.6 ms per fft+ifft, 20250 = 2*3^4*5^3 3.3 ms, the Bluestein length 20034 6.6 ms)."""
+    for [2048, 2, L] c2c: L = 20480 takes 1.6 ms per fft+ifft, 20250 = 2*3^4*5^3 3.3 ms, the Bluestein length 20034 6.6 ms); the multiples of
+    1024 among them up to 20 * 1024 (4, 5, 8, 10, 16, 20) are the rows vaeq_gen_dp_frame transforms itself (csrc/vaeq_gen_fused.h)."""
     best = None
     for m in (1, 3, 5):
         v = m
@@ -236,9 +237,10 @@ def fast_fft_len(n):
     return best
 
 
-def generate_batch_hip(R, N, amps, P, SNR, h_channel, symb_rate, sps, tau_cd, tau_pmd, phiIQ, theta, device, seed, frame, chunk=2048,
+def generate_batch_hip(R, N, amps, P, SNR, h_channel, symb_rate, sps, tau_cd, tau_pmd, phiIQ, theta, device, seed, frame, chunk=8192,
                        return_sigma=False, fft="padded"):
-    """The DP channel model for R runs on the device: one vaeq_gen_dp_frame call per chunk of runs (HIP stages + in-place hipFFT).
+    """The DP channel model for R runs on the device: one vaeq_gen_dp_frame call per chunk of runs (8192 runs = a 2.7 GB workspace for the
+    default frame; the padded default frame takes the library's three-pass form, other row lengths the stage kernels around in-place hipFFT).
 
     fft: "exact"  -- dispersion applied on the FFT of the exact sequence length Ls like the reference (circular filtering; Ls = 20034 =
                      2*3^3*7*53 for the default frame costs hipFFT 4x the time of a 20480-point transform);

@@ -22,10 +22,35 @@
 namespace vaeq {
 
 // ---- small DFTs on register arrays (forward: e^{-2 pi i nk/N}; INV: conjugate kernel, no 1/N) -----------------------------------------------
-__device__ __forceinline__ v2f cmulv(v2f a, v2f b) { return v2f{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-__device__ __forceinline__ v2f cmulc(v2f a, v2f b) { return v2f{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }   // a * conj(b)
-template <bool INV>
-__device__ __forceinline__ v2f mulmj(v2f a) { return INV ? v2f{-a.y, a.x} : v2f{a.y, -a.x}; }                      // a * (-j) (forward), a * j (INV)
+// complex products as TWO packed instructions, sums with +-j b as ONE: the half swaps and signs ride on op_sel / neg_lo / neg_hi (the backend
+// does not find these forms: it swaps with v_mov and multiplies the halves as scalars)
+__device__ __forceinline__ v2f cmulv(v2f a, v2f b)                             // a * b
+{
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));                                            // (a.x b.x, a.x b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t)); // + (-a.y b.y, a.y b.x)
+    return r;
+}
+__device__ __forceinline__ v2f cmulc(v2f a, v2f b)                             // a * conj(b)
+{
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));                               // (a.x b.x, -a.x b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));               // + (a.y b.y, a.y b.x)
+    return r;
+}
+__device__ __forceinline__ v2f cmulk(v2f a, v2f k) { return v2f{a.x * k.x - a.y * k.y, a.x * k.y + a.y * k.x}; }          // by a literal: left to the compiler
+__device__ __forceinline__ v2f add_jb(v2f a, v2f b)                            // a + j b = (a.x - b.y, a.y + b.x)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f sub_jb(v2f a, v2f b)                            // a - j b = (a.x + b.y, a.y - b.x)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 template <bool INV>
 __device__ __forceinline__ void dft2(v2f (&x)[2])
@@ -36,8 +61,10 @@ __device__ __forceinline__ void dft2(v2f (&x)[2])
 template <bool INV>
 __device__ __forceinline__ void dft4(v2f (&x)[4])
 {
-    const v2f s02 = x[0] + x[2], d02 = x[0] - x[2], s13 = x[1] + x[3], d13 = mulmj<INV>(x[1] - x[3]);
-    x[0] = s02 + s13; x[1] = d02 + d13; x[2] = s02 - s13; x[3] = d02 - d13;
+    const v2f s02 = x[0] + x[2], d02 = x[0] - x[2], s13 = x[1] + x[3], d13 = x[1] - x[3];
+    x[0] = s02 + s13; x[2] = s02 - s13;
+    x[1] = INV ? add_jb(d02, d13) : sub_jb(d02, d13);                          // forward: d02 - j d13
+    x[3] = INV ? sub_jb(d02, d13) : add_jb(d02, d13);
 }
 template <bool INV>
 __device__ __forceinline__ void dft5(v2f (&x)[5])
@@ -45,10 +72,12 @@ __device__ __forceinline__ void dft5(v2f (&x)[5])
     constexpr float c1 = 0.30901699437494745f, c2 = -0.8090169943749473f, s1 = 0.9510565162951535f, s2 = 0.5877852522924732f;
     const v2f t1 = x[1] + x[4], t2 = x[2] + x[3], t3 = x[1] - x[4], t4 = x[2] - x[3];
     const v2f m1 = x[0] + c1 * t1 + c2 * t2, m2 = x[0] + c2 * t1 + c1 * t2;
-    const v2f n1 = mulmj<INV>(s1 * t3 + s2 * t4), n2 = mulmj<INV>(s2 * t3 - s1 * t4);   // forward: -j (..)
+    const v2f n1 = s1 * t3 + s2 * t4, n2 = s2 * t3 - s1 * t4;
     x[0] = x[0] + t1 + t2;
-    x[1] = m1 + n1; x[4] = m1 - n1;
-    x[2] = m2 + n2; x[3] = m2 - n2;
+    x[1] = INV ? add_jb(m1, n1) : sub_jb(m1, n1);                              // forward: m1 - j n1
+    x[4] = INV ? sub_jb(m1, n1) : add_jb(m1, n1);
+    x[2] = INV ? add_jb(m2, n2) : sub_jb(m2, n2);
+    x[3] = INV ? sub_jb(m2, n2) : add_jb(m2, n2);
 }
 template <int N, bool INV>
 __device__ __forceinline__ void dft_prim(v2f (&x)[N])
@@ -101,7 +130,7 @@ __device__ __forceinline__ void dft_comp(v2f (&x)[N0 * N1])
         for (int n1 = 0; n1 < N1; n1++) t[n1] = x[n0 + N0 * n1];
         dft_prim<N1, INV>(t);
 #pragma unroll
-        for (int k1 = 0; k1 < N1; k1++) s[k1][n0] = (n0 * k1 == 0) ? t[k1] : cmulv(t[k1], tw_const<N0 * N1, INV>(n0 * k1));
+        for (int k1 = 0; k1 < N1; k1++) s[k1][n0] = (n0 * k1 == 0) ? t[k1] : cmulk(t[k1], tw_const<N0 * N1, INV>(n0 * k1));
     }
 #pragma unroll
     for (int k1 = 0; k1 < N1; k1++) {
