@@ -6,6 +6,9 @@ namespace vaeq {
 
 int launch_dp_wave_mw(const vaeq_dp_args &a, hipStream_t st);          // vaeq_dp_wave_mw.hip
 int64_t dp_wave_mw_resident(int B, int M, int n_lev);
+bool dp_wave_baked(int B, int M);                                       // vaeq_dp_wave_bk.hip
+int launch_dp_wave_bk(const vaeq_dp_args &a, hipStream_t st);
+int64_t dp_wave_bk_resident(int B, int n_lev);
 
 // Whether the wave-per-run kernel covers this call (else the generic kernel runs).
 bool dp_wave_supported(const vaeq_dp_args &a)
@@ -24,6 +27,7 @@ bool dp_wave_supported(const vaeq_dp_args &a)
 int64_t dp_wave_resident(int B, int M, int n_lev)
 {
     if (B > 128) return dp_wave_mw_resident(B, M, n_lev);
+    if (dp_wave_baked(B, M)) return dp_wave_bk_resident(B, n_lev);
     switch (M) {
     case 25: return B == 100 ? wave_resident_lev<25, 100, 1>(B, n_lev) : wave_resident_lev<25, 0, 1>(B, n_lev);
     case 31: return wave_resident_lev<31, 0, 1>(B, n_lev);
@@ -38,6 +42,7 @@ int64_t dp_wave_resident(int B, int M, int n_lev)
 int launch_dp_wave(const vaeq_dp_args &a, hipStream_t st)
 {
     if (a.B > 128) return launch_dp_wave_mw(a, st);
+    if (dp_wave_baked(a.B, a.M)) return launch_dp_wave_bk(a, st);
     switch (a.M) {
     case 25: return a.B == 100 ? launch_wave_lev<25, 100, 1>(a, st) : launch_wave_lev<25, 0, 1>(a, st);
     case 31: return launch_wave_lev<31, 0, 1>(a, st);
