@@ -233,17 +233,30 @@ def extra_pipeline(R, t, var, device, frames=4):
     varr = torch.full((R, 2), float(var), device=device)
     state = {"f": 0}
 
-    def frame():
+    def frame(ev=None):
         f = state["f"]
+        if ev:
+            ev[0].record()
         rx, data = ch.generate_batch_hip(R, CFG["N_frame_max"], t["amps"], t["P"], CFG["SNR"], h_ch, CFG["symb_rate"], sps, CFG["tau_cd"], CFG["tau_pmd"],
                                          CFG["phiIQ"], CFG["theta"] + f * CFG["theta_diff"], device, 77, f)
+        if ev:
+            ev[1].record()
         out = eng.train(rx, B, CFG["N_frame_max"] // B, 2.5e-3, want_q=False, want_compact=True)
+        if ev:
+            ev[2].record()
         state["ser"] = dp_epilogue_compact(out["eq"][:, 0], out["dec"][:, 0], out["y"][:, 0], data, amp, nu, varr, B)["SER"]
+        if ev:
+            ev[3].record()
         state["f"] = f + 1
     frame()
     ms = float(np.median(_event_ms(frame, frames)))
-    return {"ms_per_frame": ms, "dp_symbols_per_s": R * CFG["N_frame_max"] / (ms * 1e-3), "runs": R,
-            "stages": "vaeq_gen_dp_frame -> vaeq_dp_train (eq_out/dec_out, q not materialised) -> vaeq_dp_epilogue_compact, one stream, back to back"}
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]          # one more frame with an event after every stage (same stream, no host waits)
+    frame(ev)
+    torch.cuda.synchronize()
+    stage = {k: ev[i].elapsed_time(ev[i + 1]) for i, k in enumerate(("generate", "train", "epilogue"))}
+    return {"ms_per_frame": ms, "dp_symbols_per_s": R * CFG["N_frame_max"] / (ms * 1e-3), "runs": R, "stage_ms": stage,
+            "stages": "vaeq_gen_dp_frame (three passes, own split FFT) -> vaeq_dp_train (eq_out/dec_out, q not materialised) -> vaeq_dp_epilogue_compact, one stream, "
+                      "back to back"}
 
 
 def extra_configs(R, t, var, frame_rx, device):

@@ -38,6 +38,8 @@ def test_bench_line_contract():
     assert 2000 < rf["peak_measured_copy"] < 8000 and rf["frac_of_measured_copy"] > rf["frac"]
     e = d["extra"]
     assert e["pipeline"]["ms_per_frame"] > rf["kernel_ms"] and e["pipeline"]["dp_symbols_per_s"] > 0
+    sm = e["pipeline"]["stage_ms"]
+    assert set(sm) == {"generate", "train", "epilogue"} and all(v > 0 for v in sm.values()) and sm["train"] > 0.5 * rf["kernel_ms"]
     c4, c2 = e["configs"]["config4_vaeflex"], e["configs"]["config2_awgn"]
     assert c4["kernel"].startswith("vaeq::dp_wave_kernel<25, 8, ") and c4["value"] > 0 and 0 < c4["flop_frac"] < 1
     assert c2["kernel"].startswith("vaeq::awgn_wave_kernel<25, 8, 3, 1>") and c2["value"] > 0 and 0 < c2["flop_frac"] < 1
