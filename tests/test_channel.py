@@ -1,6 +1,7 @@
 """Channel generators: the numpy restatement reproduces the reference's frames under the same seeds (G6);
 the batched torch generator has the same statistics."""
 import numpy as np
+import pytest
 import torch
 
 from conftest import load_golden
@@ -58,3 +59,23 @@ def test_batched_generator_statistics():
     lev = torch.round((data.float() / float(amps[1] - amps[0])) + 3.5).long().clamp(0, 7)
     emp = torch.bincount(lev.flatten(), minlength=8).double() / lev.numel()
     assert np.max(np.abs(emp.numpy() - P)) < 0.01
+
+
+def test_cdf_cache_is_keyed_by_content():
+    """channel._cdf_dev: the runs' cumulative PCS tables are cached by content -- equal tables share one tensor, an in-place change misses."""
+    import torch
+    R, n = 5, 8
+    P = np.random.default_rng(0).dirichlet(np.ones(n), R)
+    a = ch._cdf_dev(P, R, n, "cpu")
+    assert a.shape == (R, n) and a.dtype == torch.float32
+    assert np.array_equal(a.numpy(), np.cumsum(P, axis=1).astype(np.float32))
+    assert ch._cdf_dev(P.copy(), R, n, "cpu") is a
+    P[2, 3] += 1e-9
+    b = ch._cdf_dev(P, R, n, "cpu")
+    assert b is not a
+    row = ch._cdf_dev(P[0], R, n, "cpu")                      # one table for all runs
+    assert row.shape == (R, n) and row.is_contiguous() and np.array_equal(row.numpy(), np.tile(np.cumsum(P[0]).astype(np.float32), (R, 1)))
+    with pytest.raises(ValueError):
+        ch._cdf_dev(P[:3], R, n, "cpu")
+    g1, g2 = ch.dp_frame_geometry(600, [1.0, 0.2j], 2), ch.dp_frame_geometry(600, [1.0, 0.2j], 2)
+    assert g1 is g2 and ch.dp_frame_geometry(601, [1.0, 0.2j], 2)["N_conv"] == g1["N_conv"] + 1

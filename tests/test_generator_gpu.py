@@ -158,6 +158,25 @@ def test_fused_frame_long_pulse_and_last_stripe_ownership():
     assert float((rxf - rxs).abs().max()) < 1e-5 * float(rxs.abs().max())
 
 
+@pytest.mark.parametrize("N,fixed", [(1200, False), (3900, False), (700, True), (1900, False)])
+def test_awgn_generator_one_pass_equals_two_pass(N, fixed, monkeypatch):
+    """Short AWGN frames (up to four 2048-sample tiles: the training frames of both AWGN scripts) are generated in one pass, one workgroup per run;
+    the result is bit for bit the two-pass form's (power pass + noise pass, what longer frames use): same symbols, same power sums in the same
+    order, same noise words."""
+    from vae_equalizer_amd.func_VAELE_MQAM_shaping import awgn_tables
+    t = awgn_tables("64-QAM", 0.0270955, 24, "h1", 2)
+    R = 37
+    P = np.stack([t["P"] if r % 3 else np.full_like(t["P"], 1 / len(t["P"])) for r in range(R)])
+    snr = np.linspace(12, 30, R).astype(np.float32)
+    kw = dict(sigma_fixed=np.linspace(0.01, 0.2, R).astype(np.float32)) if fixed else {}
+    monkeypatch.delenv("VAEQ_AWGN_TWOPASS", raising=False)
+    a = ch.generate_awgn_batch_hip(R, N, t["amps"], P, snr, t["h_channel"], 2, "cuda:0", 5, 2, return_sigma=True, **kw)
+    monkeypatch.setenv("VAEQ_AWGN_TWOPASS", "1")
+    b = ch.generate_awgn_batch_hip(R, N, t["amps"], P, snr, t["h_channel"], 2, "cuda:0", 5, 2, return_sigma=True, **kw)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
 def test_generated_frames_train():
     """End to end: frames from the HIP generator make the equalizer converge (loss falls, Var_est falls)."""
     from vae_equalizer_amd.dp_runs import DPRun, run_dp_batch

@@ -83,37 +83,43 @@ struct TxFuse {
     int Lout, sps;
 };
 
-template <int MODE>
-__global__ __launch_bounds__(TX_NT) void gen_tx_kernel(int N_conv, int n_lev, int Lg, int Ls, int Lrow, const float *__restrict__ amp,
-                                                       const float *__restrict__ cdf_g, const float2 *__restrict__ g, uint64_t seed,
-                                                       uint32_t frame, int npol, float2 *__restrict__ sig, int N, int ref_lo,
-                                                       __half *__restrict__ data, TxFuse fz)
+// LDS of one stage-1 workgroup and the two steps every form of the kernel shares: the run's tables, then one tile's symbols + FIR
+struct TxShared {
+    float2 sym[4 * TX_SYMPH];
+    float2 gsp[TX_GLO + TX_MAXG + TX_GHI];
+    float cdf[8];
+    float amps[8];
+};
+__device__ __forceinline__ void tx_stage_tables(TxShared &sh, int run, int n_lev, int Lg, const float *__restrict__ amp, const float *__restrict__ cdf_g,
+                                                const float2 *__restrict__ g)
 {
-    __shared__ float2 sym[4 * TX_SYMPH];
-    __shared__ float2 gsp[TX_GLO + TX_MAXG + TX_GHI];
-    __shared__ float cdf[8];
-    __shared__ float amps[8];
-    const int run = blockIdx.z, pol = blockIdx.y, s0 = blockIdx.x * TX_TILE, tid = threadIdx.x;
-    if (tid < n_lev) { cdf[tid] = cdf_g[(size_t)run * n_lev + tid]; amps[tid] = amp[tid]; }
+    const int tid = threadIdx.x;
+    if (tid < n_lev) { sh.cdf[tid] = cdf_g[(size_t)run * n_lev + tid]; sh.amps[tid] = amp[tid]; }
     for (int i = tid; i < TX_GLO + TX_MAXG + TX_GHI; i += TX_NT) {
         const int k = i - TX_GLO;
-        gsp[i] = (k >= 0 && k < Lg) ? g[k] : make_float2(0.f, 0.f);
+        sh.gsp[i] = (k >= 0 && k < Lg) ? g[k] : make_float2(0.f, 0.f);
     }
     __syncthreads();
+}
+// tile s0 .. s0 + 2047 of (run, pol): symbols into LDS (and, for the ones the tile owns, out as the TX reference), barrier, then the 8 samples
+// 8 tid .. 8 tid + 7 of the tile into acc.  `last`: the row's last tile also owns the symbols past its own half.
+__device__ __forceinline__ void tx_tile_fir(TxShared &sh, int s0, bool last, int run, int pol, int npol, int N_conv, int n_lev, int Lg, uint64_t seed,
+                                            uint32_t frame, int N, int ref_lo, __half *__restrict__ data, cacc (&acc)[8])
+{
+    const int tid = threadIdx.x;
     const int nlo = s0 / 2;                                                    // even (TX_TILE / 2 is)
     const int cnt = TX_TILE / 2 + (Lg + 7) / 2 + 8;                            // symbols this tile may touch (<= 4 * TX_SYMPH)
-    const bool last = s0 + TX_TILE >= Lrow;
     __half *dI = data ? data + ((size_t)(run * npol + pol) * 2 + 0) * N : nullptr, *dQ = dI ? dI + N : nullptr;
     for (int pi = tid; 2 * pi < cnt; pi += TX_NT) {
         const int n = nlo + 2 * pi;
         int lv[4];
-        draw_symbol_pair(seed, frame, run, pol, (uint32_t)n, cdf, n_lev, lv);
+        draw_symbol_pair(seed, frame, run, pol, (uint32_t)n, sh.cdf, n_lev, lv);
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             const int ne = n + e, m = 2 * pi + e;
             const bool in = ne < N_conv;
-            const float aI = amps[lv[2 * e]], aQ = amps[lv[2 * e + 1]];
-            sym[(m & 3) * TX_SYMPH + (m >> 2)] = in ? make_float2(aI, aQ) : make_float2(0.f, 0.f);
+            const float aI = sh.amps[lv[2 * e]], aQ = sh.amps[lv[2 * e + 1]];
+            sh.sym[(m & 3) * TX_SYMPH + (m >> 2)] = in ? make_float2(aI, aQ) : make_float2(0.f, 0.f);
             const int nr = ne - ref_lo;
             if (dI && in && nr >= 0 && nr < N && (m < TX_TILE / 2 || last)) {   // each symbol is owned by exactly one tile
                 dI[nr] = __float2half(aI);
@@ -122,13 +128,10 @@ __global__ __launch_bounds__(TX_NT) void gen_tx_kernel(int N_conv, int n_lev, in
         }
     }
     __syncthreads();
-    const int sb = s0 + 8 * tid;
-    // (MODE 0: every thread stays for the output transpose)
-    cacc acc[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) acc[i] = cacc0();
     const int MW = ((Lg + 7) / 2 + 1 + 3) & ~3;                                // symbols m = 0 .. MW-1 relative to 4 tid
-    const float2 *gp = gsp + TX_GLO;
+    const float2 *gp = sh.gsp + TX_GLO;
 #pragma unroll 1
     for (int m0 = 0; m0 < MW; m0 += 4) {
         const int kb = Lg - 1 - 2 * m0;                                        // sample i of symbol m0 + mm uses tap kb - 2 mm + i
@@ -137,11 +140,48 @@ __global__ __launch_bounds__(TX_NT) void gen_tx_kernel(int N_conv, int n_lev, in
         for (int j = 0; j < 14; j++) tp[j] = gp[kb - 6 + j];
 #pragma unroll
         for (int mm = 0; mm < 4; mm++) {
-            const float2 sv = sym[mm * TX_SYMPH + tid + (m0 >> 2)];
+            const float2 sv = sh.sym[mm * TX_SYMPH + tid + (m0 >> 2)];
 #pragma unroll
             for (int i = 0; i < 8; i++) cmac(acc[i], tp[6 - 2 * mm + i].x, tp[6 - 2 * mm + i].y, sv);
         }
     }
+}
+// AWGN: sample pairs (sb + 2u, sb + 2u + 1) of one tile + noise -> planar rx (noise word j = sample / 2: the same Philox words as gen_finish_kernel)
+__device__ __forceinline__ void tx_noise_store(const cacc (&acc)[8], int sb, float sigma, int run, int pol, uint64_t seed, uint32_t frame, int Lout,
+                                               float *__restrict__ rI, float *__restrict__ rQ)
+{
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int i0 = sb + 2 * u;
+        if (i0 >= Lout) break;
+        const Philox4 r = philox4x32_10((uint32_t)(i0 >> 1), run, frame, (uint32_t)(STREAM_NOISE * 2 + pol), (uint32_t)seed, (uint32_t)(seed >> 32));
+        float sn0, cs0, sn1, cs1;
+        const float rad0 = sigma * sqrtf(-2.0f * __logf(u01(r.x))), rad1 = sigma * sqrtf(-2.0f * __logf(u01(r.z)));
+        __sincosf(6.283185307179586f * u01(r.y), &sn0, &cs0);
+        __sincosf(6.283185307179586f * u01(r.w), &sn1, &cs1);
+        const float2 v0 = cfin(acc[2 * u]), v1 = cfin(acc[2 * u + 1]);
+        rI[i0] = v0.x + rad0 * cs0;
+        rQ[i0] = v0.y + rad0 * sn0;
+        if (i0 + 1 < Lout) {
+            rI[i0 + 1] = v1.x + rad1 * cs1;
+            rQ[i0 + 1] = v1.y + rad1 * sn1;
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(TX_NT) void gen_tx_kernel(int N_conv, int n_lev, int Lg, int Ls, int Lrow, const float *__restrict__ amp,
+                                                       const float *__restrict__ cdf_g, const float2 *__restrict__ g, uint64_t seed,
+                                                       uint32_t frame, int npol, float2 *__restrict__ sig, int N, int ref_lo,
+                                                       __half *__restrict__ data, TxFuse fz)
+{
+    __shared__ TxShared sh;
+    const int run = blockIdx.z, pol = blockIdx.y, s0 = blockIdx.x * TX_TILE, tid = threadIdx.x;
+    tx_stage_tables(sh, run, n_lev, Lg, amp, cdf_g, g);
+    const int sb = s0 + 8 * tid;
+    // (MODE 0: every thread stays for the output transpose)
+    cacc acc[8];
+    tx_tile_fir(sh, s0, s0 + TX_TILE >= Lrow, run, pol, npol, N_conv, n_lev, Lg, seed, frame, N, ref_lo, data, acc);
     __shared__ float red[64];
     if (MODE == 0) {
         // a thread holds 8 CONSECUTIVE samples (64 bytes): written straight out, a wave's store would touch 64 separate 64-byte segments.  They
@@ -187,23 +227,44 @@ __global__ __launch_bounds__(TX_NT) void gen_tx_kernel(int N_conv, int n_lev, in
     }
     if (fz.sigma_out && blockIdx.x == 0 && tid == 0) fz.sigma_out[run] = sigma;
     float *rI = fz.rx + (size_t)run * 2 * fz.Lout, *rQ = rI + fz.Lout;
+    tx_noise_store(acc, sb, sigma, run, pol, seed, frame, fz.Lout, rI, rQ);
+}
+
+// AWGN frames of up to NT tiles (training frames: 1200 symbols = 2 tiles) in ONE pass, one workgroup per run: the tiles' clean samples stay in
+// registers while their power is summed (per tile, then over the tiles in order: bitwise the sums of the two-pass form), then the noise goes on.
+// Against MODE 1 + MODE 2: symbols drawn and FIR computed once instead of twice, one launch.
+template <int NT>
+__global__ __launch_bounds__(TX_NT) void gen_awgn_onepass_kernel(int N_conv, int n_lev, int Lg, int Ls, const float *__restrict__ amp,
+                                                                 const float *__restrict__ cdf_g, const float2 *__restrict__ g, uint64_t seed,
+                                                                 uint32_t frame, int N, int ref_lo, __half *__restrict__ data, TxFuse fz)
+{
+    __shared__ TxShared sh;
+    __shared__ float red[64];
+    const int run = blockIdx.x, tid = threadIdx.x, ntile = (Ls + TX_TILE - 1) / TX_TILE;
+    tx_stage_tables(sh, run, n_lev, Lg, amp, cdf_g, g);
+    cacc acc[NT][8];
+    float pw = 0.f;
 #pragma unroll
-    for (int u = 0; u < 4; u++) {                              // sample pairs (sb + 2u, sb + 2u + 1): noise word j = sample / 2
-        const int i0 = sb + 2 * u;
-        if (i0 >= fz.Lout) break;
-        const Philox4 r = philox4x32_10((uint32_t)(i0 >> 1), run, frame, (uint32_t)(STREAM_NOISE * 2 + pol), (uint32_t)seed, (uint32_t)(seed >> 32));
-        float sn0, cs0, sn1, cs1;
-        const float rad0 = sigma * sqrtf(-2.0f * __logf(u01(r.x))), rad1 = sigma * sqrtf(-2.0f * __logf(u01(r.z)));
-        __sincosf(6.283185307179586f * u01(r.y), &sn0, &cs0);
-        __sincosf(6.283185307179586f * u01(r.w), &sn1, &cs1);
-        const float2 v0 = cfin(acc[2 * u]), v1 = cfin(acc[2 * u + 1]);
-        rI[i0] = v0.x + rad0 * cs0;
-        rQ[i0] = v0.y + rad0 * sn0;
-        if (i0 + 1 < fz.Lout) {
-            rI[i0 + 1] = v1.x + rad1 * cs1;
-            rQ[i0 + 1] = v1.y + rad1 * sn1;
+    for (int t = 0; t < NT; t++) {
+        if (t < ntile) {                                       // uniform
+            tx_tile_fir(sh, t * TX_TILE, t == ntile - 1, run, 0, 1, N_conv, n_lev, Lg, seed, frame, N, ref_lo, data, acc[t]);
+            const int sb = t * TX_TILE + 8 * tid;
+            float p = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float2 v = cfin(acc[t][i]);
+                if (sb + i < Ls) p += v.x * v.x + v.y * v.y;
+            }
+            block_reduce3<TX_NT>(p, 0.f, 0.f, red);             // ends with a barrier: the next tile may overwrite the symbols
+            pw += red[0];
         }
     }
+    const float sigma = fz.sigma_fixed ? fz.sigma_fixed[run] : sqrtf(pw / (float)Ls * (float)fz.sps * 0.5f / exp10f(fz.snr_db[run] * 0.1f));
+    if (fz.sigma_out && tid == 0) fz.sigma_out[run] = sigma;
+    float *rI = fz.rx + (size_t)run * 2 * fz.Lout, *rQ = rI + fz.Lout;
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+        if (t < ntile) tx_noise_store(acc[t], t * TX_TILE + 8 * tid, sigma, run, 0, seed, frame, fz.Lout, rI, rQ);
 }
 
 // any sps: one thread per output sample, symbols and reference drawn per use
@@ -426,6 +487,15 @@ extern "C" int vaeq_gen_awgn(int32_t R, int32_t N, int32_t N_conv, int32_t sps, 
         const dim3 grid((Ls + vaeq::TX_TILE - 1) / vaeq::TX_TILE, 1, R);
         const float2 *g2 = reinterpret_cast<const float2 *>(g_complex);
         vaeq::TxFuse fz{power_ws, snr_db, sigma_fixed, rx, sigma_out, sps * N, sps};
+        const char *two_env = getenv("VAEQ_AWGN_TWOPASS");     // A/B switch: the two-pass form for every frame length
+        if (grid.x <= 4 && !(two_env && two_env[0] == '1')) {  // short frames (the training frames of both AWGN scripts): one pass, one workgroup per run
+            __half *dh = reinterpret_cast<__half *>(data_f16);
+            if (grid.x <= 2)
+                hipLaunchKernelGGL(vaeq::gen_awgn_onepass_kernel<2>, dim3(R), dim3(vaeq::TX_NT), 0, st, N_conv, n_lev, Lg, Ls, amp, cdf, g2, seed, frame, N, ref_offset, dh, fz);
+            else
+                hipLaunchKernelGGL(vaeq::gen_awgn_onepass_kernel<4>, dim3(R), dim3(vaeq::TX_NT), 0, st, N_conv, n_lev, Lg, Ls, amp, cdf, g2, seed, frame, N, ref_offset, dh, fz);
+            return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+        }
         if (!sigma_fixed)
             hipLaunchKernelGGL(vaeq::gen_tx_kernel<1>, grid, dim3(vaeq::TX_NT), 0, st, N_conv, n_lev, Lg, Ls, Ls, amp, cdf, g2, seed, frame, 1, sig, N,
                                ref_offset, static_cast<__half *>(nullptr), fz);
