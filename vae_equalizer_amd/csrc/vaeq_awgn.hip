@@ -333,6 +333,8 @@ __global__ __launch_bounds__(256) void awgn_forward_kernel(int64_t N, int sps, i
 //   SER_q (:97-123) on q[:, 11+sh : -11] vs data[:, 11 : -11-sh], minimum over the four quadrant rotations
 // MT > 0: tap count baked in, four symbols per thread from one register window (sps == 2).
 
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));             // four floats at any 4-byte boundary (one global_load_dwordx4)
+
 template <int NLEV, int MT>
 __global__ __launch_bounds__(256, 4) void awgn_validate_kernel(int N, int sps, int Mrt, int n_shift, const float *__restrict__ x,
                                                             const float *__restrict__ W, const float *__restrict__ amp_g,
@@ -367,12 +369,24 @@ __global__ __launch_bounds__(256, 4) void awgn_validate_kernel(int N, int sps, i
             const int64_t sb = 2 * (int64_t)n0 - pad;                          // first sample of the tile window
             __syncthreads();
             for (int v = tid; v < NCH; v += 256) {
+                const int64_t s4 = sb + 4 * v;
+                float a4[4], b4[4];
+                if (s4 >= 0 && s4 + 3 < L) {                                   // one 16-byte load per row (any 4-byte alignment)
+                    const f4u ua = *reinterpret_cast<const f4u *>(x0 + s4), ub = *reinterpret_cast<const f4u *>(x1 + s4);
+                    a4[0] = ua.x; a4[1] = ua.y; a4[2] = ua.z; a4[3] = ua.w;
+                    b4[0] = ub.x; b4[1] = ub.y; b4[2] = ub.z; b4[3] = ub.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const bool ok = s4 + i >= 0 && s4 + i < L;
+                        a4[i] = ok ? x0[s4 + i] : 0.f;
+                        b4[i] = ok ? x1[s4 + i] : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const int64_t sx = sb + 4 * v + i;
-                    const bool ok = sx >= 0 && sx < L;
                     const int c = 4 * v + i;
-                    xt[(c & 7) * XPH + (c >> 3)] = make_float2(ok ? x0[sx] : 0.f, ok ? x1[sx] : 0.f);
+                    xt[(c & 7) * XPH + (c >> 3)] = make_float2(a4[i], b4[i]);
                 }
             }
             __syncthreads();
@@ -402,13 +416,22 @@ __global__ __launch_bounds__(256, 4) void awgn_validate_kernel(int N, int sps, i
                     cmac(acc[t], w.x, w.y, xt[(j & 7) * XPH + tid + (j >> 3)]);
                 }
             }
+            {
+                const int nb = n0 + 4 * tid;
+                float2 yv[4];
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int n = n0 + 4 * tid + t;
-                if (n < N) {
-                    const float2 yv = cfin(acc[t]);
-                    y0[n] = yv.x; y1[n] = yv.y;
-                    sa0 += fabsf(yv.x); sa1 += fabsf(yv.y);
+                for (int t = 0; t < 4; t++) yv[t] = cfin(acc[t]);
+                if (nb + 3 < N) {                                              // 16-byte stores
+                    *reinterpret_cast<f4u *>(y0 + nb) = f4u{yv[0].x, yv[1].x, yv[2].x, yv[3].x};
+                    *reinterpret_cast<f4u *>(y1 + nb) = f4u{yv[0].y, yv[1].y, yv[2].y, yv[3].y};
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int n = nb + t;
+                    if (n < N) {
+                        if (nb + 3 >= N) { y0[n] = yv[t].x; y1[n] = yv[t].y; }
+                        sa0 += fabsf(yv[t].x); sa1 += fabsf(yv[t].y);
+                    }
                 }
             }
         }
@@ -438,33 +461,47 @@ __global__ __launch_bounds__(256, 4) void awgn_validate_kernel(int N, int sps, i
     bool uniform = delta > 0.f;
 #pragma unroll
     for (int i = 2; i < NLEV; i++) uniform = uniform && fabsf(amp[i] - (a0 + (float)i * delta)) <= 1e-6f * delta;
-    for (int n = tid; n < N; n += 256) {
-        const float yI = y0[n] * s0, yQ = y1[n] * s1;
-        int dI = 0, dQ = 0;
-        float bI = 3.0e38f, bQ = 3.0e38f;
-        if (uniform) {
-            dI = min(max((int)rintf((yI - a0) * rdelta), 0), NLEV - 1);
-            dQ = min(max((int)rintf((yQ - a0) * rdelta), 0), NLEV - 1);
-            const float dd = yI - (a0 + (float)dI * delta);                    // only stabilises the softmax of E below
-            bI = dd * dd;
+    for (int nb = 4 * tid; nb < N; nb += 4 * 256) {          // four consecutive symbols per thread: 16-byte loads of y
+        float yI4[4], yQ4[4];
+        if (nb + 3 < N) {
+            const f4u ua = *reinterpret_cast<const f4u *>(y0 + nb), ub = *reinterpret_cast<const f4u *>(y1 + nb);
+            yI4[0] = ua.x; yI4[1] = ua.y; yI4[2] = ua.z; yI4[3] = ua.w;
+            yQ4[0] = ub.x; yQ4[1] = ub.y; yQ4[2] = ub.z; yQ4[3] = ub.w;
         } else {
 #pragma unroll
-            for (int i = 0; i < NLEV; i++) {
-                const float eI = (yI - amp[i]) * (yI - amp[i]), eQ = (yQ - amp[i]) * (yQ - amp[i]);
-                if (eI < bI) { bI = eI; dI = i; }
-                if (eQ < bQ) { bQ = eQ; dQ = i; }
-            }
+            for (int t = 0; t < 4; t++) { yI4[t] = nb + t < N ? y0[nb + t] : 0.f; yQ4[t] = nb + t < N ? y1[nb + t] : 0.f; }
         }
-        decs[n] = (unsigned char)(dI | (dQ << 4));
-        if (n < NE) {
-            float ssum = 0.f, e1 = 0.f;
 #pragma unroll
-            for (int i = 0; i < NLEV; i++) {
-                const float d = yI - amp[i], w = __expf(bI * ivar - d * d * ivar);
-                ssum += w;
-                e1 = fmaf(amp[i], w, e1);
+        for (int t = 0; t < 4; t++) {
+            const int n = nb + t;
+            if (n >= N) break;
+            const float yI = yI4[t] * s0, yQ = yQ4[t] * s1;
+            int dI = 0, dQ = 0;
+            float bI = 3.0e38f, bQ = 3.0e38f;
+            if (uniform) {
+                dI = min(max((int)rintf((yI - a0) * rdelta), 0), NLEV - 1);
+                dQ = min(max((int)rintf((yQ - a0) * rdelta), 0), NLEV - 1);
+                const float dd = yI - (a0 + (float)dI * delta);                // only stabilises the softmax of E below
+                bI = dd * dd;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NLEV; i++) {
+                    const float eI = (yI - amp[i]) * (yI - amp[i]), eQ = (yQ - amp[i]) * (yQ - amp[i]);
+                    if (eI < bI) { bI = eI; dI = i; }
+                    if (eQ < bQ) { bQ = eQ; dQ = i; }
+                }
             }
-            E[n] = e1 / ssum;
+            decs[n] = (unsigned char)(dI | (dQ << 4));
+            if (n < NE) {
+                float ssum = 0.f, e1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < NLEV; i++) {
+                    const float d = yI - amp[i], w = __expf(bI * ivar - d * d * ivar);
+                    ssum += w;
+                    e1 = fmaf(amp[i], w, e1);
+                }
+                E[n] = e1 / ssum;
+            }
         }
     }
     __syncthreads();
