@@ -333,8 +333,6 @@ __global__ __launch_bounds__(256) void awgn_forward_kernel(int64_t N, int sps, i
 //   SER_q (:97-123) on q[:, 11+sh : -11] vs data[:, 11 : -11-sh], minimum over the four quadrant rotations
 // MT > 0: tap count baked in, four symbols per thread from one register window (sps == 2).
 
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));             // four floats at any 4-byte boundary (one global_load_dwordx4)
-
 template <int NLEV, int MT>
 __global__ __launch_bounds__(256, 4) void awgn_validate_kernel(int N, int sps, int Mrt, int n_shift, const float *__restrict__ x,
                                                             const float *__restrict__ W, const float *__restrict__ amp_g,

@@ -8,6 +8,9 @@ namespace vaeq {
 // the kernel it actually timed instead of a literal that can go stale when the dispatch changes).  Defined in vaeq_misc.hip.
 void note_kernel(const char *fmt, ...);
 
+// Four floats at any 4-byte boundary: one global_load_dwordx4 / global_store_dwordx4 (gfx950 serves unaligned vector accesses to global memory).
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
 // Sum over the 64 lanes of a wave, result in every lane.  Fixed xor-butterfly order:
 // bitwise reproducible run to run (no float atomics anywhere in this library).
 __device__ __forceinline__ float wave_sum(float v)

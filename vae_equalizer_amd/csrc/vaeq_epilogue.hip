@@ -29,8 +29,6 @@ constexpr int N_LAGH = 11;                    // lags per thread: h = 0 -> lags 
 constexpr int EPI_TILE = N_CHUNK * EPI_CH;    // 704 symbols staged in LDS per correlation tile
 constexpr int ES_LEN = EPI_TILE + 2 * HALF_SHIFT + 4;
 
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));             // four floats at any 4-byte boundary (one global_load_dwordx4)
-
 struct EpiShared {
     float corr[2][2][2][N_SHIFT];             // [c][b][a][lag]
     int shift[2];
