@@ -1,4 +1,5 @@
-// vaeq_dp_wave.hip -- dispatch of the wave-per-run DP kernel (vaeq_dp_wave_kernel.h): one wavefront per run for B <= 128; the
+// vaeq_dp_wave.hip -- dispatch of the wave-per-run DP kernel (vaeq_dp_wave_kernel.h): one wavefront per run for B <= 128 (M = 25: B = 100 and 128 baked,
+// every other even B on the fixed layout of B = 128; other M: run-time layout); the
 // multi-wave variants for 128 < B <= 1024 are instantiated in vaeq_dp_wave_mw.hip / vaeq_dp_wave_mw8.hip.
 #include "vaeq_dp_wave_kernel.h"
 
@@ -6,9 +7,11 @@ namespace vaeq {
 
 int launch_dp_wave_mw(const vaeq_dp_args &a, hipStream_t st);          // vaeq_dp_wave_mw.hip
 int64_t dp_wave_mw_resident(int B, int M, int n_lev);
-bool dp_wave_baked(int B, int M);                                       // vaeq_dp_wave_bk.hip
+bool dp_wave_fixl(int B, int M);                                        // vaeq_dp_wave_bk.hip (false under VAEQ_DP_RUNTIME_LAYOUT=1: A/B switch)
 int launch_dp_wave_bk(const vaeq_dp_args &a, hipStream_t st);
-int64_t dp_wave_bk_resident(int B, int n_lev);
+int64_t dp_wave_bk_resident(int n_lev);
+int launch_dp_wave_b128(const vaeq_dp_args &a, hipStream_t st);         // vaeq_dp_wave_b128.hip
+int64_t dp_wave_b128_resident(int n_lev);
 
 // Whether the wave-per-run kernel covers this call (else the generic kernel runs).
 bool dp_wave_supported(const vaeq_dp_args &a)
@@ -27,7 +30,8 @@ bool dp_wave_supported(const vaeq_dp_args &a)
 int64_t dp_wave_resident(int B, int M, int n_lev)
 {
     if (B > 128) return dp_wave_mw_resident(B, M, n_lev);
-    if (dp_wave_baked(B, M)) return dp_wave_bk_resident(B, n_lev);
+    if (M == 25 && B == 128 && dp_wave_fixl(64, 25)) return dp_wave_b128_resident(n_lev);
+    if (dp_wave_fixl(B, M)) return dp_wave_bk_resident(n_lev);
     switch (M) {
     case 25: return B == 100 ? wave_resident_lev<25, 100, 1>(B, n_lev) : wave_resident_lev<25, 0, 1>(B, n_lev);
     case 31: return wave_resident_lev<31, 0, 1>(B, n_lev);
@@ -42,7 +46,8 @@ int64_t dp_wave_resident(int B, int M, int n_lev)
 int launch_dp_wave(const vaeq_dp_args &a, hipStream_t st)
 {
     if (a.B > 128) return launch_dp_wave_mw(a, st);
-    if (dp_wave_baked(a.B, a.M)) return launch_dp_wave_bk(a, st);
+    if (a.M == 25 && a.B == 128 && dp_wave_fixl(64, 25)) return launch_dp_wave_b128(a, st);
+    if (dp_wave_fixl(a.B, a.M)) return launch_dp_wave_bk(a, st);
     switch (a.M) {
     case 25: return a.B == 100 ? launch_wave_lev<25, 100, 1>(a, st) : launch_wave_lev<25, 0, 1>(a, st);
     case 31: return launch_wave_lev<31, 0, 1>(a, st);

@@ -205,7 +205,7 @@ constexpr bool uniform_parts(int B, int M, int NP)
 // NW = wavefronts per run: 1 (B <= 128, no barriers at all) or 2 / 4 / 8 (B <= 256 / 512 / 1024): thread gl = 64 wv + lane owns the symbol pair
 // (2 gl, 2 gl + 1), the tap-gradient sums are split 2 NW ways, wave 0 owns the taps and their Adam moments; phases are separated
 // by s_barrier after an LDS-only wait (sync_lds), so the in-flight q / y stores still never stall a phase.
-template <int M, int NLEV, int BT, bool PAIR, int OUT, int NW = 1>
+template <int M, int NLEV, int BT, bool PAIR, int OUT, int NW = 1, int BL = 0>
 __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_dp_args a)
 {
     constexpr int mh = M / 2, Mh = 2 * mh, MP = M + 1;
@@ -216,13 +216,16 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
     constexpr int NT = 64 * NW, NP = 2 * NW;              // threads per run; parts a tap-gradient sum is split into
     // baked shape whose tap-gradient sums split into NP equal, non-empty parts: their loops run on a scalar trip count and start from the first term
     constexpr bool UNI = BT > 0 && uniform_parts(BT, M, NP);
-    constexpr bool PIPE = VAEQ_PIPE && BT > 0;             // run-time minibatch lengths keep more addresses live: there one operand set,
-    constexpr bool WIDE = BT > 0;                          // ... 8 accumulator chains and one chi at a time in dL/dU (fits the register file)
+    // BL > 0 (with BT == 0): the LDS LAYOUT of minibatch length BL (all offsets and strides immediate) for any run-time B <= BL of BL's parity class
+    constexpr bool FIXL = BT > 0 || BL > 0;
+    constexpr bool PIPE = VAEQ_PIPE && FIXL;               // run-time layouts keep more addresses live: there one operand set,
+    constexpr bool WIDE = FIXL;                            // ... 8 accumulator chains and one chi at a time in dL/dU (fits the register file)
     constexpr bool PIPE_DU = VAEQ_PIPE_DU;                 // dL/dU runs at the kernel's register peak (moments of the demapper still live): no second operand set there
     const int B = BT ? BT : a.B;
+    const int BS = BT ? BT : BL ? BL : B;                      // the minibatch length the LDS layout (offsets, row strides) is made for
     const int L = 2 * B, nm = L - Mh, P2 = B / 2;
     const float rnm = 1.0f / (float)nm;
-    const WaveLayout lay = wave_layout(B, M, NW);
+    const WaveLayout lay = wave_layout(BS, M, NW);
     const int Lph = lay.Lph, Uph = lay.Uph;
     float2 *Xs = reinterpret_cast<float2 *>(sm + lay.X), *Es = reinterpret_cast<float2 *>(sm + lay.E);
     float2 *Us = reinterpret_cast<float2 *>(sm + lay.U), *GY = Us;
@@ -482,16 +485,16 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
 #pragma unroll
                 for (int o = 0; o < 2; o++) {
                     if (act) {
-                        PSv[o * (B + 1) + n0 + 1] = inc[o] - vv[o][1];
-                        PSv[o * (B + 1) + n0 + 2] = inc[o];
+                        PSv[o * (BS + 1) + n0 + 1] = inc[o] - vv[o][1];
+                        PSv[o * (BS + 1) + n0 + 2] = inc[o];
                     }
-                    if (gl == 0) PSv[o * (B + 1)] = 0.f;
+                    if (gl == 0) PSv[o * (BS + 1)] = 0.f;
                 }
             }
             sync_lds<NW>();
             if (owner) {                                       // VS[nu][j]: lane = (j = tk, nu = half)
                 const int lo = (Mh - tk + 1) >> 1, hi_ = (nm - 1 + Mh - tk) >> 1;
-                VS[half * M + tk] = PSv[half * (B + 1) + hi_ + 1] - PSv[half * (B + 1) + lo];
+                VS[half * M + tk] = PSv[half * (BS + 1) + hi_ + 1] - PSv[half * (BS + 1) + lo];
             }
             sync_lds<NW>();
 
@@ -778,8 +781,8 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
             if (act) {
 #pragma unroll
                 for (int v = 0; v < 2; v++) {
-                    GY[v * B + n0] = gy[0][v];
-                    GY[v * B + n0 + 1] = gy[1][v];
+                    GY[v * BS + n0] = gy[0][v];
+                    GY[v * BS + n0 + 1] = gy[1][v];
                 }
             }
             if (owner && !a.no_update) {
@@ -810,7 +813,7 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                     const int ma = (part * Bq) >> 1, mb = min(B, part * Bq + Bq) >> 1;
                     const int cA = tkc, cB = tkc + 2;
                     const float2 *xA = Xs + (cA & 3) * Lph + (cA >> 2) + ma, *xB = Xs + (cB & 3) * Lph + (cB >> 2) + ma;
-                    const float2 *G0 = GY + 2 * ma, *G1 = GY + B + 2 * ma;
+                    const float2 *G0 = GY + 2 * ma, *G1 = GY + BS + 2 * ma;
                     auto load1 = [&](int m, v2f *r) {
                         r[0] = lds2(G0 + 2 * m); r[1] = lds2(G0 + 2 * m + 1); r[2] = lds2(G1 + 2 * m); r[3] = lds2(G1 + 2 * m + 1);   // gy[o][2m], gy[o][2m+1]
                         r[4] = lds2(xA + m); r[5] = lds2(xA + 4 * Lph + m); r[6] = lds2(xB + m); r[7] = lds2(xB + 4 * Lph + m);
@@ -962,6 +965,36 @@ static int launch_wave(const vaeq_dp_args &a, hipStream_t st)
     note_kernel("vaeq::dp_wave_kernel<%d, %d, %d, %s, %d, %d>", M, NLEV, BT, pair ? "true" : "false", out, NW);
     hipLaunchKernelGGL(k, dim3(a.R), dim3(64 * NW), lds, st, a);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}
+
+// run-time B <= BL on the fixed LDS layout of BL (immediate offsets and strides, pipelined tap loops), with the output-mode specialisations
+template <int M, int NLEV, int BL, int NW>
+static int launch_wave_fixl(const vaeq_dp_args &a, hipStream_t st)
+{
+    const size_t lds = (size_t)wave_layout(BL, M, NW).total;
+    const bool pair = ((a.keep_len | a.keep_off) & 1) == 0;
+    const int out = (!a.eq_out && !a.dec_out) ? 1 : !a.q_out ? 2 : 0;
+    void (*k)(const vaeq_dp_args);
+    if (out == 1) k = pair ? dp_wave_kernel<M, NLEV, 0, true, 1, NW, BL> : dp_wave_kernel<M, NLEV, 0, false, 1, NW, BL>;
+    else if (out == 2) k = pair ? dp_wave_kernel<M, NLEV, 0, true, 2, NW, BL> : dp_wave_kernel<M, NLEV, 0, false, 2, NW, BL>;
+    else k = pair ? dp_wave_kernel<M, NLEV, 0, true, 0, NW, BL> : dp_wave_kernel<M, NLEV, 0, false, 0, NW, BL>;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return VAEQ_ERR_LDS;
+    note_kernel("vaeq::dp_wave_kernel<%d, %d, 0, %s, %d, %d, %d>", M, NLEV, pair ? "true" : "false", out, NW, BL);
+    hipLaunchKernelGGL(k, dim3(a.R), dim3(64 * NW), lds, st, a);
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}
+
+template <int M, int NLEV, int BL, int NW>
+static int64_t wave_resident_fixl()
+{
+    int nb = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return VAEQ_ERR_DEVICE;
+    auto k = dp_wave_kernel<M, NLEV, 0, true, 0, NW, BL>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64 * NW, (size_t)wave_layout(BL, M, NW).total) != hipSuccess) return VAEQ_ERR_DEVICE;
+    return (int64_t)nb * prop.multiProcessorCount;
 }
 
 template <int M, int BT, int NW>
