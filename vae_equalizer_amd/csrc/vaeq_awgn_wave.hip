@@ -19,6 +19,10 @@
 #include "vaeq_common.h"
 #include "vaeq_wave.h"
 
+#ifndef VAEQ_AWGN_BAKED_FULL
+#define VAEQ_AWGN_BAKED_FULL 1
+#endif
+
 namespace vaeq {
 
 struct AwgnWaveLayout {
@@ -51,10 +55,10 @@ __host__ __device__ inline AwgnWaveLayout awgn_wave_layout(int B, int M, int NW 
 // acc[r][sym] = sum_k taps[k] (x) x_r[2*sym + k] for the symbol pair of every round; xp[r] = the lane's phase-0 pointer in round r.
 // With up to two rounds per lane: the first tap group starts the accumulators and the 8-byte LDS reads stay ds_read_b64 (lds2): +4 % at B = 512.  With
 // three rounds the kernel is register-starved and that form costs more in spills than it saves (43 spilled dwords, -8 % at B = 350): round 1's form there.
-template <int M, int NR>
+template <int M, int NR, bool LEAN = (NR >= 3)>
 __device__ __forceinline__ void wave_fir(cacc (&acc)[NR][2], const float2 *(&xp)[NR], int Lph, const float2 *taps)
 {
-    if constexpr (NR >= 3) {                           // register-starved (three rounds per lane): zeroed accumulators, ordinary loads
+    if constexpr (LEAN) {                           // register-starved (three rounds per lane): zeroed accumulators, ordinary loads
 #pragma unroll
         for (int r = 0; r < NR; r++) acc[r][0] = acc[r][1] = cacc0();
         constexpr int G = M / 4;
@@ -133,7 +137,8 @@ __device__ __forceinline__ void amsgrad_fast(float &p, float &m, float &v, float
 }
 
 // NW = wavefronts per run (1: no barriers; 2..4 for B > 384, see vaeq_dp_wave_kernel.h): wave wv owns the pairs 64 NR wv + 64 r + lane.
-template <int M, int NLEV, int NR, int NW = 1>
+// BL > 0: the minibatch length baked into the kernel (LDS offsets immediate, trip counts constant)
+template <int M, int NLEV, int NR, int NW = 1, int BL = 0>
 __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_args a)
 {
     constexpr int mh = M / 2, Mh = 2 * mh;
@@ -143,7 +148,8 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
     const int gl = threadIdx.x, lane = NW > 1 ? (gl & 63) : gl, wv = NW > 1 ? (gl >> 6) : 0, run = blockIdx.x;
     const int l0 = lane + 64 * NR * wv;                       // first pair of this lane
     constexpr int NT = 64 * NW;
-    const int B = a.B, L = 2 * B, nm = L - Mh, P2 = B / 2, nq = (nm + 3) / 4;
+    constexpr bool LEAN = NR >= 3 && !(BL && VAEQ_AWGN_BAKED_FULL);   // three rounds per lane are register-starved unless the shape is baked
+    const int B = BL ? BL : a.B, L = 2 * B, nm = L - Mh, P2 = B / 2, nq = (nm + 3) / 4;
     const float rB = 1.0f / (float)B;
     const AwgnWaveLayout lay = awgn_wave_layout(B, M, NW);
     const int Lph = lay.Lph, Uph = lay.Uph;
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
         float2 y[NR][2];
         {
             cacc ya[NR][2];
-            wave_fir<M, NR>(ya, xp, Lph, Wt);
+            wave_fir<M, NR, LEAN>(ya, xp, Lph, Wt);
 #pragma unroll
             for (int r = 0; r < NR; r++)
 #pragma unroll
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
         float se = 0.f;
         {
             cacc D[NR][4];
-            if constexpr (NR >= 3) {                           // (see wave_fir)
+            if constexpr (LEAN) {                              // (see wave_fir)
     #pragma unroll
                 for (int r = 0; r < NR; r++)
     #pragma unroll
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
             float dt0 = 0.f, dt1 = 0.f;
             {
                 cacc cu[NR][2];
-                wave_fir<M, NR>(cu, ep, Lph, Ht);
+                wave_fir<M, NR, LEAN>(cu, ep, Lph, Ht);
 #pragma unroll
                 for (int r = 0; r < NR; r++)
 #pragma unroll
@@ -635,15 +641,16 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
     if (gl == 0 && !a.no_update) a.step[run] = step;
 }
 
-template <int M, int NLEV, int NR, int NW = 1>
+template <int M, int NLEV, int NR, int NW = 1, int BL = 0>
 static int launch_awgn_wave_k(const vaeq_awgn_args &a, hipStream_t st)
 {
     const size_t lds = (size_t)awgn_wave_layout(a.B, M, NW).total;
-    auto k = awgn_wave_kernel<M, NLEV, NR, NW>;
+    auto k = awgn_wave_kernel<M, NLEV, NR, NW, BL>;
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VAEQ_ERR_LDS;
-    note_kernel("vaeq::awgn_wave_kernel<%d, %d, %d, %d>", M, NLEV, NR, NW);
+    if (BL) note_kernel("vaeq::awgn_wave_kernel<%d, %d, %d, %d, %d>", M, NLEV, NR, NW, BL);
+    else note_kernel("vaeq::awgn_wave_kernel<%d, %d, %d, %d>", M, NLEV, NR, NW);
     hipLaunchKernelGGL(k, dim3(a.R), dim3(64 * NW), lds, st, a);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
@@ -651,6 +658,7 @@ static int launch_awgn_wave_k(const vaeq_awgn_args &a, hipStream_t st)
 template <int M, int NLEV>
 static int launch_awgn_wave_r(const vaeq_awgn_args &a, hipStream_t st)
 {
+    if (M == 25 && a.B == 350) return launch_awgn_wave_k<M, NLEV, 3, 1, M == 25 ? 350 : 0>(a, st);   // the reference's minibatch (Eval_run_shaping_vaele.py:26), baked
     switch ((a.B / 2 + 63) / 64) {
     case 1: return launch_awgn_wave_k<M, NLEV, 1>(a, st);
     case 2: return launch_awgn_wave_k<M, NLEV, 2>(a, st);
