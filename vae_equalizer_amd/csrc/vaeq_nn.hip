@@ -863,8 +863,9 @@ __global__ __launch_bounds__(NT) void nn_forward_kernel(int N, int sps, int M, i
 
 // Fused validation pass (:287-301): tiled eval forward, hard decisions = argmax of the logits (first maximum, like argmax q),
 // E_q[x_I] of the first 1000 symbols, then the common shift search + SER; q never leaves the chip.
-template <int NT, int NLEV>
-__global__ __launch_bounds__(NT) void nn_validate_kernel(int N, int sps, int M, int k1, int k2, int n_shift, const float *__restrict__ x,
+// BK = 1: the sweep script's shape (sps = 2, M = 25, k1 = 25, k2 = 3) baked
+template <int NT, int NLEV, int BK = 0>
+__global__ __launch_bounds__(NT) void nn_validate_kernel(int N, int sps_, int M_, int k1_, int k2_, int n_shift, const float *__restrict__ x,
                                                          const float *__restrict__ theta, const float *__restrict__ bn_running,
                                                          const float *__restrict__ amp_g, const __half *__restrict__ data,
                                                          float *__restrict__ ser_out, int *__restrict__ shift_out)
@@ -876,6 +877,7 @@ __global__ __launch_bounds__(NT) void nn_validate_kernel(int N, int sps, int M, 
     __shared__ int sh_s;
     const int tid = threadIdx.x, run = blockIdx.x;
     constexpr int C = 2 * NLEV;
+    const int sps = BK ? 2 : sps_, M = BK ? 25 : M_, k1 = BK ? 25 : k1_, k2 = BK ? 3 : k2_;
     const bool bn = bn_running != nullptr;
     const NNLayout l = nn_layout(NN_TILE, sps, M, NLEV, k1, k2, bn, true);
     float *xs = sm + l.xs, *z1 = sm + l.z1, *a2 = sm + l.a2, *th = sm + l.th, *w1t = sm + l.w1t, *w2t = sm + l.w2t, *red = sm + l.red;
@@ -935,7 +937,7 @@ static int launch_nn_validate(int R, int N, int sps, int M, int k1, int k2, int 
 {
     const size_t lds = (size_t)nn_layout(NN_TILE, sps, M, NLEV, k1, k2, bn != nullptr, true).total * 4 + (((size_t)N + 15) & ~(size_t)15);
     if (lds > 150 * 1024) return VAEQ_ERR_LDS;
-    auto k = nn_validate_kernel<1024, NLEV>;
+    auto k = (NLEV == 8 && sps == 2 && M == 25 && k1 == 25 && k2 == 3) ? nn_validate_kernel<1024, NLEV, NLEV == 8 ? 1 : 0> : nn_validate_kernel<1024, NLEV, 0>;   // (64-QAM only: see launch_nn_train)
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VAEQ_ERR_LDS;
     hipLaunchKernelGGL(k, dim3(R), dim3(1024), lds, st, N, sps, M, k1, k2, n_shift, x, theta, bn, amp, data, ser, shift);
