@@ -42,7 +42,7 @@ def test_bench_line_contract():
     assert set(sm) == {"generate", "train", "epilogue"} and all(v > 0 for v in sm.values()) and sm["train"] > 0.5 * rf["kernel_ms"]
     c4, c2 = e["configs"]["config4_vaeflex"], e["configs"]["config2_awgn"]
     assert c4["kernel"].startswith("vaeq::dp_wave_kernel<25, 8, ") and c4["value"] > 0 and 0 < c4["flop_frac"] < 1
-    assert c2["kernel"].startswith("vaeq::awgn_wave_kernel<25, 8, 3, 1>") and c2["value"] > 0 and 0 < c2["flop_frac"] < 1
+    assert c2["kernel"].startswith("vaeq::awgn_wave_kernel<25, 8, 3, 1, 350>") and c2["value"] > 0 and 0 < c2["flop_frac"] < 1
     ep = c2["epoch_pipeline"]
     assert ep["ms_train_part"] > 0 and ep["ms_validation_part"] > ep["ms_train_part"] and ep["run_epochs_per_s_epe2"] > 0
     cb = d["cpu_baseline"]
