@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Kernel time of one frame (100 minibatch steps of B=100 [argv 4], M=25, 64-QAM) vs number of runs, per kernel variant.
+"""Kernel time of one frame (100 minibatch steps of B=100 [argv 4], M=25 [argv 5], 64-QAM) vs number of runs, per kernel variant.
 Shows residency (time is flat while all runs are co-resident) and per-step latency.  GPU box only."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,11 +13,12 @@ def main():
     Rs = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else "64,256,512,1024,2048,3072,4096,6144".split(","))]
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
     B = int(sys.argv[4]) if len(sys.argv) > 4 else 100
+    M = int(sys.argv[5]) if len(sys.argv) > 5 else 25
     g = torch.Generator(device=dev).manual_seed(0)
     for th in variants:
         for R in Rs:
             rx = 0.4 * torch.randn(R, 1, 2, 2, steps * 2 * B, device=dev, generator=g)
-            eng = DPEngine(R, 25, amp, np.full(8, 1 / 8, np.float32), [0.0025, 0.0025], 0.0, dev, 2, th)
+            eng = DPEngine(R, M, amp, np.full(8, 1 / 8, np.float32), [0.0025, 0.0025], 0.0, dev, 2, th)
             for _ in range(2):
                 out = eng.train(rx, B, steps, 2.5e-3)
             torch.cuda.synchronize()

@@ -1,5 +1,5 @@
 // vaeq_dp_wave.hip -- dispatch of the wave-per-run DP kernel (vaeq_dp_wave_kernel.h): one wavefront per run for B <= 128 (M = 25: B = 100 and 128 baked,
-// every other even B on the fixed layout of B = 128; other M: run-time layout); the
+// every other even B on the fixed layout of B = 128 -- like all B of the other tap counts; the run-time layout only as M = 25's A/B form); the
 // multi-wave variants for 128 < B <= 1024 are instantiated in vaeq_dp_wave_mw.hip / vaeq_dp_wave_mw8.hip.
 #include "vaeq_dp_wave_kernel.h"
 
@@ -32,15 +32,8 @@ int64_t dp_wave_resident(int B, int M, int n_lev)
     if (B > 128) return dp_wave_mw_resident(B, M, n_lev);
     if (M == 25 && B == 128 && dp_wave_fixl(64, 25)) return dp_wave_b128_resident(n_lev);
     if (dp_wave_fixl(B, M)) return dp_wave_bk_resident(n_lev);
-    switch (M) {
-    case 25: return B == 100 ? wave_resident_lev<25, 100, 1>(B, n_lev) : wave_resident_lev<25, 0, 1>(B, n_lev);
-    case 31: return wave_resident_lev<31, 0, 1>(B, n_lev);
-    case 21: return wave_resident_lev<21, 0, 1>(B, n_lev);
-    case 17: return wave_resident_lev<17, 0, 1>(B, n_lev);
-    case 13: return wave_resident_lev<13, 0, 1>(B, n_lev);
-    case 9: return wave_resident_lev<9, 0, 1>(B, n_lev);
-    }
-    return VAEQ_ERR_SHAPE;
+    if (M == 25 && B == 100) return wave_resident_lev<25, 100, 1>(B, n_lev);
+    return wave_resident_any<1>(B, M, n_lev);
 }
 
 int launch_dp_wave(const vaeq_dp_args &a, hipStream_t st)
@@ -48,15 +41,8 @@ int launch_dp_wave(const vaeq_dp_args &a, hipStream_t st)
     if (a.B > 128) return launch_dp_wave_mw(a, st);
     if (a.M == 25 && a.B == 128 && dp_wave_fixl(64, 25)) return launch_dp_wave_b128(a, st);
     if (dp_wave_fixl(a.B, a.M)) return launch_dp_wave_bk(a, st);
-    switch (a.M) {
-    case 25: return a.B == 100 ? launch_wave_lev<25, 100, 1>(a, st) : launch_wave_lev<25, 0, 1>(a, st);
-    case 31: return launch_wave_lev<31, 0, 1>(a, st);
-    case 21: return launch_wave_lev<21, 0, 1>(a, st);
-    case 17: return launch_wave_lev<17, 0, 1>(a, st);
-    case 13: return launch_wave_lev<13, 0, 1>(a, st);
-    case 9: return launch_wave_lev<9, 0, 1>(a, st);
-    }
-    return VAEQ_ERR_SHAPE;
+    if (a.M == 25 && a.B == 100) return launch_wave_lev<25, 100, 1>(a, st);
+    return launch_wave_any<1>(a, st);
 }
 
 }  // namespace vaeq

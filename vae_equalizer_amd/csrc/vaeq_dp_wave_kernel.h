@@ -217,7 +217,9 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
     // baked shape whose tap-gradient sums split into NP equal, non-empty parts: their loops run on a scalar trip count and start from the first term
     constexpr bool UNI = BT > 0 && uniform_parts(BT, M, NP);
     // BL > 0 (with BT == 0): the LDS LAYOUT of minibatch length BL (all offsets and strides immediate) for any run-time B <= BL of BL's parity class
-    constexpr bool FIXL = BT > 0 || BL > 0;
+    // (M = 13 / 17 on a fixed layout: the pipelined form unrolls into 27-117 spilled registers and loses 25-38 %: they keep the lean loops; so
+    //  does M = 31 at one wavefront per run, where it costs 2-5 %)
+    constexpr bool FIXL = BT > 0 || (BL > 0 && M != 13 && M != 17 && !(M == 31 && NW == 1));
     constexpr bool PIPE = VAEQ_PIPE && FIXL;               // run-time layouts keep more addresses live: there one operand set,
     constexpr bool WIDE = FIXL;                            // ... 8 accumulator chains and one chi at a time in dL/dU (fits the register file)
     constexpr bool PIPE_DU = VAEQ_PIPE_DU;                 // dL/dU runs at the kernel's register peak (moments of the demapper still live): no second operand set there
@@ -968,16 +970,18 @@ static int launch_wave(const vaeq_dp_args &a, hipStream_t st)
 }
 
 // run-time B <= BL on the fixed LDS layout of BL (immediate offsets and strides, pipelined tap loops), with the output-mode specialisations
-template <int M, int NLEV, int BL, int NW>
+// (SPEC = false: only the all-outputs-nullable instantiation, for the tap counts that are not the reference's default)
+template <int M, int NLEV, int BL, int NW, bool SPEC = true>
 static int launch_wave_fixl(const vaeq_dp_args &a, hipStream_t st)
 {
     const size_t lds = (size_t)wave_layout(BL, M, NW).total;
     const bool pair = ((a.keep_len | a.keep_off) & 1) == 0;
-    const int out = (!a.eq_out && !a.dec_out) ? 1 : !a.q_out ? 2 : 0;
-    void (*k)(const vaeq_dp_args);
-    if (out == 1) k = pair ? dp_wave_kernel<M, NLEV, 0, true, 1, NW, BL> : dp_wave_kernel<M, NLEV, 0, false, 1, NW, BL>;
-    else if (out == 2) k = pair ? dp_wave_kernel<M, NLEV, 0, true, 2, NW, BL> : dp_wave_kernel<M, NLEV, 0, false, 2, NW, BL>;
-    else k = pair ? dp_wave_kernel<M, NLEV, 0, true, 0, NW, BL> : dp_wave_kernel<M, NLEV, 0, false, 0, NW, BL>;
+    const int out = !SPEC ? 0 : (!a.eq_out && !a.dec_out) ? 1 : !a.q_out ? 2 : 0;
+    void (*k)(const vaeq_dp_args) = pair ? dp_wave_kernel<M, NLEV, 0, true, 0, NW, BL> : dp_wave_kernel<M, NLEV, 0, false, 0, NW, BL>;
+    if constexpr (SPEC) {
+        if (out == 1) k = pair ? dp_wave_kernel<M, NLEV, 0, true, 1, NW, BL> : dp_wave_kernel<M, NLEV, 0, false, 1, NW, BL>;
+        else if (out == 2) k = pair ? dp_wave_kernel<M, NLEV, 0, true, 2, NW, BL> : dp_wave_kernel<M, NLEV, 0, false, 2, NW, BL>;
+    }
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VAEQ_ERR_LDS;
@@ -1031,17 +1035,39 @@ static int64_t wave_resident_lev(int B, int n_lev)
     return VAEQ_ERR_SHAPE;
 }
 
-// every supported M for a given NW (the per-NW translation units instantiate these)
+// every supported M for a given NW (the per-NW translation units instantiate these): M = 25 on the run-time layout (its fixed-layout and baked forms
+// are dispatched before; this is their A/B counterpart), every other tap count on the fixed layout of the NW class's largest minibatch
+template <int M, int NW>
+static int launch_wave_fixl_lev(const vaeq_dp_args &a, hipStream_t st)
+{
+    switch (a.n_lev) {
+    case 2: return launch_wave_fixl<M, 2, 128 * NW, NW, false>(a, st);
+    case 4: return launch_wave_fixl<M, 4, 128 * NW, NW, false>(a, st);
+    case 8: return launch_wave_fixl<M, 8, 128 * NW, NW, false>(a, st);
+    }
+    return VAEQ_ERR_SHAPE;
+}
+template <int M, int NW>
+static int64_t wave_resident_fixl_lev(int n_lev)
+{
+    switch (n_lev) {
+    case 2: return wave_resident_fixl<M, 2, 128 * NW, NW>();
+    case 4: return wave_resident_fixl<M, 4, 128 * NW, NW>();
+    case 8: return wave_resident_fixl<M, 8, 128 * NW, NW>();
+    }
+    return VAEQ_ERR_SHAPE;
+}
+
 template <int NW>
 static int launch_wave_any(const vaeq_dp_args &a, hipStream_t st)
 {
     switch (a.M) {
     case 25: return launch_wave_lev<25, 0, NW>(a, st);
-    case 31: return launch_wave_lev<31, 0, NW>(a, st);
-    case 21: return launch_wave_lev<21, 0, NW>(a, st);
-    case 17: return launch_wave_lev<17, 0, NW>(a, st);
-    case 13: return launch_wave_lev<13, 0, NW>(a, st);
-    case 9: return launch_wave_lev<9, 0, NW>(a, st);
+    case 31: return launch_wave_fixl_lev<31, NW>(a, st);
+    case 21: return launch_wave_fixl_lev<21, NW>(a, st);
+    case 17: return launch_wave_fixl_lev<17, NW>(a, st);
+    case 13: return launch_wave_fixl_lev<13, NW>(a, st);
+    case 9: return launch_wave_fixl_lev<9, NW>(a, st);
     }
     return VAEQ_ERR_SHAPE;
 }
@@ -1051,11 +1077,11 @@ static int64_t wave_resident_any(int B, int M, int n_lev)
 {
     switch (M) {
     case 25: return wave_resident_lev<25, 0, NW>(B, n_lev);
-    case 31: return wave_resident_lev<31, 0, NW>(B, n_lev);
-    case 21: return wave_resident_lev<21, 0, NW>(B, n_lev);
-    case 17: return wave_resident_lev<17, 0, NW>(B, n_lev);
-    case 13: return wave_resident_lev<13, 0, NW>(B, n_lev);
-    case 9: return wave_resident_lev<9, 0, NW>(B, n_lev);
+    case 31: return wave_resident_fixl_lev<31, NW>(n_lev);
+    case 21: return wave_resident_fixl_lev<21, NW>(n_lev);
+    case 17: return wave_resident_fixl_lev<17, NW>(n_lev);
+    case 13: return wave_resident_fixl_lev<13, NW>(n_lev);
+    case 9: return wave_resident_fixl_lev<9, NW>(n_lev);
     }
     return VAEQ_ERR_SHAPE;
 }
