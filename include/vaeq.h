@@ -303,7 +303,8 @@ int vaeq_nn_validate(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev
 
 /* Single-polarisation AWGN / ISI channel of AWGN_channel/func_VAELE_MQAM_shaping.py:39-61 (generate_data) for R runs, same three
  * stages without the dispersion step: g[Lg] = rrc * h_channel; scratch: power_ws [R][ceil(Ls / 2048)] floats, and sig_ws [R][Ls]
- * complex64 only for sps != 2 (for sps == 2 the clean signal stays in registers: one pass for the power, one that adds the noise);
+ * complex64 only for sps != 2 (for sps == 2 the clean signal stays in registers: frames of up to four 2048-sample tiles in ONE pass, one workgroup per
+ * run; longer ones in two -- one pass for the power, one that adds the noise -- with bit-identical results; env VAEQ_AWGN_TWOPASS=1 forces two);
  * rx[R][2][sps*N] (:57), data_f16 (nullable) [R][2][N] = symbols ref_offset .. ref_offset+N-1 (:59), sigma_out[R] nullable.
  * sigma_fixed (nullable [R]): use this noise standard deviation instead of the power-derived one -- the VAE-NN script's model
  * (func_VAENN_MQAM.py:52: sigma_n = sqrt(1/2) / 10^(SNR/20)); snr_db may then be NULL. */
