@@ -14,87 +14,140 @@
 
 #include "vaeq.h"
 #include "vaeq_common.h"
+#include "vaeq_wave.h"
 
 namespace vaeq {
 
-__global__ __launch_bounds__(64) void cma_kernel(int N, int sps, int M, int mode, int batchlen, int symb_step, const float *__restrict__ rx,
+// HALF (M <= 32): lanes 0..31 hold the taps of output polarisation 0, lanes 32..63 those of output 1 -- a lane keeps 4 instead of 8 coefficients, a
+// symbol costs two half-wave sums instead of four wave sums and half the FMAs of the filter and of the update.  !HALF: lane = tap of both outputs (M <= 64).
+template <bool HALF>
+__global__ __launch_bounds__(64, 8) void cma_kernel(int N, int sps, int M, int mode, int batchlen, int symb_step, const float *__restrict__ rx,
                                                  float Rc, float *__restrict__ h, const float *__restrict__ lr, float *__restrict__ out,
                                                  float *__restrict__ eout)
 {
     extern __shared__ float ring[];                            // mode 1: [batchlen][8] = out[2][2], e[2], window start, unused
+    constexpr int NO = HALF ? 1 : 2;                           // output polarisations a lane works for
     const int run = blockIdx.x, lane = threadIdx.x;
+    const int tl = HALF ? (lane & 31) : lane, ob = HALF ? (lane >> 5) : 0;     // tap of this lane; its (first) output polarisation
     const int mh = M / 2, Lp = N + 2 * mh, K = N / sps;
     const float *x = rx + (size_t)run * 4 * N;                 // [pol][re/im][N]
     float pw = 0.f;
     for (int i = lane; i < 4 * N; i += 64) pw = fmaf(x[i], x[i], pw);
     const float inv = 1.0f / (wave_sum(pw) / (float)(2 * Lp));
-    const bool tap = lane < M;
-    float hr[2][2], hi[2][2];                                  // [out pol][in pol] at tap = lane
+    const bool tap = tl < M;
+    float hr[NO][2], hi[NO][2];                                // [out pol (- ob)][in pol] at tap = tl
     float *hrun = h + (size_t)run * 8 * M;
 #pragma unroll
-    for (int o = 0; o < 2; o++)
+    for (int o = 0; o < NO; o++)
 #pragma unroll
         for (int p = 0; p < 2; p++) {
-            hr[o][p] = tap ? hrun[((o * 2 + p) * 2 + 0) * M + lane] : 0.f;
-            hi[o][p] = tap ? hrun[((o * 2 + p) * 2 + 1) * M + lane] : 0.f;
+            hr[o][p] = tap ? hrun[(((ob + o) * 2 + p) * 2 + 0) * M + tl] : 0.f;
+            hi[o][p] = tap ? hrun[(((ob + o) * 2 + p) * 2 + 1) * M + tl] : 0.f;
         }
     const float two_lr = 2.0f * lr[run];
     float *orun = out + (size_t)run * 4 * K, *erun = eout ? eout + (size_t)run * 2 * K : nullptr;
-    auto window = [&](int i0, float (&yr)[2], float (&yi)[2]) { // padded sample i0 + lane of both polarisations, scaled
-        const int sx = i0 + lane - mh;
+    auto window_raw = [&](int i0, float (&yr)[2], float (&yi)[2]) {   // padded sample i0 + tap of both polarisations, unscaled
+        const int sx = i0 + tl - mh;
         const bool ok = tap && sx >= 0 && sx < N;
+        const int sc = ok ? sx : 0;                            // (one unconditional load per row: no divergent branch on the chain)
 #pragma unroll
         for (int p = 0; p < 2; p++) {
-            yr[p] = ok ? x[(p * 2 + 0) * N + sx] * inv : 0.f;
-            yi[p] = ok ? x[(p * 2 + 1) * N + sx] * inv : 0.f;
+            const float a_ = x[(p * 2 + 0) * N + sc], b_ = x[(p * 2 + 1) * N + sc];
+            yr[p] = ok ? a_ : 0.f;
+            yi[p] = ok ? b_ : 0.f;
         }
     };
-    for (int j = 0; mh + sps * j < N + mh; j++) {
-        const int i0 = sps * j, kraw = (mh + sps * j) / sps - mh, k = kraw < 0 ? kraw + K : kraw;
-        float yr[2], yi[2];
-        window(i0, yr, yi);
-        float o_[2][2], e_[2];
+    // The symbol loop is one dependency chain per run; what must not sit on it is memory latency.  (i) The window of symbol j + 1 is fetched while
+    // symbol j is computed (and scaled only when it becomes the current one).  (ii) Outputs are parked one symbol per lane and leave 64 symbols at a
+    // time as coalesced rows: gfx9 counts stores in vmcnt, so a per-symbol store by lane 0 made every next window wait for the previous symbol's
+    // writes to land (2.3 us per symbol).  (iii) The sums run on the vector ALU (DPP): a shuffle butterfly is six dependent LDS round trips each.
+    const int J = (N + sps - 1) / sps;                         // symbols: mh + sps j < N + mh
+    const int joff = mh - mh / sps;                            // kraw = j - joff: (mh + sps j) / sps - mh
+    float keep[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float yr[2], yi[2];
+    window_raw(0, yr, yi);
 #pragma unroll
-        for (int o = 0; o < 2; o++) {
+    for (int p = 0; p < 2; p++) { yr[p] *= inv; yi[p] *= inv; }
+    for (int j = 0; j < J; j++) {
+        const int i0 = sps * j, kraw = j - joff;
+        float yrn[2], yin[2];
+        window_raw(i0 + sps, yrn, yin);                        // (past the end: zeros)
+        float o_[2][2], e_[2];
+        if constexpr (HALF) {
             float re = 0.f, im = 0.f;
 #pragma unroll
             for (int p = 0; p < 2; p++) {
-                re = fmaf(yr[p], hr[o][p], re); re = fmaf(-yi[p], hi[o][p], re);
-                im = fmaf(yr[p], hi[o][p], im); im = fmaf(yi[p], hr[o][p], im);
+                re = fmaf(yr[p], hr[0][p], re); re = fmaf(-yi[p], hi[0][p], re);
+                im = fmaf(yr[p], hi[0][p], im); im = fmaf(yi[p], hr[0][p], im);
             }
-            o_[o][0] = wave_sum(re);
-            o_[o][1] = wave_sum(im);
-            e_[o] = Rc - o_[o][0] * o_[o][0] - o_[o][1] * o_[o][1];
+            re += dpp_f<0xB1>(re); im += dpp_f<0xB1>(im);      // sums inside each 16-lane row ...
+            re += dpp_f<0x4E>(re); im += dpp_f<0x4E>(im);
+            re += dpp_f<0x141>(re); im += dpp_f<0x141>(im);
+            re += dpp_f<0x140>(re); im += dpp_f<0x140>(im);
+            const int br = __builtin_bit_cast(int, re), bi = __builtin_bit_cast(int, im);
+            auto rl = [](int v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, l)); };
+            o_[0][0] = rl(br, 0) + rl(br, 16); o_[0][1] = rl(bi, 0) + rl(bi, 16);     // ... rows 0 + 1 = output 0, rows 2 + 3 = output 1
+            o_[1][0] = rl(br, 32) + rl(br, 48); o_[1][1] = rl(bi, 32) + rl(bi, 48);
+        } else {
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                float re = 0.f, im = 0.f;
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    re = fmaf(yr[p], hr[o][p], re); re = fmaf(-yi[p], hi[o][p], re);
+                    im = fmaf(yr[p], hi[o][p], im); im = fmaf(yi[p], hr[o][p], im);
+                }
+                o_[o][0] = wave_sum_dpp(re);
+                o_[o][1] = wave_sum_dpp(im);
+            }
         }
-        if (lane == 0) {
-            orun[0 * K + k] = o_[0][0]; orun[1 * K + k] = o_[0][1]; orun[2 * K + k] = o_[1][0]; orun[3 * K + k] = o_[1][1];
-            if (erun) { erun[k * 2 + 0] = e_[0]; erun[k * 2 + 1] = e_[1]; }
+#pragma unroll
+        for (int o = 0; o < 2; o++) e_[o] = Rc - o_[o][0] * o_[o][0] - o_[o][1] * o_[o][1];
+        if (lane == (j & 63)) {
+            keep[0] = o_[0][0]; keep[1] = o_[0][1]; keep[2] = o_[1][0]; keep[3] = o_[1][1]; keep[4] = e_[0]; keep[5] = e_[1];
+        }
+        if ((j & 63) == 63 || j == J - 1) {                    // uniform: flush the parked symbols (j & ~63) .. j
+            const int jl = (j & ~63) + lane;
+            if (jl <= j) {
+                const int kr = jl - joff, kl = kr < 0 ? kr + K : kr;
+                orun[0 * K + kl] = keep[0]; orun[1 * K + kl] = keep[1]; orun[2 * K + kl] = keep[2]; orun[3 * K + kl] = keep[3];
+                if (erun) { erun[kl * 2 + 0] = keep[4]; erun[kl * 2 + 1] = keep[5]; }
+            }
         }
         if (mode == 0) {                                       // :371-381
 #pragma unroll
-            for (int o = 0; o < 2; o++)
+            for (int o = 0; o < NO; o++) {
+                const float oR = HALF ? (ob ? o_[1][0] : o_[0][0]) : o_[o][0], oI = HALF ? (ob ? o_[1][1] : o_[0][1]) : o_[o][1];
+                const float ge = two_lr * (HALF ? (ob ? e_[1] : e_[0]) : e_[o]);
 #pragma unroll
                 for (int p = 0; p < 2; p++) {
-                    hr[o][p] += two_lr * e_[o] * (o_[o][0] * yr[p] + o_[o][1] * yi[p]);
-                    hi[o][p] += two_lr * e_[o] * (o_[o][1] * yr[p] - o_[o][0] * yi[p]);
+                    hr[o][p] += ge * (oR * yr[p] + oI * yi[p]);
+                    hi[o][p] += ge * (oI * yr[p] - oR * yi[p]);
                 }
+            }
         } else if (kraw >= 0) {
             if (kraw >= batchlen && kraw % symb_step == 0) {   // :421 / :475: the last `batchlen` symbols, kraw itself excluded
-                float ar[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, ai[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+                float ar[NO][2], ai[NO][2];
+#pragma unroll
+                for (int o = 0; o < NO; o++) ar[o][0] = ar[o][1] = ai[o][0] = ai[o][1] = 0.f;
+                // the window of symbol kk starts at sample sps (kk + joff): no look-up in the ring, so the loads of several symbols are in flight at once
+#pragma unroll 2
                 for (int kk = kraw - batchlen; kk < kraw; kk++) {
                     const float *s = ring + (size_t)(kk % batchlen) * 8;
                     float wr[2], wi[2];
-                    window(__float_as_int(s[6]), wr, wi);
+                    window_raw(sps * (kk + joff), wr, wi);
 #pragma unroll
-                    for (int o = 0; o < 2; o++)
+                    for (int o = 0; o < NO; o++) {
+                        const float sR = HALF ? s[ob * 2] : s[o * 2], sI = HALF ? s[ob * 2 + 1] : s[o * 2 + 1], sE = HALF ? s[4 + ob] : s[4 + o];
 #pragma unroll
                         for (int p = 0; p < 2; p++) {
-                            ar[o][p] = fmaf(s[o * 2] * wr[p] + s[o * 2 + 1] * wi[p], s[4 + o], ar[o][p]);
-                            ai[o][p] = fmaf(s[o * 2 + 1] * wr[p] - s[o * 2] * wi[p], s[4 + o], ai[o][p]);
+                            ar[o][p] = fmaf(sR * (wr[p] * inv) + sI * (wi[p] * inv), sE, ar[o][p]);
+                            ai[o][p] = fmaf(sI * (wr[p] * inv) - sR * (wi[p] * inv), sE, ai[o][p]);
                         }
+                    }
                 }
 #pragma unroll
-                for (int o = 0; o < 2; o++)
+                for (int o = 0; o < NO; o++)
 #pragma unroll
                     for (int p = 0; p < 2; p++) {
                         hr[o][p] = fmaf(two_lr, ar[o][p], hr[o][p]);
@@ -103,18 +156,19 @@ __global__ __launch_bounds__(64) void cma_kernel(int N, int sps, int M, int mode
             }
             __syncthreads();                                   // one wave per workgroup: every read of the ring is done ...
             float *slot = ring + (size_t)(kraw % batchlen) * 8; // ... before symbol kraw replaces symbol kraw - batchlen in it
-            if (lane < 4) slot[lane] = o_[lane >> 1][lane & 1];
-            if (lane == 4) { slot[4] = e_[0]; slot[5] = e_[1]; slot[6] = __int_as_float(i0); }
+            if (lane < 4) slot[lane] = lane == 0 ? o_[0][0] : lane == 1 ? o_[0][1] : lane == 2 ? o_[1][0] : o_[1][1];   // (selects: a run-time register index would go through scratch)
+            if (lane == 4) { slot[4] = e_[0]; slot[5] = e_[1]; }
             __syncthreads();
         }
+        yr[0] = yrn[0] * inv; yr[1] = yrn[1] * inv; yi[0] = yin[0] * inv; yi[1] = yin[1] * inv;
     }
     if (tap) {
 #pragma unroll
-        for (int o = 0; o < 2; o++)
+        for (int o = 0; o < NO; o++)
 #pragma unroll
             for (int p = 0; p < 2; p++) {
-                hrun[((o * 2 + p) * 2 + 0) * M + lane] = hr[o][p];
-                hrun[((o * 2 + p) * 2 + 1) * M + lane] = hi[o][p];
+                hrun[(((ob + o) * 2 + p) * 2 + 0) * M + tl] = hr[o][p];
+                hrun[(((ob + o) * 2 + p) * 2 + 1) * M + tl] = hi[o][p];
             }
     }
 }
@@ -195,7 +249,7 @@ extern "C" int vaeq_cma(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t mo
     if (R < 0 || N <= 0 || N > 0x3fffffff || sps <= 0 || M <= 0 || (M & 1) == 0 || M > 63 || N / sps < 2 * M) return VAEQ_ERR_SHAPE;
     if (!(mode == 0 || mode == 1) || (mode == 1 && (batchlen <= 0 || symb_step <= 0 || batchlen > 4096))) return VAEQ_ERR_SHAPE;
     const size_t lds = mode == 1 ? (size_t)batchlen * 8 * sizeof(float) : 0;
-    hipLaunchKernelGGL(vaeq::cma_kernel, dim3(R), dim3(64), lds, reinterpret_cast<hipStream_t>(stream), (int)N, sps, M, mode, batchlen, symb_step, rx,
+    hipLaunchKernelGGL(M <= 32 ? vaeq::cma_kernel<true> : vaeq::cma_kernel<false>, dim3(R), dim3(64), lds, reinterpret_cast<hipStream_t>(stream), (int)N, sps, M, mode, batchlen, symb_step, rx,
                        R_mod, h, lr, out, e);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
