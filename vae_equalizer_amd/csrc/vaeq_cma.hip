@@ -16,16 +16,28 @@
 #include "vaeq_common.h"
 #include "vaeq_wave.h"
 
+#ifndef CMA_WAVES
+#define CMA_WAVES 6
+#endif
+#ifndef CMA_UNROLL
+#define CMA_UNROLL 2
+#endif
+
 namespace vaeq {
 
 // HALF (M <= 32): lanes 0..31 hold the taps of output polarisation 0, lanes 32..63 those of output 1 -- a lane keeps 4 instead of 8 coefficients, a
 // symbol costs two half-wave sums instead of four wave sums and half the FMAs of the filter and of the update.  !HALF: lane = tap of both outputs (M <= 64).
-template <bool HALF>
-__global__ __launch_bounds__(64, 8) void cma_kernel(int N, int sps, int M, int mode, int batchlen, int symb_step, const float *__restrict__ rx,
-                                                 float Rc, float *__restrict__ h, const float *__restrict__ lr, float *__restrict__ out,
-                                                 float *__restrict__ eout)
+// STAGE (batch modes, when it fits): the scaled samples of the last sps (batchlen + 1) + M padded positions live in an LDS ring of xmask + 1 float4
+// (both polarisations, re / im): the filter window and every term of the batch update are ONE 16-byte LDS read instead of four global loads with
+// bounds checks and 64-bit address arithmetic (42 -> 13 instructions per update term).
+template <bool HALF, bool STAGE>
+__global__ __launch_bounds__(64, CMA_WAVES) void cma_kernel(int N, int sps, int M, int mode, int batchlen, int symb_step, int xmask,
+                                                 const float *__restrict__ rx, float Rc, float *__restrict__ h, const float *__restrict__ lr,
+                                                 float *__restrict__ out, float *__restrict__ eout)
 {
-    extern __shared__ float ring[];                            // mode 1: [batchlen][8] = out[2][2], e[2], window start, unused
+    extern __shared__ float4 ring4[];                          // mode 1: [batchlen][8] floats = out[2][2], e[2], -, - ; STAGE: then xs[xmask + 1] float4
+    float *ring = reinterpret_cast<float *>(ring4);
+    float4 *xs = ring4 + 2 * (size_t)batchlen;
     constexpr int NO = HALF ? 1 : 2;                           // output polarisations a lane works for
     const int run = blockIdx.x, lane = threadIdx.x;
     const int tl = HALF ? (lane & 31) : lane, ob = HALF ? (lane >> 5) : 0;     // tap of this lane; its (first) output polarisation
@@ -65,13 +77,35 @@ __global__ __launch_bounds__(64, 8) void cma_kernel(int N, int sps, int M, int m
     const int joff = mh - mh / sps;                            // kraw = j - joff: (mh + sps j) / sps - mh
     float keep[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float yr[2], yi[2];
-    window_raw(0, yr, yi);
+    // STAGE: padded position u = sample index + mh; xs[u & xmask] = scaled sample (zero outside the frame); positions < `filled` are in the ring
+    auto sample4 = [&](int u) {                                // scaled sample at padded position u (global memory)
+        const int n = u - mh;
+        const bool ok = n >= 0 && n < N;
+        const int nc = ok ? n : 0;
+        const float a0 = x[nc], a1 = x[N + nc], a2 = x[2 * N + nc], a3 = x[3 * N + nc];
+        return ok ? make_float4(a0 * inv, a1 * inv, a2 * inv, a3 * inv) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    if constexpr (STAGE) {
+        for (int u = lane; u < M + sps; u += 64) xs[u & xmask] = sample4(u);       // windows of symbols 0 and 1
+        __syncthreads();
+        const float4 v = xs[tl & xmask];
+        yr[0] = tap ? v.x : 0.f; yi[0] = tap ? v.y : 0.f; yr[1] = tap ? v.z : 0.f; yi[1] = tap ? v.w : 0.f;
+    } else {
+        window_raw(0, yr, yi);
 #pragma unroll
-    for (int p = 0; p < 2; p++) { yr[p] *= inv; yi[p] *= inv; }
+        for (int p = 0; p < 2; p++) { yr[p] *= inv; yi[p] *= inv; }
+    }
     for (int j = 0; j < J; j++) {
         const int i0 = sps * j, kraw = j - joff;
         float yrn[2], yin[2];
-        window_raw(i0 + sps, yrn, yin);                        // (past the end: zeros)
+        float4 nx = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (STAGE) {
+            if (lane < sps) nx = sample4(M + sps * (j + 1) + lane);               // the samples symbol j + 2 adds; written to the ring after this symbol
+            const float4 v = xs[(i0 + sps + tl) & xmask];                         // the next symbol's window (already in the ring): off the chain
+            yrn[0] = tap ? v.x : 0.f; yin[0] = tap ? v.y : 0.f; yrn[1] = tap ? v.z : 0.f; yin[1] = tap ? v.w : 0.f;
+        } else {
+            window_raw(i0 + sps, yrn, yin);                    // (past the end: zeros)
+        }
         float o_[2][2], e_[2];
         if constexpr (HALF) {
             float re = 0.f, im = 0.f;
@@ -130,21 +164,54 @@ __global__ __launch_bounds__(64, 8) void cma_kernel(int N, int sps, int M, int m
                 float ar[NO][2], ai[NO][2];
 #pragma unroll
                 for (int o = 0; o < NO; o++) ar[o][0] = ar[o][1] = ai[o][0] = ai[o][1] = 0.f;
-                // the window of symbol kk starts at sample sps (kk + joff): no look-up in the ring, so the loads of several symbols are in flight at once
-#pragma unroll 2
+                // the window of symbol kk starts at sample sps (kk + joff): no look-up in the ring, so the loads of two symbols are in flight at once;
+                // ring slot and sample index advance incrementally (a run-time modulo per term cost as much as the term's arithmetic)
+                int slot_i = kraw % batchlen;                  // (kraw - batchlen) mod batchlen
+                if constexpr (STAGE) {
+                    int u = sps * (kraw - batchlen + joff) + tl;
+#pragma unroll 4
+                    for (int kk = kraw - batchlen; kk < kraw; kk++) {
+                        const float *s = ring + (size_t)slot_i * 8;
+                        const float4 w = xs[u & xmask];
+                        const float wr[2] = {w.x, w.z}, wi[2] = {w.y, w.w};
+#pragma unroll
+                        for (int o = 0; o < NO; o++) {
+                            const float sR = HALF ? s[ob * 2] : s[o * 2], sI = HALF ? s[ob * 2 + 1] : s[o * 2 + 1], sE = HALF ? s[4 + ob] : s[4 + o];
+#pragma unroll
+                            for (int p = 0; p < 2; p++) {
+                                ar[o][p] = fmaf(sR * wr[p] + sI * wi[p], sE, ar[o][p]);
+                                ai[o][p] = fmaf(sI * wr[p] - sR * wi[p], sE, ai[o][p]);
+                            }
+                        }
+                        slot_i = slot_i + 1 == batchlen ? 0 : slot_i + 1;
+                        u += sps;
+                    }
+                    if (!tap) {                                // lanes without a tap read neighbours' samples: their sums are dropped
+#pragma unroll
+                        for (int o = 0; o < NO; o++) ar[o][0] = ar[o][1] = ai[o][0] = ai[o][1] = 0.f;
+                    }
+                } else {
+                int sx = sps * (kraw - batchlen + joff) + tl - mh;
+                const float *x0 = x + sx, *x1 = x0 + N, *x2 = x1 + N, *x3 = x2 + N;
+#pragma unroll CMA_UNROLL
                 for (int kk = kraw - batchlen; kk < kraw; kk++) {
-                    const float *s = ring + (size_t)(kk % batchlen) * 8;
-                    float wr[2], wi[2];
-                    window_raw(sps * (kk + joff), wr, wi);
+                    const float *s = ring + (size_t)slot_i * 8;
+                    const bool ok = tap && sx >= 0 && sx < N;
+                    const int d = ok ? 0 : -sx;                 // (masked lanes read sample 0: one unconditional load per row)
+                    const float w0 = x0[d], w1 = x1[d], w2 = x2[d], w3 = x3[d];
+                    const float wr[2] = {ok ? w0 * inv : 0.f, ok ? w2 * inv : 0.f}, wi[2] = {ok ? w1 * inv : 0.f, ok ? w3 * inv : 0.f};
 #pragma unroll
                     for (int o = 0; o < NO; o++) {
                         const float sR = HALF ? s[ob * 2] : s[o * 2], sI = HALF ? s[ob * 2 + 1] : s[o * 2 + 1], sE = HALF ? s[4 + ob] : s[4 + o];
 #pragma unroll
                         for (int p = 0; p < 2; p++) {
-                            ar[o][p] = fmaf(sR * (wr[p] * inv) + sI * (wi[p] * inv), sE, ar[o][p]);
-                            ai[o][p] = fmaf(sI * (wr[p] * inv) - sR * (wi[p] * inv), sE, ai[o][p]);
+                            ar[o][p] = fmaf(sR * wr[p] + sI * wi[p], sE, ar[o][p]);
+                            ai[o][p] = fmaf(sI * wr[p] - sR * wi[p], sE, ai[o][p]);
                         }
                     }
+                    slot_i = slot_i + 1 == batchlen ? 0 : slot_i + 1;
+                    sx += sps; x0 += sps; x1 += sps; x2 += sps; x3 += sps;
+                }
                 }
 #pragma unroll
                 for (int o = 0; o < NO; o++)
@@ -158,9 +225,15 @@ __global__ __launch_bounds__(64, 8) void cma_kernel(int N, int sps, int M, int m
             float *slot = ring + (size_t)(kraw % batchlen) * 8; // ... before symbol kraw replaces symbol kraw - batchlen in it
             if (lane < 4) slot[lane] = lane == 0 ? o_[0][0] : lane == 1 ? o_[0][1] : lane == 2 ? o_[1][0] : o_[1][1];   // (selects: a run-time register index would go through scratch)
             if (lane == 4) { slot[4] = e_[0]; slot[5] = e_[1]; }
-            __syncthreads();
+            if constexpr (!STAGE) __syncthreads();
         }
-        yr[0] = yrn[0] * inv; yr[1] = yrn[1] * inv; yi[0] = yin[0] * inv; yi[1] = yin[1] * inv;
+        if constexpr (STAGE) {
+            if (lane < sps) xs[(M + sps * (j + 1) + lane) & xmask] = nx;
+            __syncthreads();
+            yr[0] = yrn[0]; yr[1] = yrn[1]; yi[0] = yin[0]; yi[1] = yin[1];
+        } else {
+            yr[0] = yrn[0] * inv; yr[1] = yrn[1] * inv; yi[0] = yin[0] * inv; yi[1] = yin[1] * inv;
+        }
     }
     if (tap) {
 #pragma unroll
@@ -248,9 +321,19 @@ extern "C" int vaeq_cma(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t mo
     if (!rx || !h || !lr || !out) return VAEQ_ERR_NULL;
     if (R < 0 || N <= 0 || N > 0x3fffffff || sps <= 0 || M <= 0 || (M & 1) == 0 || M > 63 || N / sps < 2 * M) return VAEQ_ERR_SHAPE;
     if (!(mode == 0 || mode == 1) || (mode == 1 && (batchlen <= 0 || symb_step <= 0 || batchlen > 4096))) return VAEQ_ERR_SHAPE;
-    const size_t lds = mode == 1 ? (size_t)batchlen * 8 * sizeof(float) : 0;
-    hipLaunchKernelGGL(M <= 32 ? vaeq::cma_kernel<true> : vaeq::cma_kernel<false>, dim3(R), dim3(64), lds, reinterpret_cast<hipStream_t>(stream), (int)N, sps, M, mode, batchlen, symb_step, rx,
-                       R_mod, h, lr, out, e);
+    size_t lds = mode == 1 ? (size_t)batchlen * 8 * sizeof(float) : 0;
+    int xcap = 64;                                             // sample ring: a power of two >= sps (batchlen + 2) + M positions
+    while (xcap < sps * (batchlen + 2) + M) xcap <<= 1;
+    // staged samples pay when the 100-term update runs often (CMAflex: every symb_step = 10 symbols); with one update per batchlen symbols (CMAbatch)
+    // the per-symbol barrier of the staged form costs more than the update gains (17.7 vs 20.3 ms per 8192-run frame)
+    const bool stage = mode == 1 && lds + (size_t)xcap * 16 <= 24 * 1024 && 4 * symb_step <= batchlen;
+    if (stage) lds += (size_t)xcap * 16;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    void (*k)(int, int, int, int, int, int, int, const float *, float, float *, const float *, float *, float *) =
+        M <= 32 ? (stage ? vaeq::cma_kernel<true, true> : vaeq::cma_kernel<true, false>) : (stage ? vaeq::cma_kernel<false, true> : vaeq::cma_kernel<false, false>);
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return VAEQ_ERR_LDS;
+    hipLaunchKernelGGL(k, dim3(R), dim3(64), lds, st, (int)N, sps, M, mode, batchlen, symb_step, xcap - 1, rx, R_mod, h, lr, out, e);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
 
