@@ -246,12 +246,13 @@ __global__ __launch_bounds__(64, CMA_WAVES) void cma_kernel(int N, int sps, int 
     }
 }
 
-constexpr int CPE_NT = 256;
+constexpr int CPE_NT = 512;
 
 __global__ __launch_bounds__(CPE_NT) void cpe_kernel(int N, int M_ma, const float *__restrict__ y, float *__restrict__ yout)
 {
     extern __shared__ float cpe_lds[];                         // [3][N]: 4th power (re, im) and the phase estimate of one polarisation
     __shared__ int cnt[CPE_NT + 1];
+    __shared__ float csr[CPE_NT], csi[CPE_NT];                // sums of the threads' chunks of the 4th power
     float *p4r = cpe_lds, *p4i = cpe_lds + N, *phi = cpe_lds + 2 * N;
     const int run = blockIdx.x, tid = threadIdx.x;
     // a thread owns one chunk of consecutive symbols; an ODD chunk length keeps the lanes' LDS accesses on different banks
@@ -264,9 +265,23 @@ __global__ __launch_bounds__(CPE_NT) void cpe_kernel(int N, int M_ma, const floa
             p4i[n] = 4.0f * (a2 * av * bv - av * b2 * bv);
         }
         __syncthreads();
-        if (n0 < n1) {                                         // moving average over [n - half, n + half] (zero outside): direct sum, then slide
+        {                                                      // chunk sums: a window's first sum is whole chunks + two ragged ends (50 instead of 501 reads)
+            float cr = 0.f, ci = 0.f;
+            for (int n = n0; n < n1; n++) { cr += p4r[n]; ci += p4i[n]; }
+            csr[tid] = cr; csi[tid] = ci;
+        }
+        __syncthreads();
+        if (n0 < n1) {                                         // moving average over [n - half, n + half] (zero outside): first sum, then slide
             float sr = 0.f, si = 0.f;
-            for (int m = max(0, n0 - half); m <= min(N - 1, n0 + half); m++) { sr += p4r[m]; si += p4i[m]; }
+            const int lo0 = max(0, n0 - half), hi0 = min(N - 1, n0 + half);
+            const int c0 = (lo0 + chunk - 1) / chunk, c1 = (hi0 + 1) / chunk;      // whole chunks c0 .. c1 - 1 lie inside [lo0, hi0]
+            if (c0 < c1) {
+                for (int m = lo0; m < c0 * chunk; m++) { sr += p4r[m]; si += p4i[m]; }
+                for (int c = c0; c < c1; c++) { sr += csr[c]; si += csi[c]; }
+                for (int m = c1 * chunk; m <= hi0; m++) { sr += p4r[m]; si += p4i[m]; }
+            } else {
+                for (int m = lo0; m <= hi0; m++) { sr += p4r[m]; si += p4i[m]; }
+            }
             for (int n = n0; n < n1; n++) {
                 phi[n] = atan2f(si / (float)M_ma, -sr / (float)M_ma) * 0.25f;
                 const int lo = n - half, hi_ = n + half + 1;
