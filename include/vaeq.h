@@ -219,6 +219,16 @@ int vaeq_dp_epilogue_compact(int32_t R, int64_t N, int32_t n_lev, int32_t batch_
                              const void *tx_f16, const float *amp, const float *var, const float *nu_sc, float *ser, int32_t *shift,
                              int32_t *r_flag, void *stream);
 
+/* The two-stage epilogue of the constant-modulus baselines in one launch (optical_DP_channel/func_CMA_DP_MQAM_shaping.py:39-52 after the phase
+ * estimation; the CMAbatch / CMAflex modules are identical there): the constellation stage FIRST (find_shift_symb_full on y, roll / cut,
+ * SER_constell_shaping), whose mean-radius normalisation stays in the kept window of the aligned output (the reference normalises a slice view in place,
+ * shared_funcs.py:242), then soft_dec (:48) on that and the soft-demapper stage (find_shift_symb_full on E_q[x_I], SER_IQflip on argmax q) -- q is never
+ * materialised.  y[R][2][2][N]: phase-corrected output cut to [10:-10]; tx_f16[R][2][2][N]: TX reference cut likewise; ser[R][4] = constellation SER of
+ * both polarisations, then soft-demapper SER; shift[R][2][2], rflag[R][2]: index 0 = soft-demapper stage (relative to the aligned sequence), 1 =
+ * constellation stage; workspace: vaeq_dp_epilogue_ws_bytes(R, N). */
+int vaeq_cma_epilogue(int32_t R, int64_t N, int32_t n_lev, const float *y, const void *tx_f16, const float *amp, const float *var,
+                      const float *nu_sc, float *ser, int32_t *shift, int32_t *rflag, void *workspace, void *stream);
+
 /* ------------------------------------------------------------------------
  * Seeded on-device DP channel simulator (input producer): optical_DP_channel/shared_funcs.py:65-90 in three stages with
  * the FFT / inverse FFT over Ls done by the caller (hipFFT through torch.fft) between them.  Counter-based RNG (Philox4x32-10):

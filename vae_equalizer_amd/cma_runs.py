@@ -21,7 +21,16 @@ N_CUT = 10   # symbols cut at both frame ends before the phase estimation (func_
 
 
 def cma_frame_epilogue(out_const, data, amp, nu_sc, var):
-    """out_const[R,2,2,K] (CMA output of one frame), data[R,2,2,K] fp16 -> dict(SER[R,4], shift_c, r_c, shift_q, r_q, y)."""
+    """out_const[R,2,2,K] (CMA output of one frame), data[R,2,2,K] fp16 -> dict(SER[R,4], shift_c, r_c, shift_q, r_q): phase estimation
+    (vaeq_cpe) + the two-stage epilogue in one HIP launch (vaeq_cma_epilogue; q is never materialised)."""
+    from .engine import cma_epilogue
+    y = cpe(out_const[..., N_CUT:-N_CUT].contiguous())                          # :39
+    return cma_epilogue(y, data[..., N_CUT:-N_CUT], amp, nu_sc, var)            # :40-52
+
+
+def cma_frame_epilogue_torch(out_const, data, amp, nu_sc, var):
+    """The same from the batched torch restatements of the reference's functions + the HIP soft demapper (materialises q): the form the fused
+    kernel is checked against; also returns y = the aligned output with its kept window normalised (what the reference leaves in out_const)."""
     y = cpe(out_const[..., N_CUT:-N_CUT].contiguous())                          # :39
     d = data[..., N_CUT:-N_CUT]                                                 # :40
     R, N = y.shape[0], y.shape[-1]

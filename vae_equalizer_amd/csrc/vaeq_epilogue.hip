@@ -279,7 +279,11 @@ __device__ __forceinline__ void epi_ld_d(const int8_t *row, int m0, bool wide, c
     }
 }
 
-template <int NLEV>
+// CMA = true: the two-stage epilogue of the constant-modulus baselines (func_CMA_DP_MQAM_shaping.py:41-52 and its CMAbatch / CMAflex twins) on the
+// phase-corrected output y: the constellation path runs FIRST; its alignment and mean-radius normalisation are then written into y's kept window (the
+// reference normalises a view in place, shared_funcs.py:242), the soft demapper (:48) turns that into E_q[x_I] and hard decisions in the workspace, and
+// the soft-demapper path runs on those -- its shifts relative to the already aligned sequence, as in the reference.
+template <int NLEV, bool CMA = false>
 __global__ __launch_bounds__(EPI_NT, EPI_WAVES) void dp_epilogue_kernel(int64_t N, int batch_len, const float *__restrict__ q, const float *__restrict__ y,
                                                              const __half *__restrict__ txg, const float *__restrict__ amp_g,
                                                              const float *__restrict__ var, const float *__restrict__ nu_sc,
@@ -328,7 +332,8 @@ __global__ __launch_bounds__(EPI_NT, EPI_WAVES) void dp_epilogue_kernel(int64_t 
     }
     __syncthreads();                                            // the workgroup's own global writes are visible to it after the barrier
 
-    for (int path = 0; path < 2; path++) {                      // 0: soft-demapper path on q, 1: constellation path on y
+    for (int pi = 0; pi < 2; pi++) {                            // 0: soft-demapper path on q, 1: constellation path on y
+        const int path = CMA ? 1 - pi : pi;
         if (path == 0) epi_correlate(E, N, tx, N, sh);
         else epi_correlate(yr, 2 * N, tx, N, sh);               // y[:, 0, :]: rows 0 and 2 of y[2][2][N]   (:321)
         const int s0 = sh.shift[0], s1 = sh.shift[1], r = sh.r;
@@ -444,7 +449,42 @@ __global__ __launch_bounds__(EPI_NT, EPI_WAVES) void dp_epilogue_kernel(int64_t 
             for (int k = 0; k < 8; k++) best = fminf(best, (float)sh.cnt[k * 2 + tid] / den);
             ser[(size_t)run * 4 + (path == 0 ? 2 : 0) + tid] = best;       // rows 0-1 constellation, 2-3 soft demapper (:79,89)
         }
-        __syncthreads();
+        if (CMA && path == 1) {
+            // aligned output (rolls wrap around the frame, :42-43), kept window scaled by the mean-radius factor, soft demapper per axis (:48):
+            // E_q[x_I] and the first maximum of q per axis, exactly what pass 1 derives from a materialised q
+            float amp2[NLEV];
+#pragma unroll
+            for (int i = 0; i < NLEV; i++) amp2[i] = amp[i] * amp[i];
+            const float nusc = nu_sc[run];
+            for (int n = tid; n < (int)N; n += EPI_NT) {
+                const bool kp = n >= EDGE && n < (int)N - EDGE - ms;
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const int sp = (p - r) & 1;
+                    int m = n + (p ? s1 : s0);
+                    if (m >= (int)N) m -= (int)N;
+                    if (m < 0) m += (int)N;
+                    const float i2v = 0.5f / var[run * 2 + p];
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        float v = yr[(size_t)(sp * 2 + c) * N + m];
+                        if (kp) v *= fac;
+                        float qq[NLEV];
+                        soft_demap<NLEV>(v, amp, amp2, i2v, nusc, qq);
+                        float best = qq[0], e = amp[0] * qq[0];
+                        int bi = 0;
+#pragma unroll
+                        for (int i = 1; i < NLEV; i++) {
+                            if (c == 0) e = fmaf(amp[i], qq[i], e);
+                            if (qq[i] > best) { best = qq[i]; bi = i; }
+                        }
+                        D[(size_t)(p * 2 + c) * N + n] = (int8_t)bi;
+                        if (c == 0) E[(size_t)p * N + n] = e;
+                    }
+                }
+            }
+        }
+        __syncthreads();                                        // (CMA: the workgroup's own global writes are visible to it after the barrier)
     }
 }
 
@@ -492,6 +532,31 @@ extern "C" int vaeq_dp_epilogue_compact(int32_t R, int64_t N, int32_t n_lev, int
     case 2: hipLaunchKernelGGL(vaeq::dp_epilogue_kernel<2>, dim3(R), dim3(vaeq::EPI_NT), 0, st, N, batch_len, q, y, tx, amp, var, nu_sc, ser, shift, rflag, wsE, wsD); break;
     case 4: hipLaunchKernelGGL(vaeq::dp_epilogue_kernel<4>, dim3(R), dim3(vaeq::EPI_NT), 0, st, N, batch_len, q, y, tx, amp, var, nu_sc, ser, shift, rflag, wsE, wsD); break;
     case 8: hipLaunchKernelGGL(vaeq::dp_epilogue_kernel<8>, dim3(R), dim3(vaeq::EPI_NT), 0, st, N, batch_len, q, y, tx, amp, var, nu_sc, ser, shift, rflag, wsE, wsD); break;
+    default: return VAEQ_ERR_SHAPE;
+    }
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}
+
+// The constant-modulus baselines' two-stage epilogue in one launch (func_CMA_DP_MQAM_shaping.py:39-52 after the phase estimation; identical in the
+// CMAbatch / CMAflex modules): y[R][2][2][N] = CPE output (already cut to [10:-10]), tx_f16[R][2][2][N] the TX reference cut likewise;
+// ser[R][4] = constellation SER of both polarisations, then soft-demapper SER; shift[R][2][2] / rflag[R][2]: index 0 = soft-demapper stage, 1 =
+// constellation stage; workspace: vaeq_dp_epilogue_ws_bytes(R, N).
+extern "C" int vaeq_cma_epilogue(int32_t R, int64_t N, int32_t n_lev, const float *y, const void *tx_f16, const float *amp, const float *var,
+                                 const float *nu_sc, float *ser, int32_t *shift, int32_t *rflag, void *workspace, void *stream)
+{
+    if (R == 0) return VAEQ_OK;                                // an empty batch owns no memory: its pointers may be NULL
+    if (!y || !tx_f16 || !amp || !var || !nu_sc || !ser || !shift || !rflag || !workspace) return VAEQ_ERR_NULL;
+    if (R < 0 || N < 2 * vaeq::EDGE + vaeq::N_SHIFT || N > 0x3fffffff) return VAEQ_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float *wsE = reinterpret_cast<float *>(workspace);
+    int8_t *wsD = reinterpret_cast<int8_t *>(wsE + (size_t)R * 2 * N);
+    const __half *tx = reinterpret_cast<const __half *>(tx_f16);
+    const float *q = nullptr;
+    const int batch_len = 0;
+    switch (n_lev) {
+    case 2: hipLaunchKernelGGL((vaeq::dp_epilogue_kernel<2, true>), dim3(R), dim3(vaeq::EPI_NT), 0, st, N, batch_len, q, y, tx, amp, var, nu_sc, ser, shift, rflag, wsE, wsD); break;
+    case 4: hipLaunchKernelGGL((vaeq::dp_epilogue_kernel<4, true>), dim3(R), dim3(vaeq::EPI_NT), 0, st, N, batch_len, q, y, tx, amp, var, nu_sc, ser, shift, rflag, wsE, wsD); break;
+    case 8: hipLaunchKernelGGL((vaeq::dp_epilogue_kernel<8, true>), dim3(R), dim3(vaeq::EPI_NT), 0, st, N, batch_len, q, y, tx, amp, var, nu_sc, ser, shift, rflag, wsE, wsD); break;
     default: return VAEQ_ERR_SHAPE;
     }
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;

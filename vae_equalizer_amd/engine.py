@@ -400,6 +400,27 @@ def dp_epilogue_compact(eq, dec, y, data, amp_levels, nu_sc, var, batch_len=None
     return dict(SER=ser, shift_q=shift[:, 0].long(), r_q=rflag[:, 0].long(), shift_c=shift[:, 1].long(), r_c=rflag[:, 1].long())
 
 
+def cma_epilogue(y, data, amp_levels, nu_sc, var):
+    """The constant-modulus baselines' two-stage epilogue of one frame in one launch (vaeq_cma_epilogue): y[R,2,2,N] = phase-corrected output cut
+    to [10:-10], data[R,2,2,N] fp16 cut likewise -> dict(SER[R,4] (constellation rows, then soft-demapper rows), shift_c, r_c, shift_q, r_q)."""
+    dev, R, N = y.device, y.shape[0], y.shape[-1]
+    amp = _f32(amp_levels, dev).reshape(-1)
+    var = _f32(var, dev).expand(R, 2).contiguous()
+    nu = _f32(nu_sc, dev).expand(R).contiguous()
+    y = y.contiguous()
+    data = data.to(torch.float16).contiguous()
+    ser = torch.empty(R, 4, dtype=torch.float32, device=dev)
+    shift = torch.empty(R, 2, 2, dtype=torch.int32, device=dev)
+    rflag = torch.empty(R, 2, dtype=torch.int32, device=dev)
+    L = nat.lib()
+    ws = torch.empty(int(L.vaeq_dp_epilogue_ws_bytes(R, N)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(L.vaeq_cma_epilogue(R, N, amp.numel(), nat.ptr(y), nat.ptr(data, torch.float16), nat.ptr(amp), nat.ptr(var), nat.ptr(nu), nat.ptr(ser),
+                                      nat.ptr(shift, torch.int32), nat.ptr(rflag, torch.int32), nat.ptr(ws, torch.uint8), nat.current_stream(dev)),
+                  "vaeq_cma_epilogue")
+    return dict(SER=ser, shift_q=shift[:, 0].long(), r_q=rflag[:, 0].long(), shift_c=shift[:, 1].long(), r_c=rflag[:, 1].long())
+
+
 def awgn_loss(q, x, h, amp_levels, P=None):
     """ELBO of the single-polarisation variants for a given q (vaeq_awgn_loss): q[R,2n,B] (or [2n,B]), x[R,2,B*sps], h[R,2,M];
     P[R,n] / [n] -> the VAE-LE form (KL to the prior), P None -> the VAE-NN form (entropy).  Returns loss[R] (or a 0-dim tensor)."""
