@@ -22,6 +22,9 @@ namespace vaeq {
 #ifndef EPI_WAVES
 #define EPI_WAVES 6
 #endif
+#ifndef EPI_WAVES_CMA
+#define EPI_WAVES_CMA 6                       // (5 waves per SIMD without the CMA mode's 92 bytes of scratch: 6.8 vs 6.6 ms, no gain)
+#endif
 constexpr int EPI_NT = 256, N_SHIFT = 21, HALF_SHIFT = 10, N_CUT = 10, EDGE = 11;
 constexpr int N_CHUNK = EPI_NT / 8;           // thread = (chunk, E-polarisation b, TX polarisation a, lag half h): 32 x 2 x 2 x 2; the I and Q rows of a ride in one packed FMA
 constexpr int EPI_CH = 22;                    // symbols per chunk (even: a thread's 32-sample lag window is 16 aligned register pairs)
@@ -284,7 +287,7 @@ __device__ __forceinline__ void epi_ld_d(const int8_t *row, int m0, bool wide, c
 // reference normalises a view in place, shared_funcs.py:242), the soft demapper (:48) turns that into E_q[x_I] and hard decisions in the workspace, and
 // the soft-demapper path runs on those -- its shifts relative to the already aligned sequence, as in the reference.
 template <int NLEV, bool CMA = false>
-__global__ __launch_bounds__(EPI_NT, EPI_WAVES) void dp_epilogue_kernel(int64_t N, int batch_len, const float *__restrict__ q, const float *__restrict__ y,
+__global__ __launch_bounds__(EPI_NT, CMA ? EPI_WAVES_CMA : EPI_WAVES) void dp_epilogue_kernel(int64_t N, int batch_len, const float *__restrict__ q, const float *__restrict__ y,
                                                              const __half *__restrict__ txg, const float *__restrict__ amp_g,
                                                              const float *__restrict__ var, const float *__restrict__ nu_sc,
                                                              float *__restrict__ ser, int32_t *__restrict__ shift_out,
