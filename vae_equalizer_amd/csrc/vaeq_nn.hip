@@ -448,8 +448,9 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
     float *sm = reinterpret_cast<float *>(smem4);
     constexpr int C = 2 * NLEV;
     const int tid = threadIdx.x, run = blockIdx.x;
-    const int B = BK ? 300 : a.B, sps = SPS ? SPS : a.sps, M = BK ? 25 : a.M, k1 = BK ? 25 : a.k1, k2 = BK ? 3 : a.k2;
-    const NNLayout l = nn_layout(B, sps, M, NLEV, k1, k2, BN);
+    // BK = 2: only the LDS layout of that shape is constant; the shape itself stays in run-time variables (no unrolling on constant trip counts)
+    const int B = BK == 1 ? 300 : a.B, sps = SPS ? SPS : a.sps, M = BK == 1 ? 25 : a.M, k1 = BK == 1 ? 25 : a.k1, k2 = BK == 1 ? 3 : a.k2;
+    const NNLayout l = BK ? nn_layout(300, SPS ? SPS : 2, 25, NLEV, 25, 3, BN) : nn_layout(B, sps, M, NLEV, k1, k2, BN);
     const int L = l.L, p1 = l.p1, p2 = l.p2, Lx = l.Lx, Lz = l.Lz, mh = l.mh, Mh = l.Mh, nm = l.nm, NP = l.NP;
     float *zb = sm + l.zb, *bnst = sm + l.bnst;                // BN ? separate buffers : zb aliases z1
     float *xs = sm + l.xs, *z1 = sm + l.z1, *a2 = sm + l.a2, *mu = sm + l.mu, *vr = sm + l.vr, *es = sm + l.es, *VS = sm + l.VS;
@@ -949,10 +950,13 @@ static int launch_nn_train(const vaeq_nn_args &a, size_t lds, hipStream_t st)
 {
     void (*k)(const vaeq_nn_args) = a.batch_norm ? nn_train_kernel<512, NLEV, true, 0> : nn_train_kernel<512, NLEV, false, 0>;
     if (a.sps == 2) k = a.batch_norm ? nn_train_kernel<512, NLEV, true, 2> : nn_train_kernel<512, NLEV, false, 2>;
-    // the sweep script's shape baked, for 64-QAM only: +18 % (Net) / +14 % (Net_BN) there; at 16- and 4-QAM the constant trip counts make the
-    // compiler unroll into 54-73 spilled registers resp. one wave per SIMD less (-1 ... -20 %)
-    if (NLEV == 8 && a.sps == 2 && a.B == 300 && a.M == 25 && a.k1 == 25 && a.k2 == 3)
-        k = a.batch_norm ? nn_train_kernel<512, NLEV, true, 2, NLEV == 8 ? 1 : 0> : nn_train_kernel<512, NLEV, false, 2, NLEV == 8 ? 1 : 0>;
+    // the sweep script's shape baked: fully (layout + trip counts) for 64-QAM, +18 % (Net) / +14 % (Net_BN); for 16-QAM only the LDS layout (+10 % / +7 %:
+    // with constant trip counts the compiler unrolls into 54-73 spilled registers there, -1 ... -13 %); 4-QAM keeps the run-time shape (either form
+    // costs it a resident workgroup per CU: -20 ... -27 %)
+    if ((NLEV == 8 || NLEV == 4) && a.sps == 2 && a.B == 300 && a.M == 25 && a.k1 == 25 && a.k2 == 3) {
+        constexpr int BK = NLEV == 8 ? 1 : NLEV == 4 ? 2 : 0;
+        k = a.batch_norm ? nn_train_kernel<512, NLEV, true, 2, BK> : nn_train_kernel<512, NLEV, false, 2, BK>;
+    }
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VAEQ_ERR_LDS;
     hipLaunchKernelGGL(k, dim3(a.R), dim3(512), lds, st, a);
