@@ -19,6 +19,9 @@ What one invocation does (rank 0 prints ONE JSON line, contract in the task stat
 
 N > 1: one process per GPU (torch.distributed.run), each rank owns its own R runs (weak scaling, the sweep is embarrassingly parallel),
 no data-path collective; the only communication is the all_gather of the per-run result rows, inside every timed region.
+
+--config5: the same step on SURVEY config 5's saturation variant (Eval_run_DP.py:24,34: 4 nu x 5 SNR x 3 lr x iter 64 = 3840 runs with
+per-run PCS tables / noise levels), a FIXED total sharded r mod N over the ranks: "scaling": "strong" (DESIGN.md section 6 states the expected curve).
 """
 import argparse
 import json
@@ -68,6 +71,38 @@ def make_frames(n_frames, R, device, seed, with_data=False):
         if f == 0:
             data0 = data
     return (frames, t, data0) if with_data else (frames, t)
+
+
+def config5_points(n_iter):
+    """SURVEY config 5 (Eval_run_DP.py:24,34 comments x :41 x iter): the sweep script's own loop order flattened, one dict per run."""
+    from vae_equalizer_amd import Eval_run_DP as ev
+    saved = ev.nu_vec, ev.SNR_vec, ev.iter
+    ev.nu_vec, ev.SNR_vec, ev.iter = [0, 0.0270955, 0.0872449, 0.1222578], [20, 22, 24, 26, 28], n_iter
+    try:
+        return [p for _, p in ev.sweep_points()]
+    finally:
+        ev.nu_vec, ev.SNR_vec, ev.iter = saved
+
+
+def make_frames_config5(n_frames, pts, device, seed):
+    """rx of n_frames frames for the runs ``pts`` (per-run PCS tables and SNR) -> (frames, amps, P[R,n], var[R,2], nu_sc[R], lr[R])."""
+    from vae_equalizer_amd import channel as ch
+    from vae_equalizer_amd import shared_funcs as sfun
+    tabs = [sfun.qam_tables(CFG["mod"], p["nu"]) for p in pts]
+    h_ch = sfun.upsampled_channel(CFG["channel"], CFG["sps"])
+    R = len(pts)
+    P = np.stack([t["P"] for t in tabs]).astype(np.float32)
+    snr = np.array([p["SNR"] for p in pts], np.float32)
+    var = np.stack([np.full(2, t["pow_mean"] / 10 ** (p["SNR"] / 10) / 2) for t, p in zip(tabs, pts)]).astype(np.float32)
+    nu_sc = np.array([t["nu_sc"] for t in tabs], np.float32)
+    lr = np.array([p["lr_optim"] for p in pts], np.float32)
+    frames = []
+    for f in range(n_frames):
+        theta = np.array([p["theta"] + f * p["theta_diff"] for p in pts])
+        rx, _ = ch.generate_batch_hip(R, CFG["N_frame_max"], tabs[0]["amps"], P, snr, h_ch, CFG["symb_rate"], CFG["sps"], CFG["tau_cd"], CFG["tau_pmd"],
+                                      CFG["phiIQ"], theta, device, seed, f)
+        frames.append(rx.unsqueeze(1))
+    return frames, tabs[0]["amps"], P, var, nu_sc, lr
 
 
 def host_cores():
@@ -160,7 +195,7 @@ def parity_gate(frame_rx, data0, t, var, lr, device, threads):
                                         "note": "free runs past the chaotic horizon (SURVEY section 7)"}}
 
 
-def cpu_baseline(frame_rx, t, var, lr, target_s, threads):
+def cpu_baseline(frame_rx, t, var, lr, target_s, threads, note=""):
     """The C oracle (oracle/, a port of the reference's step) on the host cores, OpenMP over runs, on a bounded sample of
     the same workload: the first `Rc` runs of the first frame, trained repeatedly until ~target_s of wall time."""
     import oracle
@@ -191,7 +226,7 @@ def cpu_baseline(frame_rx, t, var, lr, target_s, threads):
             "sample": f"{Rc} runs x {done} frame(s) x {steps * B} DP symbols of the same config, fp32 C oracle with OpenMP over runs, "
                       f"{el:.1f} s wall; per core {sym / el / used:.0f} DP-symbols/s. The reference itself (PyTorch, CPU-only by construction, "
                       f"func_VAELE_DP_MQAM_shaping.py:18) ran {REFERENCE_DP_SYMBOLS_PER_S:.0f} DP-symbols/s on 4 threads in the survey container "
-                      "(BASELINE.md section 2); it cannot travel to the GPU box",
+                      "(BASELINE.md section 2); it cannot travel to the GPU box" + note,
             "reference_dp_symbols_per_s": REFERENCE_DP_SYMBOLS_PER_S}
 
 
@@ -342,6 +377,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip extra.pipeline / extra.configs / the stream-copy calibration")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity gate (profiling runs only)")
     ap.add_argument("--distinct-frames", type=int, default=4, help="distinct synthetic frames cycled through the steps")
+    ap.add_argument("--config5", action="store_true", help="strong scaling: SURVEY config 5's saturation variant (4 nu x 5 SNR x 3 lr x --iter seeds), "
+                    "a fixed total sharded r mod N over the ranks, one gather of the result rows")
+    ap.add_argument("--iter", type=int, default=64, help="--config5: seeds per sweep point (script default 5 -> 300 runs; 64 -> 3840 runs)")
     args = ap.parse_args()
 
     from vae_equalizer_amd import sweep
@@ -352,6 +390,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     import torch.distributed as dist
+    collective = dist.is_available() and dist.is_initialized()   # N > 1, or N = 1 under VAEQ_FORCE_COLLECTIVE=1 (RCCL exercised on one GPU)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -361,23 +400,41 @@ def main():
     resident = int(nat.lib().vaeq_dp_resident_runs(B, sps, M, 8, args.threads))
     if resident <= 0:
         raise SystemExit(f"vaeq_dp_resident_runs failed: {resident}")
-    R = args.runs if args.runs > 0 else 4 * resident
     steps_per_frame = CFG["N_frame_max"] // B
     n_distinct = max(1, min(args.distinct_frames, K + Wm))
-    frames, t, data0 = make_frames(n_distinct, R, device, seed=1000 + rank, with_data=True)
+    from vae_equalizer_amd import shared_funcs as sfun
+    t = sfun.qam_tables(CFG["mod"], CFG["nu"])
     var = t["pow_mean"] / 10 ** (CFG["SNR"] / 10) / 2
-    lr = np.array([CFG["lr_optim_vec"][(rank * R + i) % 3] for i in range(R)], np.float32)     # the sweep's lr axis
+    if args.config5:
+        pts = config5_points(args.iter)
+        R_total = len(pts)
+        mine = sweep.my_slice(R_total, rank, world)
+        R = len(mine)
+        frames, amps5, P5, var5, nu5, lr = make_frames_config5(n_distinct, [pts[i] for i in mine], device, seed=1000 + rank)
+        eng_args = (R, M, amps5, P5, var5, nu5, device, sps, args.threads)
+    else:
+        R = args.runs if args.runs > 0 else 4 * resident
+        R_total = world * R
+        frames, _t = make_frames(n_distinct, R, device, seed=1000 + rank)
+        lr = np.array([CFG["lr_optim_vec"][(rank * R + i) % 3] for i in range(R)], np.float32)     # the sweep's lr axis
+        eng_args = (R, M, t["amps"], t["P"], [var, var], t["nu_sc"], device, sps, args.threads)
 
     parity = None
     if rank == 0 and not args.no_parity:
-        parity = parity_gate(frames[0], data0, t, var, lr, device, args.threads)
+        if args.config5:                                       # the gate's runs: config 3's constants (the config-5 points are pinned by tests/golden G10, G13)
+            gframes, _t, data0 = make_frames(1, 64, device, seed=1000, with_data=True)
+            glr = np.array([CFG["lr_optim_vec"][i % 3] for i in range(64)], np.float32)
+        else:
+            gframes, _t, data0 = make_frames(1, min(R, 64), device, seed=1000 + rank, with_data=True)   # = the first runs of frames[0]
+            glr = lr
+        parity = parity_gate(gframes[0], data0, t, var, glr, device, args.threads)
+        del gframes, data0
         if not parity["ok"]:
             print(json.dumps({"metric": "equalized symbols/s/GPU, DP 64-QAM VAE-LE", "value": None, "parity": parity,
                               "error": "parity gate failed: the HIP path disagrees with the CPU oracle; nothing was timed"}), flush=True)
             sys.exit(3)
-    del data0
 
-    eng = DPEngine(R, M, t["amps"], t["P"], [var, var], t["nu_sc"], device, sps, args.threads)
+    eng = DPEngine(*eng_args)
     lr_t = torch.tensor(lr, device=device)
 
     def one_step(k):
@@ -394,7 +451,7 @@ def main():
     regions, launch_ms, step_no = [], [], Wm
     while True:
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -403,14 +460,14 @@ def main():
             out = one_step(step_no + k)
             ev[k][1].record()
         rows = torch.cat([out["loss"][:, 0, -1:], out["var_est"][:, 0, :, -1]], dim=1)             # per-run result row
-        if world > 1:
-            allrows = sweep.gather_rows(rows, world * R, rank, world)                              # the sweep's single gather (RCCL over xGMI)
-            assert allrows.shape[0] == world * R
+        if collective:
+            allrows = sweep.gather_rows(rows, R_total, rank, world, force_collective=True)         # the sweep's single gather (RCCL over xGMI)
+            assert allrows.shape[0] == R_total
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
         el = time.perf_counter() - t0
-        if world > 1:
+        if collective:
             tt = torch.tensor([el], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())                              # identical on every rank: all ranks take the same number of regions
@@ -421,41 +478,56 @@ def main():
         if sum(regions) >= args.min_seconds or len(regions) >= 200:
             break
     el = float(np.median(regions))
-    kern_ms = float(np.mean(launch_ms))                       # the AVERAGE launch of the timed regions prices the roofline (rocprofv3's kernel stats
-    kern_ms_median = float(np.median(launch_ms))              # report the same statistic); the median is given next to it
+    kern_ms = float(np.median(launch_ms))                     # the MEDIAN launch of the timed regions prices the roofline, like `value` takes the median
+    kern_ms_mean = float(np.mean(launch_ms))                  # region (one cold launch no longer puts kernel_ms above ms_per_step); the mean -- the statistic
+                                                              # rocprofv3's kernel stats report -- is given next to it
 
     if rank == 0:
         sym_per_launch = R * CFG["N_frame_max"]
-        value = world * sym_per_launch * K / el
+        value = R_total * CFG["N_frame_max"] * K / el
         achieved = ALGO_BYTES_PER_DP_SYMBOL * sym_per_launch / (kern_ms * 1e-3) / 1e9
         rate_k = sym_per_launch / (kern_ms * 1e-3)
-        traffic = None
+        traffic, why = None, "profiles/pmc_traffic.json is missing"
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tj):
             try:
                 d = json.load(open(tj))
-                if d.get("runs") == R and d.get("threads", 0) == args.threads and d.get("kernel", kernel_name) == kernel_name:  # same launch as this run
-                    traffic = d.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        extras = world == 1 and not args.no_extras
+                mism = [f"{k}: profiled {d.get(k)!r}, this run {v!r}" for k, v in (("runs", R), ("threads", args.threads), ("kernel", kernel_name)) if d.get(k) != v]
+                if args.config5:
+                    mism.append("workload: profiled the default workload, this run --config5")
+                if mism:                                       # not the launch that was profiled: say so instead of quoting a stale figure
+                    why = "profiles/pmc_traffic.json is of another launch (" + "; ".join(mism) + ")"
+                else:
+                    traffic, why = d.get("hbm_bytes_per_launch"), None
+            except Exception as e:
+                why = f"profiles/pmc_traffic.json unreadable: {e}"
+        extras = world == 1 and not args.no_extras and not args.config5
         copy_gbs = stream_copy_gbs(device) if extras else None
+        if args.config5:
+            workload = (f"SURVEY config 5, saturation variant: optical DP 64-QAM + PCS VAE-LE, nu in {{0, .0270955, .0872449, .1222578}} x SNR in {{20..28}} dB x "
+                        f"lr in {{2.5e-3,2e-3,3e-3}} x iter {args.iter} = {R_total} runs in total, run r on rank r mod {world}; h0, 90 GBd, M_est=25, batch_len=100, "
+                        "N_frame_max=10000 (100 minibatch steps per bench step)")
+        else:
+            workload = ("SURVEY config 3: optical DP 64-QAM VAE-LE, nu=0, SNR 23 dB, h0, 90 GBd, M_est=25, batch_len=100, "
+                        "N_frame_max=10000 (100 minibatch steps per bench step), lr in {2.5e-3,2e-3,3e-3}; seed axis raised to "
+                        f"{R} independent runs per GPU (script default iter=5 -> 15 runs)")
         res = {
             "metric": "equalized symbols/s/GPU, DP 64-QAM VAE-LE", "value": value, "unit": "DP-symbols/s (1 DP symbol = 2 polarisation symbols)",
-            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": el / K * 1e3, "higher_is_better": True, "scaling": "strong" if args.config5 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (on-device DP channel simulator vaeq_gen_dp_*: Philox PCS draw, RRC, CD+PMD+rotation in the frequency domain, AWGN)",
             "per_gpu": value / world,
             "timed_regions": len(regions), "region_ms": {"min": min(regions) * 1e3, "median": el * 1e3, "max": max(regions) * 1e3},
-            "config": {"workload": "SURVEY config 3: optical DP 64-QAM VAE-LE, nu=0, SNR 23 dB, h0, 90 GBd, M_est=25, batch_len=100, "
-                                   "N_frame_max=10000 (100 minibatch steps per bench step), lr in {2.5e-3,2e-3,3e-3}; seed axis raised to "
-                                   f"{R} independent runs per GPU (script default iter=5 -> 15 runs)",
-                       "runs_per_gpu": R, "resident_runs_per_gpu": resident, "dp_symbols_per_step_per_gpu": sym_per_launch,
+            "config": {"workload": workload,
+                       "runs_per_gpu": R, "runs_total": R_total, "resident_runs_per_gpu": resident, "dp_symbols_per_step_per_gpu": sym_per_launch,
                        "kernel_choice": args.threads,
-                       "distinct_frames": n_distinct, "parallelism": f"sweep-sharded x{world}, one all_gather of result rows per timed region"},
+                       "distinct_frames": n_distinct, "parallelism": f"sweep-sharded x{world}, one all_gather of result rows per timed region"
+                                                                      + (f" ({dist.get_backend()})" if collective else "")},
             "parity": parity,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch, tools/profile_traffic.sh)" if traffic else None,
-                         "kernel": kernel_name, "kernel_ms": kern_ms, "kernel_ms_median": kern_ms_median, "kernel_ms_minmax": [min(launch_ms), max(launch_ms)],
+                         "traffic_dropped_because": why,
+                         "kernel": kernel_name, "kernel_ms": kern_ms, "kernel_ms_statistic": "median of the timed launches (HIP events)", "kernel_ms_mean": kern_ms_mean,
+                         "kernel_ms_minmax": [min(launch_ms), max(launch_ms)],
                          "launches_timed": len(launch_ms),
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_DP_SYMBOL * sym_per_launch,
                          "peak_measured_copy": copy_gbs, "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None,
@@ -465,14 +537,36 @@ def main():
                          "algorithmic_flops_per_dp_symbol": ALGO_FLOPS_PER_DP_SYMBOL,
                          "binds": "fp32 VALU issue + LDS (45 flop/B is above the 20 flop/B ridge); the HBM fraction is reported because north_star declares it"},
         }
+        if not args.no_cpu_baseline and world == 1 and not args.config5:      # reported baseline: rank 0 at N = 1 only
+            # The CPU leg (~12 s of OpenMP work) runs in a thread WHILE the GPU keeps executing the headline launch back to back (untimed for `value`,
+            # reported as extra.sustained): the GPU is busy for the whole invocation and the line also says what ten seconds of sustained load reach.
+            import threading
+            cores = host_cores()
+            box = {}
+            frame0 = frames[0]
+            th = threading.Thread(target=lambda: box.update(r=cpu_baseline(frame0, t, var, lr, args.cpu_seconds, max(1, cores - 1),
+                                                                            note="; one host core was left to the thread that kept the GPU busy meanwhile")))
+            t0 = time.perf_counter()
+            th.start()
+            sus_ms, nl = [], 0
+            while th.is_alive():
+                sus_ms += _event_ms(lambda: one_step(nl), 8)
+                nl += 8
+            th.join()
+            wall = time.perf_counter() - t0
+            res["cpu_baseline"] = box["r"]
+            if extras:
+                res.setdefault("extra", {})["sustained"] = {"seconds": wall, "launches": nl, "kernel_ms_median": float(np.median(sus_ms)),
+                                                            "kernel_ms_mean": float(np.mean(sus_ms)), "dp_symbols_per_s": nl * sym_per_launch / wall,
+                                                            "note": "the headline launch back to back (host-enqueued in groups of 8) while the CPU baseline leg runs"}
         if extras:
             del out, eng
             torch.cuda.empty_cache()
-            res["extra"] = {"pipeline": extra_pipeline(R, t, var, device), "configs": extra_configs(R, t, var, frames[0], device)}
-        if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
-            res["cpu_baseline"] = cpu_baseline(frames[0], t, var, lr, args.cpu_seconds, 0)
+            res.setdefault("extra", {})["pipeline"] = extra_pipeline(R, t, var, device)
+            res["extra"]["pipeline_small"] = extra_pipeline(300, t, var, device, frames=20)
+            res["extra"]["configs"] = extra_configs(R, t, var, frames[0], device)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

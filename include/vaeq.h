@@ -98,6 +98,13 @@ typedef struct vaeq_dp_args {
 
 int vaeq_dp_train(const vaeq_dp_args *args, void *stream);
 
+/* SURVEY 8(b)'s `vaeq_dp_step_debug`: ONE minibatch step per run that additionally dumps the step's gradients, for teacher-forced parity
+ * tests against loss.backward() of the reference (func_VAELE_DP_MQAM_shaping.py:64-65: dL/dW as net.conv_w.weight.grad [2][4][M], dL/dh_est
+ * [2][2][2][M]).  = vaeq_dp_train on the first window of the first frame (n_frames and steps taken as 1) with dbg_gW / dbg_gh pointed at
+ * gW / gh; args->no_update chooses between "gradients only" and "gradients + the Adam step"; every other field as for vaeq_dp_train.
+ * (vaeq_dp_train itself dumps the LAST step's gradients when args->dbg_gW / dbg_gh are set: same kernels, same values.) */
+int vaeq_dp_step_debug(const vaeq_dp_args *args, float *gW, float *gh, void *stream);
+
 /* LDS bytes one run (= one workgroup) needs for the given shape, or a negative error code. */
 int64_t vaeq_dp_lds_bytes(int32_t B, int32_t sps, int32_t M, int32_t n_lev);
 

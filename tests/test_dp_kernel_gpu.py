@@ -54,6 +54,33 @@ def test_teacher_forced_step(name, threads):
     assert int(eng.step[0]) == 1
 
 
+def test_step_debug_entry_point():
+    """vaeq_dp_step_debug: one teacher-forced step that dumps dL/dW, dL/dh -- against the reference's autograd gradients (G1) and,
+    bit for bit, against what vaeq_dp_train leaves in dbg_gW / dbg_gh."""
+    import ctypes as C
+    from vae_equalizer_amd import _native as nat
+    g = load_golden(G1[0])
+    B, sps, M = int(g["B"]), int(g["sps"]), int(g["M_est"])
+    rx = torch.from_numpy(g["rx"][None, None, :, :, :B * sps]).to(DEV).contiguous()
+    eng = _engine(g)
+    eng.set_state(g["W0"], g["h0"])
+    ref = eng.train(rx, B, 1, float(g["lr"]), debug_grads=True, no_update=True)
+    gW, gh = torch.zeros(1, 2, 4, M, device=DEV), torch.zeros(1, 2, 2, 2, M, device=DEV)
+    lr = torch.full((1,), float(g["lr"]), device=DEV)
+    loss = torch.zeros(1, 1, 1, device=DEV)
+    a = nat.DPArgs(R=1, n_frames=1, steps=1, B=B, sps=sps, M=M, n_lev=eng.n_lev, stride_sym=B, keep_off=0, keep_len=B, S=B * sps, rx=nat.ptr(rx),
+                   W=nat.ptr(eng.W), h=nat.ptr(eng.h), adam_mW=nat.ptr(eng.mW), adam_vW=nat.ptr(eng.vW), adam_mh=nat.ptr(eng.mh), adam_vh=nat.ptr(eng.vh),
+                   step=nat.ptr(eng.step, torch.int32), amp=nat.ptr(eng.amp), P=nat.ptr(eng.P), var=nat.ptr(eng.var), nu_sc=nat.ptr(eng.nu_sc),
+                   lr_W=nat.ptr(lr), lr_h=nat.ptr(lr), loss=nat.ptr(loss), threads=0, no_update=1)
+    nat.check(nat.lib().vaeq_dp_step_debug(C.byref(a), nat.ptr(gW), nat.ptr(gh), nat.current_stream(torch.device(DEV))), "vaeq_dp_step_debug")
+    torch.cuda.synchronize()
+    assert torch.equal(gW, ref["gW"]) and torch.equal(gh, ref["gh"]) and torch.equal(loss, ref["loss"])
+    assert relerr(_np(gh)[0], g["gh0"]) < 2e-5 and relerr(_np(gW)[0], g["gW0"]) < 1e-4
+    assert int(eng.step[0]) == 0 and np.array_equal(_np(eng.W)[0], g["W0"].astype(np.float32))      # no_update: state untouched
+    a.steps = 2
+    assert nat.lib().vaeq_dp_step_debug(C.byref(a), nat.ptr(gW), nat.ptr(gh), nat.current_stream(torch.device(DEV))) != 0
+
+
 @pytest.mark.parametrize("name", G1)
 def test_three_steps_and_moments(name):
     g = load_golden(name)

@@ -95,9 +95,17 @@ def test_hip_generator_padded_fft_differs_only_at_the_frame_edges():
     sps, N, seed, frame = 2, 4000, 11, 2
     h_est, h_ch, P, amp_levels, amps, pol, nu_sc, var, pow_mean = sfun.init("h0", "64-QAM", "cpu", 0.0, sps, 25, 23)
     args = (2, N, amps, P, 200.0, h_ch, DP["symb_rate"], sps, DP["tau_cd"], DP["tau_pmd"], DP["phiIQ"], np.array([0.3, 1.1]), "cuda:0", seed, frame)
-    rxe, de = ch.generate_batch_hip(*args, fft="exact")
-    rxp, dp_ = ch.generate_batch_hip(*args, fft="padded")
+    rxe, de, se = ch.generate_batch_hip(*args, fft="exact", return_sigma=True)
+    rxp, dp_, sp = ch.generate_batch_hip(*args, fft="padded", return_sigma=True)
     assert torch.equal(de, dp_)
+    # the noise level comes from the power BEFORE the (unitary) fibre: identical in both modes, and exact for the circular transform over Ls
+    # ("exact").  In "padded" mode a little energy of the linear filtering lands in the zero pad, so the power of what is kept differs from it:
+    # bound that against the post-dispersion power of the returned (noise-free: 200 dB) samples -- 2 x 8000 samples estimate it to ~1 %
+    assert torch.equal(se, sp)
+    for rx_, tag in ((rxe, "exact"), (rxp, "padded")):
+        p_post = (rx_.double() ** 2).sum(dim=2).mean(dim=(1, 2)).cpu().numpy()                    # mean |sig|^2 per run over both polarisations
+        p_pre = (se.double().cpu().numpy() ** 2) * 2 / sps * 10 ** (200.0 / 10)                     # sigma^2 = P sps / 2 / 10^(SNR/10)   (:83)
+        assert np.all(np.abs(p_post / p_pre - 1) < 0.03), (tag, p_post / p_pre)
     e, p = rxe.cpu().numpy(), rxp.cpu().numpy()
     scale = np.abs(e).max()
     assert np.max(np.abs(e - p)[..., 64:-64]) < 1e-3 * scale                   # interior: equal up to the tails of the response

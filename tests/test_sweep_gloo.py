@@ -57,3 +57,26 @@ def test_single_process_is_identity():
     assert sweep.my_slice(5, 0, 1) == [0, 1, 2, 3, 4]
     x = torch.randn(5, 2)
     assert sweep.gather_rows(x, 5, 0, 1) is x
+
+
+def _worker_forced(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", VAEQ_FORCE_COLLECTIVE="1")
+    from vae_equalizer_amd import sweep
+    r, w, _ = sweep.init_distributed(backend="gloo")            # VAEQ_FORCE_COLLECTIVE: a process group even at world size 1
+    x = torch.arange(35.0).reshape(7, 5)
+    rows = sweep.gather_rows(x, 7)                                # ... and the collective branch instead of the identity shortcut
+    q.put((r, w, dist.is_initialized(), rows is x, rows))
+    dist.destroy_process_group()
+
+
+def test_forced_collective_at_world_size_one():
+    """What tests/test_bench_gpu.py::test_rccl_gather_single_rank runs with backend nccl on the GPU box, rehearsed over gloo."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_forced, args=(_free_port(), q))
+    p.start()
+    r, w, init, same, rows = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and (r, w) == (0, 1) and init and not same
+    assert torch.equal(rows, torch.arange(35.0).reshape(7, 5))

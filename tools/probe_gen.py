@@ -24,14 +24,14 @@ for mode in modes:
     else:
         os.environ.pop("VAEQ_GEN_STAGED", None)
     t0 = time.perf_counter()
-    ch.generate_batch_hip(*args, 0, chunk=chunk)
+    ch.generate_batch_hip(*args, 0)
     torch.cuda.synchronize()
     first = time.perf_counter() - t0
     ts = []
     for f in range(1, 6):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ch.generate_batch_hip(*args, f, chunk=chunk)
+        ch.generate_batch_hip(*args, f)
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
     print(f"{mode:7s} R={R} chunk={chunk}: first call {first * 1e3:8.1f} ms, then {np.median(ts) * 1e3:6.2f} ms/frame (min {min(ts) * 1e3:.2f})", flush=True)

@@ -19,7 +19,7 @@ def frames(R, frame, staged):
     h_est, h_ch, P, amp_levels, amps, pol, nu_sc, var, pow_mean = sfun.init("h0", "64-QAM", "cpu", 0.0270955, 2, 25, 23)
     theta = np.linspace(0, 40, R)
     return ch.generate_batch_hip(R, 10000, amps, P, np.linspace(18, 30, R).astype(np.float32), h_ch, 90e9, 2, -26e-24, 0.1e-12 * np.sqrt(1000),
-                                 np.array([0.0314, 0.0314], np.complex64), theta, "cuda:0", 3, frame, chunk=8192)
+                                 np.array([0.0314, 0.0314], np.complex64), theta, "cuda:0", 3, frame)
 
 
 for R in (300, 1500, 4100):

@@ -40,7 +40,7 @@ N_frame_max = 10000
 
 savePATH = ""
 base_seed = None    # int -> reproducible runs (run i of the flattened sweep uses base_seed + 1000*i); None = like the reference
-generator = "numpy"  # "numpy": reference-faithful host channel simulator; "hip" / "torch": batched on-device simulators
+generator = None    # None: "hip" (on-device channel simulator) for unseeded sweeps, "numpy" (reference-faithful host simulator) when base_seed is set; or force "numpy" / "hip" / "torch"
 
 
 def sweep_points():
@@ -81,7 +81,7 @@ def main():
         if loss_type in ('CMA', 'CMAbatch', 'CMAflex'):         # the constant-modulus baselines (:58-65)
             from .cma_runs import run_cma_batch
             r = run_cma_batch(runs, loss_type, mod, sps, M, batch_len, N_frame_max, num_frames, fs, channel, tau_cd, tau_pmd, phiIQ, N_lrhalf,
-                              device=device, generator=generator if generator in ("numpy", "hip") else "hip", verbose=False)
+                              device=device, generator=generator if generator in (None, "numpy", "hip") else "hip", verbose=False)
         elif loss_type in ('VAE', 'VAEflex'):
             r = run_dp_batch(runs, mod, sps, M, batch_len, N_frame_max, num_frames, fs, channel, tau_cd, tau_pmd, phiIQ, N_lrhalf,
                              flex=(loss_type == 'VAEflex'), device=device, generator=generator, verbose=False)

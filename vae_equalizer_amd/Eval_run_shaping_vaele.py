@@ -22,7 +22,7 @@ epe = 2                 # epochs per evaluation
 
 savePATH = ""
 base_seed = None        # int -> reproducible runs; None = like the reference
-generator = "numpy"     # "numpy": reference-faithful host channel simulator per run; "hip": on-device generator (vaeq_gen_awgn)
+generator = None        # None: "hip" (on-device generator vaeq_gen_awgn) for unseeded sweeps, "numpy" (reference-faithful host simulator) when base_seed is set
 
 
 def sweep_points():

@@ -103,7 +103,7 @@ class NNArgs(C.Structure):
 
 
 # every symbol include/vaeq.h declares; tests check the library exports all of them
-EXPORTS = ["vaeq_dp_train", "vaeq_dp_lds_bytes", "vaeq_dp_resident_runs", "vaeq_soft_demap", "vaeq_dp_forward", "vaeq_dp_loss", "vaeq_dp_loss_bwd", "vaeq_dp_forward_bwd", "vaeq_dp_epilogue", "vaeq_dp_epilogue_ws_bytes", "vaeq_dp_epilogue_compact", "vaeq_gen_dp_tx", "vaeq_gen_dp_disperse", "vaeq_gen_dp_finish", "vaeq_gen_dp_frame", "vaeq_awgn_train",
+EXPORTS = ["vaeq_dp_train", "vaeq_dp_step_debug", "vaeq_dp_lds_bytes", "vaeq_dp_resident_runs", "vaeq_soft_demap", "vaeq_dp_forward", "vaeq_dp_loss", "vaeq_dp_loss_bwd", "vaeq_dp_forward_bwd", "vaeq_dp_epilogue", "vaeq_dp_epilogue_ws_bytes", "vaeq_dp_epilogue_compact", "vaeq_gen_dp_tx", "vaeq_gen_dp_disperse", "vaeq_gen_dp_finish", "vaeq_gen_dp_frame", "vaeq_awgn_train",
            "vaeq_awgn_lds_bytes", "vaeq_awgn_forward", "vaeq_awgn_validate", "vaeq_awgn_loss", "vaeq_awgn_loss_bwd", "vaeq_awgn_forward_bwd", "vaeq_gen_awgn", "vaeq_nn_train", "vaeq_nn_param_count", "vaeq_nn_lds_bytes", "vaeq_nn_forward", "vaeq_nn_validate", "vaeq_cma", "vaeq_cpe", "vaeq_version", "vaeq_strerror", "vaeq_last_kernel", "vaeq_stream_copy", "vaeq_gen_dp_power_parts", "vaeq_cma_epilogue"]
 
 
@@ -124,6 +124,8 @@ def lib():
         L.vaeq_stream_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.vaeq_dp_train.restype = C.c_int
         L.vaeq_dp_train.argtypes = [C.POINTER(DPArgs), C.c_void_p]
+        L.vaeq_dp_step_debug.restype = C.c_int
+        L.vaeq_dp_step_debug.argtypes = [C.POINTER(DPArgs), C.c_void_p, C.c_void_p, C.c_void_p]
         L.vaeq_dp_lds_bytes.restype = C.c_int64
         L.vaeq_dp_lds_bytes.argtypes = [C.c_int32] * 4
         L.vaeq_dp_resident_runs.restype = C.c_int64

@@ -283,10 +283,15 @@ def fast_fft_len(n):
     return best
 
 
-def generate_batch_hip(R, N, amps, P, SNR, h_channel, symb_rate, sps, tau_cd, tau_pmd, phiIQ, theta, device, seed, frame, chunk=8192,
+STREAM_BLOCK = 8192   # runs per vaeq_gen_dp_frame call.  Part of the DEFINITION of the random streams (run r draws from the Philox key of block
+                      # r // STREAM_BLOCK with run counter r % STREAM_BLOCK), hence a constant and not a tuning parameter: frames of a seed never
+                      # depend on how much workspace a caller wants to spend (8192 runs = a 2.7 GB workspace for the default frame)
+
+
+def generate_batch_hip(R, N, amps, P, SNR, h_channel, symb_rate, sps, tau_cd, tau_pmd, phiIQ, theta, device, seed, frame,
                        return_sigma=False, fft="padded"):
-    """The DP channel model for R runs on the device: one vaeq_gen_dp_frame call per chunk of runs (8192 runs = a 2.7 GB workspace for the
-    default frame; the padded default frame takes the library's three-pass form, other row lengths the stage kernels around in-place hipFFT).
+    """The DP channel model for R runs on the device: one vaeq_gen_dp_frame call per STREAM_BLOCK runs (the padded default frame takes the
+    library's three-pass form, other row lengths the stage kernels around in-place hipFFT).
 
     fft: "exact"  -- dispersion applied on the FFT of the exact sequence length Ls like the reference (circular filtering; Ls = 20034 =
                      2*3^3*7*53 for the default frame costs hipFFT 4x the time of a 20480-point transform);
@@ -314,12 +319,12 @@ def generate_batch_hip(R, N, amps, P, SNR, h_channel, symb_rate, sps, tau_cd, ta
         raise ValueError(f"fft must be 'exact' or 'padded', got {fft!r}")
     Lrow = geo["Ls"] if fft == "exact" else fast_fft_len(geo["Ls"] + 64)
     with torch.cuda.device(dev):
-        for r0 in range(0, R, chunk):
-            r1 = min(R, r0 + chunk)
+        for r0 in range(0, R, STREAM_BLOCK):
+            r1 = min(R, r0 + STREAM_BLOCK)
             Rc = r1 - r0
             sig = torch.empty(Rc, 2, Lrow, 2, dtype=torch.float32, device=dev)
             pw = torch.empty(Rc, L.vaeq_gen_dp_power_parts(Lrow), dtype=torch.float32, device=dev)   # the first pass's partial sums of |sig|^2
-            # runs inside a chunk are told apart by the run counter word of the Philox streams, chunks by the key (_mix_seed)
+            # runs inside a block are told apart by the run counter word of the Philox streams, blocks by the key (_mix_seed)
             nat.check(L.vaeq_gen_dp_frame(Rc, N, geo["N_conv"], sps, n, geo["Lg"], geo["Ls"], Lrow, geo["ref_offset"], nat.ptr(amp_t),
                                           nat.ptr(cdf[r0:r1].contiguous()), nat.ptr(g_t), nat.ptr(snr[r0:r1].contiguous()),
                                           nat.ptr(th[r0:r1].contiguous()), float(symb_rate) * sps, float(tau_cd), float(tau_pmd),

@@ -14,7 +14,7 @@ import torch
 from . import channel as ch
 from . import epilogue as epi
 from . import shared_funcs as sfun
-from .dp_runs import DPRun, _host_pool, check_one_symb_rate, default_device, fresh_seed  # noqa: F401
+from .dp_runs import DPRun, _host_pool, check_one_symb_rate, default_device, fresh_seed, resolve_generator  # noqa: F401
 from .engine import cma, cpe, soft_demap
 
 N_CUT = 10   # symbols cut at both frame ends before the phase estimation (func_CMA_DP_MQAM_shaping.py:26,39)
@@ -52,13 +52,14 @@ def cma_frame_epilogue_torch(out_const, data, amp, nu_sc, var):
 
 
 def run_cma_batch(runs, mode, mod, sps, M_est, batch_len, N_train_max, num_frames, flex_step, channel, tau_cd, tau_pmd, phiIQ, N_lrhalf,
-                  device=None, generator="numpy", verbose=False):
+                  device=None, generator=None, verbose=False):
     """R baseline runs (list of dp_runs.DPRun; lr_optim = the CMA step size) -> dict(SER[R,4,num_frames], Var_est[R,2,num_frames] (zeros,
     like the reference), var[R,2], h).  mode: "CMA" | "CMAbatch" | "CMAflex"."""
     if mode not in ("CMA", "CMAbatch", "CMAflex"):
         raise ValueError(f"unknown CMA variant {mode!r}")
     device = default_device() if device is None else torch.device(device)
     R = len(runs)
+    generator = resolve_generator(generator, any(r.seed is not None for r in runs))   # unseeded -> on-device simulator
     tabs = [sfun.qam_tables(mod, r.nu) for r in runs]
     h_channel = sfun.upsampled_channel(channel, sps)
     amps = tabs[0]["amps"]

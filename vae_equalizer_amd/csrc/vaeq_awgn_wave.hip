@@ -649,8 +649,7 @@ static int launch_awgn_wave_k(const vaeq_awgn_args &a, hipStream_t st)
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VAEQ_ERR_LDS;
-    if (BL) note_kernel("vaeq::awgn_wave_kernel<%d, %d, %d, %d, %d>", M, NLEV, NR, NW, BL);
-    else note_kernel("vaeq::awgn_wave_kernel<%d, %d, %d, %d>", M, NLEV, NR, NW);
+    note_kernel("vaeq::awgn_wave_kernel<%d, %d, %d, %d, %d>", M, NLEV, NR, NW, BL);   // every template argument, as rocprofv3 prints the name
     hipLaunchKernelGGL(k, dim3(a.R), dim3(64 * NW), lds, st, a);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }

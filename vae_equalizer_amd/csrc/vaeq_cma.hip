@@ -336,9 +336,10 @@ extern "C" int vaeq_cma(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t mo
     if (!rx || !h || !lr || !out) return VAEQ_ERR_NULL;
     if (R < 0 || N <= 0 || N > 0x3fffffff || sps <= 0 || M <= 0 || (M & 1) == 0 || M > 63 || N / sps < 2 * M) return VAEQ_ERR_SHAPE;
     if (!(mode == 0 || mode == 1) || (mode == 1 && (batchlen <= 0 || symb_step <= 0 || batchlen > 4096))) return VAEQ_ERR_SHAPE;
+    if (mode == 0) batchlen = symb_step = 0;                   // plain CMA takes neither: whatever was passed never reaches the sizing below or the kernel
     size_t lds = mode == 1 ? (size_t)batchlen * 8 * sizeof(float) : 0;
     int xcap = 64;                                             // sample ring: a power of two >= sps (batchlen + 2) + M positions
-    while (xcap < sps * (batchlen + 2) + M) xcap <<= 1;
+    while (mode == 1 && xcap < sps * (batchlen + 2) + M) xcap <<= 1;   // (mode 1: batchlen <= 4096 was checked above, so this ends)
     // staged samples pay when the 100-term update runs often (CMAflex: every symb_step = 10 symbols); with one update per batchlen symbols (CMAbatch)
     // the per-symbol barrier of the staged form costs more than the update gains (17.7 vs 20.3 ms per 8192-run frame)
     const bool stage = mode == 1 && lds + (size_t)xcap * 16 <= 24 * 1024 && 4 * symb_step <= batchlen;

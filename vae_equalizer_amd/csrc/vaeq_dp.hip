@@ -451,6 +451,16 @@ extern "C" int vaeq_dp_train(const vaeq_dp_args *pa, void *stream)
     return VAEQ_ERR_SHAPE;
 }
 
+extern "C" int vaeq_dp_step_debug(const vaeq_dp_args *pa, float *gW, float *gh, void *stream)
+{
+    if (!pa || !gW || !gh) return VAEQ_ERR_NULL;
+    if (pa->n_frames != 1 || pa->steps != 1) return VAEQ_ERR_SHAPE;   // one step: the array layouts are those of n_frames = steps = 1
+    vaeq_dp_args a = *pa;
+    a.dbg_gW = gW;
+    a.dbg_gh = gh;
+    return vaeq_dp_train(&a, stream);
+}
+
 namespace vaeq {
 int64_t dp_wave_resident(int B, int M, int n_lev);   // vaeq_dp_wave.hip
 template <int NT, int NLEV>

@@ -964,7 +964,7 @@ static int launch_wave(const vaeq_dp_args &a, hipStream_t st)
         hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VAEQ_ERR_LDS;
     const int out = !BT ? 0 : (!a.eq_out && !a.dec_out) ? 1 : !a.q_out ? 2 : 0;
-    note_kernel("vaeq::dp_wave_kernel<%d, %d, %d, %s, %d, %d>", M, NLEV, BT, pair ? "true" : "false", out, NW);
+    note_kernel("vaeq::dp_wave_kernel<%d, %d, %d, %s, %d, %d, 0>", M, NLEV, BT, pair ? "true" : "false", out, NW);   // every template argument, as rocprofv3 prints the name
     hipLaunchKernelGGL(k, dim3(a.R), dim3(64 * NW), lds, st, a);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }

@@ -551,11 +551,9 @@ static int get_fused_tables(int Lrow, double fs, double tau_cd, double tau_pmd, 
     const FusedKey key{dev, Lrow, fs, tau_cd, tau_pmd};
     auto it = g_fused.find(key);
     if (it == g_fused.end()) {
-        if (g_fused.size() >= 64) {                            // a sweep over many fibre parameter sets: start over (nothing in flight may use them)
-            if (hipDeviceSynchronize() != hipSuccess) return VAEQ_ERR_DEVICE;
-            for (auto &kv : g_fused) { (void)hipFree(kv.second.T); (void)hipFree(kv.second.H); }
-            g_fused.clear();
-        }
+        // entries are never freed: callers launch on the tables after this lock is released (possibly from other threads / on other devices), so
+        // there is no point at which an eviction could know them idle; a table pair is 12 bytes x Lrow (240 KB for the default frame) per distinct
+        // (device, row length, fibre parameters) -- a sweep over 1000 fibre parameter sets holds 240 MB of the 288 GB
         FusedTables t{nullptr, nullptr};
         if (hipMalloc(&t.T, sizeof(float2) * Lrow) != hipSuccess || hipMalloc(&t.H, sizeof(float4) * Lrow) != hipSuccess) {
             (void)hipFree(t.T);

@@ -67,6 +67,15 @@ def fresh_seed():
     return int(np.random.SeedSequence().entropy & 0xFFFFFFFFFFFF)
 
 
+def resolve_generator(generator, seeded):
+    """``generator=None`` (the default of every entry point): the on-device simulator ("hip") for unseeded runs -- the reference seeds nothing
+    (shared_funcs.py:75,84), so there is no random stream to be faithful to and the sweep stays on the GPU --, the reference-faithful host
+    simulator ("numpy") for seeded runs, whose frames then equal what the reference draws under the same seed (tests/golden)."""
+    if generator is None:
+        return "numpy" if seeded else "hip"
+    return generator
+
+
 def check_one_symb_rate(runs, generator):
     """The device generators take one symbol rate per call; a batch that mixes them would silently simulate runs[0]'s."""
     if generator != "numpy" and len({float(r.symb_rate) for r in runs}) > 1:
@@ -82,15 +91,17 @@ def default_device():
 
 
 def run_dp_batch(runs, mod, sps, M_est, batch_len, N_frame_max, num_frames, flex_step, channel, tau_cd, tau_pmd, phiIQ,
-                 N_lrhalf, flex=False, device=None, generator="numpy", verbose=False, threads=0, keep_last=False):
+                 N_lrhalf, flex=False, device=None, generator=None, verbose=False, threads=0, keep_last=False):
     """Train + evaluate R runs.  Returns dict(SER[R,4,num_frames], Var_est[R,2,num_frames], var[R,2]) on the CPU.
 
-    generator: "numpy" = reference-faithful host simulator per run (seeded per run when DPRun.seed is set);
+    generator: None    = "hip" when no run carries a seed, "numpy" otherwise (resolve_generator);
+               "numpy" = reference-faithful host simulator per run (seeded per run when DPRun.seed is set);
                "hip"   = on-device simulator, HIP kernels + hipFFT, Philox streams keyed by the first run's seed (row f1);
                "torch" = batched on-device simulator (channel.generate_batch_gpu), seeded from the first run's seed.
     """
     device = default_device() if device is None else torch.device(device)
     R = len(runs)
+    generator = resolve_generator(generator, any(r.seed is not None for r in runs))
     check_one_symb_rate(runs, generator)
     tabs = [sfun.qam_tables(mod, r.nu) for r in runs]
     h_channel = sfun.upsampled_channel(channel, sps)

@@ -5,6 +5,6 @@ from .cma_runs import _processing
 
 
 def processing(mod, sps, SNR, nu, M_est, theta_diff, theta, lr_optim, batch_len, N_train_max, num_frames, flex_step, channel, symb_rate, tau_cd,
-               tau_pmd, phiIQ, N_lrhalf, *, seed=None, device=None, verbose=True, generator="numpy"):
+               tau_pmd, phiIQ, N_lrhalf, *, seed=None, device=None, verbose=True, generator=None):
     return _processing("CMAflex", mod, sps, SNR, nu, M_est, theta_diff, theta, lr_optim, batch_len, N_train_max, num_frames, flex_step, channel,
                        symb_rate, tau_cd, tau_pmd, phiIQ, N_lrhalf, seed, device, verbose, generator)

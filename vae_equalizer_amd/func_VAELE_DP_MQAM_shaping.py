@@ -4,7 +4,7 @@ from .dp_runs import DPRun, run_dp_batch
 
 
 def processing(mod, sps, SNR, nu, M_est, theta_diff, theta, lr_optim, batch_len, N_frame_max, num_frames, flex_step, channel,
-               symb_rate, tau_cd, tau_pmd, phiIQ, N_lrhalf, *, seed=None, device=None, verbose=True, generator="numpy"):
+               symb_rate, tau_cd, tau_pmd, phiIQ, N_lrhalf, *, seed=None, device=None, verbose=True, generator=None):
     """One DP VAE-LE Monte-Carlo run -> (SER_valid[4,num_frames], Var_est[2,num_frames], var[2]), CPU float32 tensors.
 
     Rows of SER_valid: 0-1 constellation-based SER x/y, 2-3 soft-demapper SER x/y (:79,89).

@@ -4,7 +4,7 @@ import numpy as np
 import torch
 
 from . import channel as ch
-from .dp_runs import _host_pool, default_device
+from .dp_runs import _host_pool, default_device, resolve_generator
 from .engine import AWGNEngine
 from .shared_funcs import _CHANNELS, qam_tables
 
@@ -103,15 +103,20 @@ def SER_symb(rx, tx, sps, amp_levels, num_lev, device=None):
 
 
 def run_awgn_batch(runs, mod, sps, M_est, batch_len, N_valid, N_train, num_epochs, epe, channel, device=None, verbose=False,
-                   generator="numpy", seed=0):
+                   generator=None, seed=None):
     """R AWGN VAE-LE runs at once: ``runs`` = list of dict(SNR, nu, lr_optim, seed).  Per epoch ONE training launch and, on evaluated
     epochs, ONE fused validation launch (forward + find_shift + SER_q, vaeq_awgn_validate) for all runs (:291-322).
 
-    generator: "numpy" = the bit-faithful host channel model per run (seeded like tools/capture_golden.py when the run has a seed);
+    generator: None    = "hip" when no run carries a seed (the reference seeds nothing), else "numpy" (dp_runs.resolve_generator);
+               "numpy" = the bit-faithful host channel model per run (seeded like tools/capture_golden.py when the run has a seed);
                "hip"   = the on-device generator (vaeq_gen_awgn), Philox streams keyed by ``seed``, the draw counter and the run index.
     Returns SER_valid[R, num_epochs // epe] (CPU float32)."""
     device = default_device() if device is None else torch.device(device)
     R = len(runs)
+    generator = resolve_generator(generator, any(r.get("seed") is not None for r in runs))
+    if seed is None:                                                             # Philox key of the device generator: fresh entropy when not given
+        from .dp_runs import fresh_seed
+        seed = fresh_seed()
     tabs = [awgn_tables(mod, r["nu"], r["SNR"], channel, sps) for r in runs]
     t0 = tabs[0]
     amp = torch.tensor(t0["amps"], dtype=torch.float32, device=device)
@@ -156,7 +161,7 @@ def run_awgn_batch(runs, mod, sps, M_est, batch_len, N_valid, N_train, num_epoch
 
 
 def processing(mod, sps, SNR, nu, M_est, lr_optim, batch_len, N_valid, N_train, num_epochs, epe, channel, *, seed=None,
-               device=None, verbose=True):
+               device=None, verbose=True, generator=None):
     """One AWGN VAE-LE run -> SER_valid[num_epochs//epe] (CPU float32).
 
     NB the sweep script passes its ``N_train`` (350) as ``batch_len`` and ``train_len`` (1200) as ``N_train``
@@ -165,4 +170,4 @@ def processing(mod, sps, SNR, nu, M_est, lr_optim, batch_len, N_valid, N_train, 
     if verbose:
         print("We are using the following device for learning:", device)
     return run_awgn_batch([dict(SNR=SNR, nu=nu, lr_optim=lr_optim, seed=seed)], mod, sps, M_est, batch_len, N_valid, N_train,
-                          num_epochs, epe, channel, device=device, verbose=verbose)[0]
+                          num_epochs, epe, channel, device=device, verbose=verbose, generator=generator)[0]

@@ -5,7 +5,7 @@ from .dp_runs import DPRun, run_dp_batch
 
 
 def processing(mod, sps, SNR, nu, M_est, theta_diff, theta, lr_optim, batch_len, N_train_max, num_frames, flex_step, channel,
-               symb_rate, tau_cd, tau_pmd, phiIQ, N_lrhalf, *, seed=None, device=None, verbose=True, generator="numpy"):
+               symb_rate, tau_cd, tau_pmd, phiIQ, N_lrhalf, *, seed=None, device=None, verbose=True, generator=None):
     """One DP VAEflex run -> (SER_valid[4,num_frames], Var_est[2,num_frames], var[2]), CPU float32 tensors."""
     r = run_dp_batch([DPRun(SNR, nu, theta_diff, theta, lr_optim, symb_rate, seed)], mod, sps, M_est, batch_len, N_train_max,
                      num_frames, flex_step, channel, tau_cd, tau_pmd, phiIQ, N_lrhalf, flex=True, device=device,

@@ -18,9 +18,12 @@ def dist_info():
 
 
 def init_distributed(backend=None):
-    """Initialise the process group when launched by torch.distributed.run with WORLD_SIZE > 1 (one process per GPU)."""
+    """Initialise the process group when launched by torch.distributed.run with WORLD_SIZE > 1 (one process per GPU).
+    VAEQ_FORCE_COLLECTIVE=1 initialises it at WORLD_SIZE = 1 as well (under torch.distributed.run --nproc-per-node 1), so that RCCL's
+    initialisation and the gather's collective run on a one-GPU box exactly as they do on N GPUs (gather_rows)."""
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world > 1 and not dist.is_initialized():
+    force = bool(os.environ.get("VAEQ_FORCE_COLLECTIVE")) and "RANK" in os.environ
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
@@ -54,11 +57,17 @@ def my_slice(n_runs, rank=None, world=None):
     return list(range(rank, n_runs, world))
 
 
-def gather_rows(local_rows, n_runs, rank=None, world=None):
-    """local_rows[len(my_slice), ...] float32 -> rows[n_runs, ...] in run order, on every rank (a single all_gather)."""
+def gather_rows(local_rows, n_runs, rank=None, world=None, force_collective=None):
+    """local_rows[len(my_slice), ...] float32 -> rows[n_runs, ...] in run order, on every rank (a single all_gather).
+
+    force_collective (default: the environment's VAEQ_FORCE_COLLECTIVE): at world == 1 still go through the process group's
+    all_gather_into_tensor on device tensors when one is initialised -- the very code N ranks execute, so RCCL (backend ``nccl``) can be
+    exercised on a single GPU (tests/test_bench_gpu.py::test_rccl_gather_single_rank)."""
     if rank is None:
         rank, world, _ = dist_info()
-    if world == 1:
+    if force_collective is None:
+        force_collective = bool(os.environ.get("VAEQ_FORCE_COLLECTIVE"))
+    if world == 1 and not (force_collective and dist.is_available() and dist.is_initialized()):
         return local_rows
     per = (n_runs + world - 1) // world
     shape = (per,) + tuple(local_rows.shape[1:])
