@@ -75,6 +75,15 @@ def run_ensemble(K, nu, SNR, F, N, theta_diff, seed):
     return SER, VE, var
 
 
+def _log(*a):
+    """Statistics of a run of these tests, kept when VAEQ_ENSEMBLE_LOG names a file (profiles/r03_*/ensemble_parity.txt is such a run)."""
+    import os
+    print(*a)
+    if os.environ.get("VAEQ_ENSEMBLE_LOG"):
+        with open(os.environ["VAEQ_ENSEMBLE_LOG"], "a") as fh:
+            print(*a, file=fh)
+
+
 def escape_frames(SER):
     """First frame from which on all four SER estimates stay below 0.1 for at least three frames (F if never)."""
     K, _, F = SER.shape
@@ -113,9 +122,11 @@ def test_locking_runs_ensemble_vs_oracle(case):
     if case == "pcs_G10":
         g = load_golden("G10_pcs_run")
         nu, F, N, td, ref_SER, ref_VE, K = float(g["nu"]), int(g["num_frames"]), int(g["N_frame_max"]), float(g["theta_diff"]), g["SER"], g["Var_est"], 48
+        min_locked = 0.9                                                        # 200 frames: (nearly) every run has locked by the end
     else:
         g = load_golden("G7_runs")
         nu, F, N, td, ref_SER, ref_VE, K = 0.0, int(g["vaele_num_frames"]), int(g["vaele_N_frame_max"]), float(g["vaele_theta_diff"]), g["vaele_SER"], g["vaele_Var_est"], 64
+        min_locked = 0.6          # the capture ends at frame 140, inside the escape distribution (oracle: 108 .. beyond 140, the reference's run: 118): censored at F
     SER, VE, var = run_ensemble(K, nu, 23.0, F, N, td, seed=20260 + len(case))
     hip, orc = SER[0], SER[1]
     # (a) same frames, before chaos: frame 0 run by run (N / 100 steps from the Dirac start)
@@ -125,18 +136,21 @@ def test_locking_runs_ensemble_vs_oracle(case):
     eh, eo = escape_frames(hip), escape_frames(orc)
     ks = stats.ks_2samp(eh, eo)
     info = dict(hip=(int(eh.min()), float(np.median(eh)), int(eh.max())), oracle=(int(eo.min()), float(np.median(eo)), int(eo.max())), ks_p=float(ks.pvalue))
-    print(case, "escape frames (min, median, max):", info)
+    _log(case, f"K={K} runs x {F} frames x {N} symbols; escape frames (min, median, max):", info, "locked fraction hip/oracle:", float((eh < F).mean()), float((eo < F).mean()))
     assert ks.pvalue > 0.01, info
     assert abs(np.median(eh) - np.median(eo)) <= 0.15 * np.median(eo), info
-    assert (eh < F).mean() >= 0.9 and abs((eh < F).mean() - (eo < F).mean()) <= 0.1, info       # (nearly) every run locks, on both sides alike
+    assert min((eh < F).mean(), (eo < F).mean()) >= min_locked and abs((eh < F).mean() - (eo < F).mean()) <= 0.1, info   # the same fraction locks on both sides
     # (c) converged level: SER (4 estimators) and noise estimate, ensemble means within 3 sigma of the Monte-Carlo error
     d, lim = mc_agree(converged_means(hip, eh, F), converged_means(orc, eo, F))
+    _log(case, "converged SER |hip - oracle| per estimator:", d, "3 sigma:", lim, "level:", np.nanmean(converged_means(orc, eo, F), axis=0))
     assert np.all(d <= lim), (d, lim)
     d, lim = mc_agree(converged_means(VE[0], eh, F), converged_means(VE[1], eo, F))
+    _log(case, "converged Var_est |hip - oracle|:", d, "3 sigma:", lim, "level:", np.nanmean(converged_means(VE[1], eo, F), axis=0), "true var:", var)
     assert np.all(d <= lim), (d, lim)
     # (d) the reference's captured run (its own seed, host generator) inside the pooled ensemble's range
     er = escape_frames(ref_SER[None])[0]
     pooled = np.concatenate([eh, eo])
+    _log(case, "the reference's captured run: escape frame", int(er), "pooled ensemble range", int(pooled.min()), int(pooled.max()))
     assert pooled.min() <= er <= pooled.max(), (int(er), info)
     cm = np.concatenate([converged_means(hip, eh, F), converged_means(orc, eo, F)])
     cm = cm[~np.isnan(cm).any(1)]
@@ -165,9 +179,11 @@ def test_heavy_shaping_plateau_ensemble_vs_oracle(name):
     for a, b in ((20, 60), (60, 120), (120, 200)):
         wh, wo = hip[keep_h][:, :, a:b].mean(axis=2), orc[keep_o][:, :, a:b].mean(axis=2)         # [K, 4] plateau SER per run
         d, lim = mc_agree(wh, wo)
+        _log(name, f"frames {a}..{b}: plateau SER |hip - oracle|", d, "3 sigma", lim, "level", wo.mean(axis=0), "reference", g["SER"][:, a:b].mean(axis=1))
         assert np.all(d <= lim), ("SER", a, b, d, lim)
         vh_, vo_ = VE[0][keep_h][:, :, a:b].mean(axis=2), VE[1][keep_o][:, :, a:b].mean(axis=2)
         d, lim = mc_agree(vh_, vo_)
+        _log(name, f"frames {a}..{b}: plateau Var_est |hip - oracle|", d, "3 sigma", lim, "level", vo_.mean(axis=0), "reference", g["Var_est"][:, a:b].mean(axis=1))
         assert np.all(d <= lim), ("Var_est", a, b, d, lim)
         # the reference's run inside the pooled range (SER rows within 0.01, the noise estimate within 3 %)
         ps, pv = np.concatenate([wh, wo]), np.concatenate([vh_, vo_])
