@@ -81,6 +81,30 @@ def test_batch_equals_single_runs_bitwise():
     assert np.all(np.diff(b["var"][:, 0].numpy()[::2]) < 0)     # var follows SNR (shared_funcs.py:581)
 
 
+def test_overlapped_frames_equal_serial_frames_bitwise(monkeypatch):
+    """Below the resident-run count run_dp_batch puts the three stages of a frame on three streams (channel model of frame f + 1 and epilogue of frame
+    f - 1 beside the training launch of frame f): every result bit-identical to the serial order (func_VAELE_DP_MQAM_shaping.py:43-89 is the serial loop)."""
+    from vae_equalizer_amd.dp_runs import DPRun, run_dp_batch
+    runs = [DPRun(20 + 2 * (i % 5), [0.0, 0.0270955][i % 2], 0.06 * np.pi, np.pi / 10, 2e-3 + 5e-4 * (i % 3), 90e9) for i in range(40)]
+    runs[0].seed = 1234                                                         # the Philox key of the device generator
+    kw = dict(mod="64-QAM", sps=2, M_est=25, batch_len=100, N_frame_max=3000, num_frames=12, flex_step=10, channel="h0", tau_cd=-26e-24,
+              tau_pmd=TAU_PMD, phiIQ=PHI, N_lrhalf=5, generator="hip")
+    a = run_dp_batch(runs, **kw)
+    monkeypatch.setenv("VAEQ_SERIAL_FRAMES", "1")
+    b = run_dp_batch(runs, **kw)
+    for k in ("SER", "Var_est"):
+        assert torch.equal(a[k], b[k]), k
+    for k in ("W", "h", "mW", "vW", "mh", "vh", "step"):
+        assert torch.equal(getattr(a["engine"], k), getattr(b["engine"], k)), k
+    assert torch.isfinite(a["SER"]).all() and (a["SER"][:, :, 0] > 0.5).all()
+    kw.update(flex=True, N_frame_max=1000, num_frames=4)                         # VAEflex windows through the same pipeline
+    monkeypatch.delenv("VAEQ_SERIAL_FRAMES")
+    c = run_dp_batch(runs[:6], **kw)
+    monkeypatch.setenv("VAEQ_SERIAL_FRAMES", "1")
+    d = run_dp_batch(runs[:6], **kw)
+    assert torch.equal(c["SER"], d["SER"]) and torch.equal(c["Var_est"], d["Var_est"])
+
+
 def test_torch_generator_path_trains():
     """On-device channel generator (row f1) feeding the kernel: loss decreases, outputs well-formed."""
     from vae_equalizer_amd.dp_runs import DPRun, run_dp_batch
@@ -173,6 +197,60 @@ def test_hip_epilogue_random_batch_vs_oracle(batch_len, n):
         assert np.array_equal(r["shift_q"][i].cpu().numpy(), o["shift_q"]) and int(r["r_q"][i]) == o["r_q"], i
         assert np.array_equal(r["shift_c"][i].cpu().numpy(), o["shift_c"]) and int(r["r_c"][i]) == o["r_c"], i
         assert np.allclose(r["SER"][i].cpu().numpy(), o["SER"], atol=2.5e-3), (i, r["SER"][i], o["SER"])     # <= 2 symbols of ~900 at a threshold
+
+
+@pytest.mark.parametrize("N,batch_len,n,offgrid", [(1000, 100, 8, False), (10000, 100, 8, False), (9900, None, 8, False), (1002, None, 4, False), (3000, 50, 2, False),
+                                                 (2000, 100, 8, True)])
+def test_lds_resident_epilogue_equals_rereading_epilogue(N, batch_len, n, offgrid, monkeypatch):
+    """vaeq_dp_epilogue_compact's kernels -- dp_epilogue_compact_kernel (both correlations per staged TX tile, branch-free walks; with and without the
+    frame's TX levels resident in LDS, vaeq_epilogue_lds.h) vs the re-reading dp_epilogue_kernel (VAEQ_EPI_REREAD=1) -- agree bit for bit on synthetic runs (delays, swaps, rotations, IQ flips), also for frame lengths
+    that are no multiple of four and for a TX reference that is NOT the fp16 image of the levels (the radius walk then reads TX itself); and with the
+    numpy oracle on shifts / swaps exactly, SER within two symbols at a decision threshold."""
+    import oracle
+    from vae_equalizer_amd.engine import dp_epilogue_compact
+    lev_all = np.arange(-(n - 1), n, 2).astype(np.float32)
+    amp = (lev_all / np.sqrt(np.mean(lev_all ** 2) * 2)).astype(np.float32)
+    rng = np.random.default_rng(5 + N + n)
+    R = 9
+    qs, ys, ds, nus, vars_ = [], [], [], [], []
+    for i in range(R):
+        lev = rng.integers(0, n, (2, 2, N))
+        clean = amp[lev].astype(np.float32)
+        rot = [clean, np.stack([-clean[:, 1], clean[:, 0]], 1), -clean, np.stack([clean[:, 1], -clean[:, 0]], 1)][i % 4]
+        if i % 5 == 4:
+            rot = np.stack([rot[:, 0], -rot[:, 1]], 1)
+        y = (0.8 + 0.05 * i) * rot + (0.02 + 0.03 * i) * rng.standard_normal(rot.shape).astype(np.float32)
+        sw, d = i % 2, int(rng.integers(-9, 10))
+        y = np.roll(y, sw, axis=0)
+        dl = (d, d) if sw else (d, int(rng.integers(-9, 10)))
+        y = np.stack([np.roll(y[0], dl[0], -1), np.roll(y[1], dl[1], -1)]).astype(np.float32)
+        nu_sc = float(rng.uniform(0, 1.2)); v = rng.uniform(0.002, 0.02, 2).astype(np.float32)
+        tx = amp[lev].astype(np.float16)
+        if offgrid:
+            tx = (tx.astype(np.float32) * (1 + 0.01 * rng.standard_normal(tx.shape))).astype(np.float16)   # same levels under rint(scale t + scale), other radii
+        qs.append(oracle.dp_soft_dec(y, v, amp, nu_sc)); ys.append(y); ds.append(tx); nus.append(nu_sc); vars_.append(v)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(np.stack(a))).cuda()
+    q, yt, dt, amp_t = t(qs), t(ys), t(ds), torch.tensor(amp, device="cuda")
+    eq = torch.einsum("i,rpin->rpn", amp_t, q[:, :, :n]).contiguous()
+    dec = torch.stack([q[:, 0, :n].argmax(1), q[:, 0, n:].argmax(1), q[:, 1, :n].argmax(1), q[:, 1, n:].argmax(1)], 1).reshape(R, 2, 2, N).to(torch.int8)
+    nu_t, var_t = torch.tensor(nus, dtype=torch.float32, device="cuda"), t(vars_)
+    new = dp_epilogue_compact(eq, dec, yt, dt, amp_t, nu_t, var_t, batch_len)
+    monkeypatch.setenv("VAEQ_EPI_NOTXC", "1")                                    # the same kernel without the TX level cache in LDS
+    mid = dp_epilogue_compact(eq, dec, yt, dt, amp_t, nu_t, var_t, batch_len)
+    monkeypatch.setenv("VAEQ_EPI_REREAD", "1")
+    old = dp_epilogue_compact(eq, dec, yt, dt, amp_t, nu_t, var_t, batch_len)
+    for k in old:
+        assert torch.equal(old[k], new[k]) and torch.equal(old[k], mid[k]), (k, old[k], new[k], mid[k])
+    eq_h, dec_h = eq.cpu().numpy(), dec.cpu().numpy()
+    for i in range(R):
+        if offgrid:
+            continue                                             # (the oracle is pinned on on-grid references; the two kernels agreeing is the check here)
+        o = oracle.dp_frame_epilogue(qs[i], ys[i], ds[i], amp, nus[i], vars_[i], batch_len=batch_len)
+        assert np.array_equal(new["shift_c"][i].cpu().numpy(), o["shift_c"]) and int(new["r_c"][i]) == o["r_c"], i
+        assert np.allclose(new["SER"][i, :2].cpu().numpy(), o["SER"][:2], atol=2.5e-3), (i, new["SER"][i], o["SER"])
+        # the soft-demapper rows come from eq / dec as torch derives them from q (argmax ties, fma order): compared on the shift only when unambiguous
+        if np.array_equal(new["shift_q"][i].cpu().numpy(), o["shift_q"]) and int(new["r_q"][i]) == o["r_q"]:
+            assert np.allclose(new["SER"][i, 2:].cpu().numpy(), o["SER"][2:], atol=2.5e-3), (i, new["SER"][i], o["SER"])
 
 
 def test_awgn_batch_equals_single_runs():

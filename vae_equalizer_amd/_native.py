@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("VAEQ_LIB") or os.path.join(_PKG, "libvaeq_hip.so")   # VAEQ_LIB: A/B builds of the kernels (tools/build_variant.sh)
 SOURCES = ["vaeq_dp.hip", "vaeq_dp_wave.hip", "vaeq_dp_wave_mw.hip", "vaeq_dp_wave_mw8.hip", "vaeq_dp_wave_bk.hip", "vaeq_dp_wave_b128.hip", "vaeq_dp_wave_fl.hip", "vaeq_awgn.hip", "vaeq_awgn_wave.hip", "vaeq_misc.hip", "vaeq_nn.hip", "vaeq_cma.hip", "vaeq_epilogue.hip", "vaeq_gen.hip"]
-HEADERS = ["vaeq_common.h", "vaeq_wave.h", "vaeq_validate.h", "vaeq_dp_wave_kernel.h", "vaeq_gen_fused.h"]
+HEADERS = ["vaeq_common.h", "vaeq_wave.h", "vaeq_validate.h", "vaeq_dp_wave_kernel.h", "vaeq_gen_fused.h", "vaeq_epilogue_lds.h"]
 _LIB = None
 
 

@@ -1,12 +1,15 @@
 // vaeq_dp_wave.hip -- dispatch of the wave-per-run DP kernel (vaeq_dp_wave_kernel.h): one wavefront per run for B <= 128 (M = 25: B = 100 and 128 baked,
 // every other even B on the fixed layout of B = 128 -- like all B of the other tap counts; the run-time layout only as M = 25's A/B form); the
 // multi-wave variants for 128 < B <= 1024 are instantiated in vaeq_dp_wave_mw.hip / vaeq_dp_wave_mw8.hip.
+#include <stdlib.h>
+
 #include "vaeq_dp_wave_kernel.h"
 
 namespace vaeq {
 
 int launch_dp_wave_mw(const vaeq_dp_args &a, hipStream_t st);          // vaeq_dp_wave_mw.hip
 int64_t dp_wave_mw_resident(int B, int M, int n_lev);
+int launch_dp_wave_nw(const vaeq_dp_args &a, hipStream_t st, int nw);   // vaeq_dp_wave_mw.hip: any B on nw wavefronts per run (run-time layout)
 bool dp_wave_fixl(int B, int M);                                        // vaeq_dp_wave_bk.hip (false under VAEQ_DP_RUNTIME_LAYOUT=1: A/B switch)
 int launch_dp_wave_bk(const vaeq_dp_args &a, hipStream_t st);
 int64_t dp_wave_bk_resident(int n_lev);
@@ -39,6 +42,9 @@ int64_t dp_wave_resident(int B, int M, int n_lev)
 int launch_dp_wave(const vaeq_dp_args &a, hipStream_t st)
 {
     if (a.B > 128) return launch_dp_wave_mw(a, st);
+    if (const char *e = getenv("VAEQ_DP_FORCE_NW")) {          // experiment knob: B <= 128 on two / four wavefronts per run (run-time layout)
+        if (e[0] == '2' || e[0] == '4') return launch_dp_wave_nw(a, st, e[0] - '0');
+    }
     if (a.M == 25 && a.B == 128 && dp_wave_fixl(64, 25)) return launch_dp_wave_b128(a, st);
     if (dp_wave_fixl(a.B, a.M)) return launch_dp_wave_bk(a, st);
     if (a.M == 25 && a.B == 100) return launch_wave_lev<25, 100, 1>(a, st);

@@ -20,6 +20,8 @@ int launch_dp_wave_mw(const vaeq_dp_args &a, hipStream_t st)
     return a.B <= 256 ? launch_wave_any<2>(a, st) : a.B <= 512 ? launch_wave_any<4>(a, st) : launch_dp_wave_mw8(a, st);
 }
 
+int launch_dp_wave_nw(const vaeq_dp_args &a, hipStream_t st, int nw) { return nw == 2 ? launch_wave_any<2>(a, st) : launch_wave_any<4>(a, st); }
+
 int64_t dp_wave_mw_resident(int B, int M, int n_lev)
 {
     if (M == 25 && B == 200) return wave_resident_lev<25, 200, 2>(B, n_lev);

@@ -12,6 +12,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "vaeq.h"
 #include "vaeq_common.h"
@@ -169,6 +170,16 @@ __device__ __forceinline__ void epi_correlate(const float *__restrict__ E /*[2][
         sh.kept = 0;
     }
     __syncthreads();
+}
+
+// Add a thread's count to a workgroup counter in LDS: wave sum on the vector ALU first (exact: counts < 2^24), then ONE integer LDS atomic per wave.
+// A plain atomicAdd per thread is turned by the compiler's atomic optimiser into a serial loop over the wave's 64 lanes (s_ff1 / v_readlane / add per
+// lane): 17 counters x 64 lanes x ~8 instructions per walk and wavefront -- that loop, not the walk's arithmetic or its memory traffic, was what the
+// SER walks of this kernel spent most of their time in (phase stamps: 150 k of 180 k cycles; profiles/r03).  Integer sums: order-independent, bitwise reproducible.
+__device__ __forceinline__ void epi_count_add(int *dst, int v)
+{
+    const int tot = (int)wave_sum_dpp((float)v);
+    if ((threadIdx.x & 63) == 0) atomicAdd(dst, tot);
 }
 
 // symbols that survive the per-minibatch cut (:73-77) and the frame-edge slice (:79)
@@ -370,8 +381,8 @@ __global__ __launch_bounds__(EPI_NT, CMA ? EPI_WAVES_CMA : EPI_WAVES) void dp_ep
 #pragma unroll
                     for (int e = 0; e < 4; e++)
                         if (kp[e]) {
-                            st += sqrtf(ti[e] * ti[e] + tq[e] * tq[e]);
-                            sy += sqrtf(yi[e] * yi[e] + yq[e] * yq[e]);
+                            st += sqrtf(fmaf(ti[e], ti[e], tq[e] * tq[e]));   // (explicit fma: the same rounding as dp_epilogue_lds_kernel's table)
+                            sy += sqrtf(fmaf(yi[e], yi[e], yq[e] * yq[e]));
                         }
                 }
             }
@@ -443,8 +454,8 @@ __global__ __launch_bounds__(EPI_NT, CMA ? EPI_WAVES_CMA : EPI_WAVES) void dp_ep
             }
         }
 #pragma unroll
-        for (int i = 0; i < 16; i++) atomicAdd(&sh.cnt[i], cnt[i]);
-        atomicAdd(&sh.kept, kept);
+        for (int i = 0; i < 16; i++) epi_count_add(&sh.cnt[i], cnt[i]);
+        epi_count_add(&sh.kept, kept);
         __syncthreads();
         if (tid < 2) {                                          // min over the 8 hypotheses (:221 / :264)
             const float den = (float)max(sh.kept, 1);
@@ -493,6 +504,8 @@ __global__ __launch_bounds__(EPI_NT, CMA ? EPI_WAVES_CMA : EPI_WAVES) void dp_ep
 
 }  // namespace vaeq
 
+#include "vaeq_epilogue_lds.h"
+
 extern "C" int64_t vaeq_dp_epilogue_ws_bytes(int32_t R, int64_t N)
 {
     if (R < 0 || N < 0) return VAEQ_ERR_SHAPE;
@@ -528,6 +541,28 @@ extern "C" int vaeq_dp_epilogue_compact(int32_t R, int64_t N, int32_t n_lev, int
     if (R < 0 || N < 2 * vaeq::EDGE + vaeq::N_SHIFT || N > 0x3fffffff || batch_len < 0 || (batch_len > 0 && N % batch_len)) return VAEQ_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const __half *tx = reinterpret_cast<const __half *>(tx_f16);
+    // dp_epilogue_compact_kernel (vaeq_epilogue_lds.h): both correlations on one staged TX tile, branch-free walks, TX levels resident in LDS when the
+    // frame's packed rows fit beside the tiles (N <= ~60 000 symbols).  VAEQ_EPI_REREAD=1 keeps the re-reading dp_epilogue_kernel, VAEQ_EPI_NOTXC=1 the
+    // new kernel without the TX level cache (A/B switches and cross-checks: all three agree bit for bit)
+    const char *old_env = getenv("VAEQ_EPI_REREAD"), *notxc_env = getenv("VAEQ_EPI_NOTXC");
+    if ((batch_len == 0 || batch_len >= 4) && !(old_env && old_env[0] == '1')) {
+        const size_t dyn_txc = (size_t)4 * vaeq::nib_words((int)N) * sizeof(uint32_t);
+        const bool txc = dyn_txc + sizeof(vaeq::Epi2Shared) <= 53 * 1024 && !(notxc_env && notxc_env[0] == '1');   // three workgroups per CU
+        const size_t dyn = txc ? dyn_txc : 0;
+#define VAEQ_EPI2(NL)                                                                                                                     \
+    {                                                                                                                                     \
+        auto k = txc ? vaeq::dp_epilogue_compact_kernel<NL, true> : vaeq::dp_epilogue_compact_kernel<NL, false>;                          \
+        hipLaunchKernelGGL(k, dim3(R), dim3(vaeq::EPI_NT), dyn, st, (int)N, batch_len, eq, dec, y, tx, amp, var, nu_sc, ser, shift, rflag); \
+    }
+        switch (n_lev) {
+        case 2: VAEQ_EPI2(2) break;
+        case 4: VAEQ_EPI2(4) break;
+        case 8: VAEQ_EPI2(8) break;
+        default: return VAEQ_ERR_SHAPE;
+        }
+#undef VAEQ_EPI2
+        return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+    }
     float *wsE = const_cast<float *>(eq);
     int8_t *wsD = const_cast<int8_t *>(dec);
     const float *q = nullptr;

@@ -7,6 +7,7 @@ shape of the problem -- and may differ in SNR, nu, theta_diff, theta, lr_optim a
 symb_rate (the on-device generators simulate one symbol rate per call: Eval_run_DP batches by symbol rate, mixed batches are refused).
 """
 import math
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -36,7 +37,6 @@ def host_threads():
     """Host threads THIS process may use for the host-side channel model: VAEQ_CPU_THREADS if set, else the affinity mask capped by
     the cgroup CPU quota, divided by the number of ranks sharing the node (LOCAL_WORLD_SIZE, else WORLD_SIZE): under
     torch.distributed.run with 8 ranks each rank takes an eighth of the cores instead of all of them."""
-    import os
     if os.environ.get("VAEQ_CPU_THREADS"):
         return max(1, int(os.environ["VAEQ_CPU_THREADS"]))
     try:
@@ -81,6 +81,23 @@ def check_one_symb_rate(runs, generator):
     if generator != "numpy" and len({float(r.symb_rate) for r in runs}) > 1:
         raise ValueError(f"generator={generator!r} simulates ONE symb_rate per batch, got {sorted({float(r.symb_rate) for r in runs})}: "
                          "batch the runs by symb_rate (Eval_run_DP.main does) or use generator='numpy'")
+
+
+_SIDE = {}
+
+
+def _side_streams(device):
+    """The two side streams (channel model, epilogue) of the overlapped frame pipeline, made once per device."""
+    key = str(device)
+    if key not in _SIDE:
+        _SIDE[key] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+    return _SIDE[key]
+
+
+def _resident_runs(batch_len, sps, M_est, n_lev, threads):
+    """How many runs of this shape the device keeps co-resident (vaeq_dp_resident_runs); 0 if the library cannot say."""
+    from . import _native as nat
+    return max(0, int(nat.lib().vaeq_dp_resident_runs(int(batch_len), int(sps), int(M_est), int(n_lev), int(threads))))
 
 
 def default_device():
@@ -139,26 +156,24 @@ def run_dp_batch(runs, mod, sps, M_est, batch_len, N_frame_max, num_frames, flex
     SER = torch.empty(R, 4, num_frames, dtype=torch.float32, device=device)
     Var_est = torch.empty(R, 2, num_frames, dtype=torch.float32, device=device)
     last = None
-    for frame in range(num_frames):
-        # lr schedule: group 0 (W) only, set (not multiplied) to lr/2 (func_VAELE_DP_MQAM_shaping.py:45-46)
-        # -> lr from frame 0, lr/2 from frame N_lrhalf on (every later trigger re-sets the same value)
-        cur_lr_W = lr0_half_t if frame >= N_lrhalf else lr0_t                 # device tensors made once: no H2D copy (a host sync) per frame
-        if generator == "hip":                                                  # HIP generator kernels + hipFFT (row f1)
-            SNRs = np.array([r.SNR for r in runs], dtype=np.float32)
-            if frame == 0:
-                hip_seed = int(runs[0].seed) if runs[0].seed is not None else fresh_seed()
+    SNRs = np.array([r.SNR for r in runs], dtype=np.float32)
+    hip_seed = (int(runs[0].seed) if runs[0].seed is not None else fresh_seed()) if generator == "hip" else None
+    state = {"theta": theta}
+
+    def make_frame(frame):
+        """rx[R,2,2,S], data[R,2,2,N] of one frame (channel model of frame `frame`; advances the runs' polarisation angle, :50-51)."""
+        th = state["theta"]
+        if generator == "hip":                                                  # HIP generator kernels (row f1)
             rx, data = ch.generate_batch_hip(R, N_frame, amps, P, SNRs, h_channel, runs[0].symb_rate, sps, tau_cd, tau_pmd, phiIQ,
-                                             theta, device, hip_seed, frame)
+                                             th, device, hip_seed, frame)
         elif generator == "torch":
-            SNRs = np.array([r.SNR for r in runs], dtype=np.float32)
-            srate = runs[0].symb_rate
-            rx, data = ch.generate_batch_gpu(R, N_frame, amps, P, SNRs, h_channel, srate, sps, tau_cd, tau_pmd, phiIQ, theta,
+            rx, data = ch.generate_batch_gpu(R, N_frame, amps, P, SNRs, h_channel, runs[0].symb_rate, sps, tau_cd, tau_pmd, phiIQ, th,
                                              device, generator=tgen)
         else:
             def host_frame(i):                                  # the reference-faithful numpy channel model, one run
                 r, st = runs[i], streams[i]
                 return ch.generate_data_shaping(N_frame, amps, r.SNR, h_channel, tabs[i]["P"], 2, r.symb_rate, sps, tau_cd, tau_pmd, phiIQ,
-                                                theta[i], "cpu", rng=st.next_rng() if st else None, noise=st.noise if st else None)[:2]
+                                                th[i], "cpu", rng=st.next_rng() if st else None, noise=st.noise if st else None)[:2]
             # seeded runs own their random streams, so they can be generated concurrently (numpy releases the GIL in the FFTs and
             # convolutions); unseeded runs share numpy's global stream like the reference and stay sequential
             if R > 1 and all(st is not None for st in streams):
@@ -167,30 +182,81 @@ def run_dp_batch(runs, mod, sps, M_est, batch_len, N_frame_max, num_frames, flex
                 pairs = [host_frame(i) for i in range(R)]
             rx = torch.stack([p[0] for p in pairs]).to(device, non_blocking=True)
             data = torch.stack([p[1] for p in pairs]).to(device, non_blocking=True)
-        theta = theta + theta_diff                                              # :51
+        state["theta"] = th + theta_diff                                        # :51
         if flex:
             data = data[:, :, :, batch_len // 2:N_out + batch_len // 2]          # func_VAEflex...:51
+        return rx, data
+
+    def train_frame(frame, rx, need_q):
+        # lr schedule: group 0 (W) only, set (not multiplied) to lr/2 (func_VAELE_DP_MQAM_shaping.py:45-46)
+        # -> lr from frame 0, lr/2 from frame N_lrhalf on (every later trigger re-sets the same value)
+        cur_lr_W = lr0_half_t if frame >= N_lrhalf else lr0_t                 # device tensors made once: no H2D copy (a host sync) per frame
         # q itself is only materialised when the caller wants it back (keep_last): the epilogue reads E_q[x_I] and argmax(q), which
         # the training kernel writes directly (5 instead of 32 floats per polarisation symbol through HBM)
-        need_q = keep_last and frame == num_frames - 1
-        out = eng.train(rx, batch_len, steps, cur_lr_W, lr0_t, stride=stride, keep_off=k0, keep_len=klen, want_q=need_q, want_compact=True)
-        q, y = (out["q"][:, 0] if need_q else None), out["y"][:, 0]
+        return eng.train(rx, batch_len, steps, cur_lr_W, lr0_t, stride=stride, keep_off=k0, keep_len=klen, want_q=need_q, want_compact=True)
+
+    def finish_frame(frame, out, data):
         ve = out["var_est"][:, 0]                                               # [R,2,steps]
         Var_est[:, :, frame] = ve.mean(dim=2)                                   # :69
-        res = dp_epilogue_compact(out["eq"][:, 0], out["dec"][:, 0], y, data, amp, nu_sc_t, var, None if flex else batch_len)
+        res = dp_epilogue_compact(out["eq"][:, 0], out["dec"][:, 0], out["y"][:, 0], data, amp, nu_sc_t, var, None if flex else batch_len)
         SER[:, :, frame] = res["SER"]
-        if verbose:
-            loss = out["loss"][:, 0, -1].cpu()
-            snr_est = torch.tensor(pow_mean, dtype=torch.float32) / ve.mean(dim=(1, 2)).cpu()   # :68
-            for i in range(R):
-                tag = f"[run {i}] " if R > 1 else ""
-                print(f"{tag}{frame}", "\t\ttraining: loss = ", loss[i].item(), "\tshift_x = ", res["shift_c"][i, 0].item(),
-                      "\tshift_y = ", res["shift_c"][i, 1].item(), "\tr = ", int(res["r_c"][i]), "\tSNR_est = ",
-                      10 * math.log10(snr_est[i].item()))
-                print("\t\t\t\t\t\t\tSER_x = ", SER[i, 0, frame].item(), "\tSER_y = ", SER[i, 1, frame].item(), "\t(constell. with shaping)")
-                print("\t\t\t\t\t\t\tSER_x = ", SER[i, 2, frame].item(), "\tSER_y = ", SER[i, 3, frame].item(), "\t(soft demapper)")
-        if keep_last and frame == num_frames - 1:
-            last = dict(q=q, y=y, data=data, rx=rx, **res)
+        return res, ve
+
+    # Small batches (fewer runs than the device keeps resident: the script-faithful sweeps, 15 ... 300 runs) leave most of the chip idle
+    # while the training kernel walks its 100 dependent steps per frame: there the three stages of a frame run on three streams -- the
+    # channel model of frame f + 1 and the epilogue of frame f - 1 beside the training launch of frame f.  Same kernels on the same data
+    # in the same per-stream order: results are bit-identical to the serial order (tests/test_processing_gpu.py).  At saturating batch
+    # sizes the trainer owns every SIMD's register file and the stages can only time-slice (measured): serial order.
+    overlap = (generator == "hip" and not verbose and not keep_last and num_frames > 1 and not os.environ.get("VAEQ_SERIAL_FRAMES")
+               and R < max(1, int(_resident_runs(batch_len, sps, M_est, n_lev, threads))))
+    if overlap:
+        main = torch.cuda.current_stream(device)
+        s_gen, s_epi = _side_streams(device)
+        s_gen.wait_stream(main)
+        s_epi.wait_stream(main)                                                 # SER / Var_est / the tables above were made on `main`
+
+        def gen_async(frame):
+            with torch.cuda.stream(s_gen):
+                rx, data = make_frame(frame)
+                ev = torch.cuda.Event()
+                ev.record(s_gen)
+            rx.record_stream(main)                                              # allocated on s_gen, consumed on main / s_epi: the caching
+            data.record_stream(s_epi)                                           # allocator must not hand the blocks out before those are done
+            return rx, data, ev
+        nxt = gen_async(0)
+        for frame in range(num_frames):
+            rx, data, ev = nxt
+            if frame + 1 < num_frames:
+                nxt = gen_async(frame + 1)
+            main.wait_event(ev)
+            out = train_frame(frame, rx, False)
+            ev_t = torch.cuda.Event()
+            ev_t.record(main)
+            for k in ("eq", "dec", "y", "var_est"):
+                out[k].record_stream(s_epi)
+            with torch.cuda.stream(s_epi):
+                s_epi.wait_event(ev_t)
+                finish_frame(frame, out, data)
+        main.wait_stream(s_epi)
+        main.wait_stream(s_gen)
+    else:
+        for frame in range(num_frames):
+            rx, data = make_frame(frame)
+            need_q = keep_last and frame == num_frames - 1
+            out = train_frame(frame, rx, need_q)
+            res, ve = finish_frame(frame, out, data)
+            if verbose:
+                loss = out["loss"][:, 0, -1].cpu()
+                snr_est = torch.tensor(pow_mean, dtype=torch.float32) / ve.mean(dim=(1, 2)).cpu()   # :68
+                for i in range(R):
+                    tag = f"[run {i}] " if R > 1 else ""
+                    print(f"{tag}{frame}", "\t\ttraining: loss = ", loss[i].item(), "\tshift_x = ", res["shift_c"][i, 0].item(),
+                          "\tshift_y = ", res["shift_c"][i, 1].item(), "\tr = ", int(res["r_c"][i]), "\tSNR_est = ",
+                          10 * math.log10(snr_est[i].item()))
+                    print("\t\t\t\t\t\t\tSER_x = ", SER[i, 0, frame].item(), "\tSER_y = ", SER[i, 1, frame].item(), "\t(constell. with shaping)")
+                    print("\t\t\t\t\t\t\tSER_x = ", SER[i, 2, frame].item(), "\tSER_y = ", SER[i, 3, frame].item(), "\t(soft demapper)")
+            if keep_last and frame == num_frames - 1:
+                last = dict(q=out["q"][:, 0] if need_q else None, y=out["y"][:, 0], data=data, rx=rx, **res)
     ret = dict(SER=SER.cpu(), Var_est=Var_est.cpu(), var=torch.tensor(var_np), engine=eng)
     if last is not None:
         ret["last"] = last
