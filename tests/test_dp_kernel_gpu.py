@@ -229,7 +229,7 @@ def test_error_codes():
         eng.train(torch.zeros(1, 1, 2, 2, 400), 100, 1, 1e-3)
 
 
-@pytest.mark.parametrize("B,M,n", [(100, 25, 8), (64, 25, 4), (128, 13, 2), (50, 9, 8), (26, 25, 8), (100, 31, 8), (80, 17, 4), (60, 21, 2),
+@pytest.mark.parametrize("B,M,n", [(20, 25, 8), (14, 25, 4), (24, 25, 8), (10, 9, 8), (8, 13, 2), (16, 31, 4), (100, 25, 8), (64, 25, 4), (128, 13, 2), (50, 9, 8), (26, 25, 8), (100, 31, 8), (80, 17, 4), (60, 21, 2),
                                    (128, 25, 8), (64, 25, 8), (128, 25, 2), (50, 25, 8), (98, 25, 4), (126, 25, 8), (254, 25, 8), (300, 25, 8), (770, 25, 4), (130, 25, 8), (200, 25, 8), (256, 13, 2), (258, 31, 4), (300, 9, 8), (384, 21, 2), (512, 25, 8), (154, 17, 4), (600, 13, 4), (1000, 31, 2), (1024, 25, 8)])
 def test_wave_kernel_equals_generic_kernel(B, M, n):
     """The wave-per-run fast path (threads=1; one wavefront per run up to B = 128, two up to 256, four up to 512, eight up to 1024; M = 25: B = 100 /

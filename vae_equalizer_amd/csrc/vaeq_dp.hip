@@ -420,7 +420,8 @@ static int launch_dp_lev(const vaeq_dp_args &a, size_t lds, hipStream_t st)
 extern "C" int64_t vaeq_dp_lds_bytes(int32_t B, int32_t sps, int32_t M, int32_t n_lev)
 {
     if (B <= 0 || sps <= 0 || M <= 0 || (M & 1) == 0 || M > 63 || !(n_lev == 2 || n_lev == 4 || n_lev == 8)) return VAEQ_ERR_SHAPE;
-    if ((int64_t)B * sps - 2 * (M / 2) <= 0 || B <= 2 * (M / 2)) return VAEQ_ERR_SHAPE;  // needs nm > 0 and a non-empty KL slice
+    if ((int64_t)B * sps - 2 * (M / 2) <= 0) return VAEQ_ERR_SHAPE;  // needs nm > 0 residual samples; the KL slice mh <= n < B - mh may be empty (B <= 2 mh:
+                                                                     // the reference's short batch_len options, Eval_run_DP.py:38 -- torch sums an empty slice to 0, shared_funcs.py:131-132)
     return (int64_t)vaeq::dp_layout(B, sps, M).total * 4;
 }
 

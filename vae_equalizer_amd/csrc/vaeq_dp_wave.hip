@@ -19,7 +19,10 @@ int64_t dp_wave_b128_resident(int n_lev);
 // Whether the wave-per-run kernel covers this call (else the generic kernel runs).
 bool dp_wave_supported(const vaeq_dp_args &a)
 {
-    if (a.sps != 2 || (a.B & 1) || a.B > 1024 || a.B < 2 * (a.M / 2) + 2) return false;
+    // minibatches down to the shortest one with a residual (nm = 2 B - 2 (M / 2) >= 2 samples: the reference's short batch_len options, Eval_run_DP.py:38,
+    // e.g. B = 20 with M = 25 -- the KL slice mh <= n < B - mh is then empty, as in the reference): ten of the 64 lanes own a symbol pair, still
+    // several times the generic kernel's rate (one workgroup of 256 threads and seven barriers per step for 20 symbols)
+    if (a.sps != 2 || (a.B & 1) || a.B > 1024 || 2 * a.B - 2 * (a.M / 2) < 2 || a.B < 4) return false;
     if (!(a.M == 25 || a.M == 31 || a.M == 21 || a.M == 17 || a.M == 13 || a.M == 9)) return false;
     if ((a.S & 3) || ((a.stride_sym * 2) & 3) || (reinterpret_cast<uintptr_t>(a.rx) & 15)) return false;   // 16-byte window loads
     if (a.q_out && (reinterpret_cast<uintptr_t>(a.q_out) & 7)) return false;
