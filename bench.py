@@ -294,6 +294,33 @@ def extra_pipeline(R, t, var, device, frames=4):
                       "back to back"}
 
 
+def extra_pipeline_small(device, runs=300, frames=40):
+    """The script-faithful config-5 grid size (4 nu x 5 SNR x 3 lr x iter 5 = 300 runs, Eval_run_DP.py:24,34,41,44) through run_dp_batch itself -- what
+    Eval_run_DP.main() spends per frame: below the resident-run count the three stages of a frame run on three streams (channel model of frame f + 1
+    and epilogue of frame f - 1 beside the training launch of frame f, bit-identical results); the serial order is timed beside it."""
+    from vae_equalizer_amd.dp_runs import DPRun, run_dp_batch
+    NU, SNR = [0, 0.0270955, 0.0872449, 0.1222578], [20, 22, 24, 26, 28]
+    pts = [DPRun(s, nu, CFG["theta_diff"], CFG["theta"], lr, CFG["symb_rate"]) for nu in NU for lr in CFG["lr_optim_vec"] for s in SNR for _ in range(5)][:runs]
+    out = {"runs": len(pts), "frames": frames}
+    for key, serial in (("ms_per_frame", False), ("ms_per_frame_serial", True)):
+        if serial:
+            os.environ["VAEQ_SERIAL_FRAMES"] = "1"
+        try:
+            run_dp_batch(pts, CFG["mod"], CFG["sps"], CFG["M_est"], CFG["batch_len"], CFG["N_frame_max"], 3, CFG["flex_step"], CFG["channel"], CFG["tau_cd"],
+                         CFG["tau_pmd"], CFG["phiIQ"], 170, device=device)                                     # warm-up: tables, allocator
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_dp_batch(pts, CFG["mod"], CFG["sps"], CFG["M_est"], CFG["batch_len"], CFG["N_frame_max"], frames, CFG["flex_step"], CFG["channel"],
+                         CFG["tau_cd"], CFG["tau_pmd"], CFG["phiIQ"], 170, device=device)
+            torch.cuda.synchronize()
+            out[key] = (time.perf_counter() - t0) / frames * 1e3
+        finally:
+            os.environ.pop("VAEQ_SERIAL_FRAMES", None)
+    out["dp_symbols_per_s"] = len(pts) * CFG["N_frame_max"] / (out["ms_per_frame"] * 1e-3)
+    out["stages"] = "run_dp_batch: vaeq_gen_dp_frame | vaeq_dp_train | vaeq_dp_epilogue_compact on three streams (wall time per frame incl. the host side); serial order beside it"
+    return out
+
+
 def extra_configs(R, t, var, frame_rx, device):
     """Kernel-level rates of BASELINE configs 4 (VAEflex) and 2 (AWGN 64-QAM + PCS) from the same invocation."""
     from vae_equalizer_amd import _native as nat
@@ -563,7 +590,7 @@ def main():
             del out, eng
             torch.cuda.empty_cache()
             res.setdefault("extra", {})["pipeline"] = extra_pipeline(R, t, var, device)
-            res["extra"]["pipeline_small"] = extra_pipeline(300, t, var, device, frames=20)
+            res["extra"]["pipeline_small"] = extra_pipeline_small(device)
             res["extra"]["configs"] = extra_configs(R, t, var, frames[0], device)
         print(json.dumps(res), flush=True)
     if collective:

@@ -17,4 +17,7 @@ grep "R=" $OUT/nn.log
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- python3 /root/repo/tools/probe_awgn.py 8192 30 0 > $OUT/pmc_$c.log 2>&1 || { echo pmc $c failed; tail -5 $OUT/pmc_$c.log; exit 1; }
 done
+# HBM traffic of the bench kernel from the PMC counters -> profiles/pmc_traffic.json (what bench.py quotes as roofline.traffic): regenerated with every
+# round's final build so that it cannot go stale (kernel name and run count are checked by bench.py)
+/root/repo/tools/profile_traffic.sh $(basename $OUT)/traffic && cp $OUT/traffic/pmc_traffic.json $OUT/pmc_traffic.json
 echo done

@@ -52,6 +52,9 @@
 #ifndef VAEQ_PIPE_DU
 #define VAEQ_PIPE_DU 0
 #endif
+#ifndef VAEQ_ROW_STEP
+#define VAEQ_ROW_STEP 1                                // q row offsets as one running scalar (0: products row * No4, A/B knob)
+#endif
 #ifndef VAEQ_WPS
 #define VAEQ_WPS 2                                     // workgroups per SIMD the register budget is sized for (3 would need <= 168 VGPRs: it spills)
 #endif
@@ -368,14 +371,29 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
             const uint32_t col = (uint32_t)(s * klen + (n0 - k0));
             const uint32_t vo0 = kept0 ? col * 4u : OOB, vo1 = kept1 ? col * 4u + 4u : OOB;     // byte offsets inside a row; OOB = not stored
             if (yf) {
+                uint32_t yrow = 0u;                            // rows (o, re / im) in ascending order: a running scalar offset (see qrow below)
+                auto next_row = [&]() {
+#if VAEQ_ROW_STEP
+                    yrow += No4;
+                    asm volatile("" : "+s"(yrow));
+#endif
+                };
 #pragma unroll
                 for (int o = 0; o < 2; o++) {
+#if VAEQ_ROW_STEP
+                    const uint32_t r0 = yrow;
+                    next_row();
+                    const uint32_t r1 = yrow;
+                    next_row();
+#else
+                    const uint32_t r0 = (uint32_t)(o * 2 + 0) * No4, r1 = (uint32_t)(o * 2 + 1) * No4;
+#endif
                     if (pairst) {
-                        bst64(v2f{y[0][o].x, y[1][o].x}, yr, vo0, (uint32_t)(o * 2 + 0) * No4);
-                        bst64(v2f{y[0][o].y, y[1][o].y}, yr, vo0, (uint32_t)(o * 2 + 1) * No4);
+                        bst64(v2f{y[0][o].x, y[1][o].x}, yr, vo0, r0);
+                        bst64(v2f{y[0][o].y, y[1][o].y}, yr, vo0, r1);
                     } else {
-                        bst32(y[0][o].x, yr, vo0, (uint32_t)(o * 2 + 0) * No4); bst32(y[0][o].y, yr, vo0, (uint32_t)(o * 2 + 1) * No4);
-                        bst32(y[1][o].x, yr, vo1, (uint32_t)(o * 2 + 0) * No4); bst32(y[1][o].y, yr, vo1, (uint32_t)(o * 2 + 1) * No4);
+                        bst32(y[0][o].x, yr, vo0, r0); bst32(y[0][o].y, yr, vo0, r1);
+                        bst32(y[1][o].x, yr, vo1, r0); bst32(y[1][o].y, yr, vo1, r1);
                     }
                 }
             }
@@ -383,6 +401,11 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
             VAEQ_STAMP(3);
             // ============ P2: soft demap + moments (registers), mu -> LDS, prefix sums of the variances
             float mv[2][2][2], mt3[2][2][2], mkc[2][2][2];     // [sym][o][c]: Var_q, 3rd central moment, KL-gradient moment
+#if VAEQ_ROW_STEP
+            // the 4 n rows of q leave in ascending order: their byte offset is ONE running scalar (an s_add per row) -- as 32 products row * No4 they
+            // were 32 live scalars, spilled and fetched back with v_readlane + hazard s_nops in front of every store
+            uint32_t qrow = 0u;
+#endif
             float klsum = 0.f, vv[2][2];                       // vv[o][sym] = v_I + v_Q
 #pragma unroll
             for (int o = 0; o < 2; o++) {
@@ -458,9 +481,17 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                     if (qf) {
 #pragma unroll
                         for (int i = 0; i < NLEV; i++) {
+#if VAEQ_ROW_STEP
+                            const uint32_t ro = qrow;
+#else
                             const uint32_t ro = (uint32_t)(o * 2 * NLEV + c * NLEV + i) * No4;
+#endif
                             if (pairst) bst64(q[i], qr, vo0, ro);
                             else { bst32(q[i].x, qr, vo0, ro); bst32(q[i].y, qr, vo1, ro); }
+#if VAEQ_ROW_STEP
+                            qrow += No4;
+                            asm volatile("" : "+s"(qrow));     // keeps it a running value (the optimiser would turn it back into products)
+#endif
                         }
                     }
                 }
