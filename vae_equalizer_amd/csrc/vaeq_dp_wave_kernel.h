@@ -55,6 +55,10 @@
 #ifndef VAEQ_ROW_STEP
 #define VAEQ_ROW_STEP 1                                // q row offsets as one running scalar (0: products row * No4, A/B knob)
 #endif
+#ifndef VAEQ_DEMAP_SHIFT
+#define VAEQ_DEMAP_SHIFT 0                             // 1: softmax shift from the nearest level instead of a maximum search -- 32 instructions fewer per step, but
+                                                       // the fused form spills 7 VGPRs at the 254-register limit: 8.65 vs 8.45 ms (profiles/r03/kernel_variants_ab.txt); off
+#endif
 #ifndef VAEQ_WPS
 #define VAEQ_WPS 2                                     // workgroups per SIMD the register budget is sized for (3 would need <= 168 VGPRs: it spills)
 #endif
@@ -252,6 +256,7 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
     }
     const float var0 = a.var[run * 2 + 0], var1 = a.var[run * 2 + 1];
     const float lrW = a.lr_W[run], lrH = a.lr_h[run];
+    const float lev_delta = amp[NLEV - 1] - amp[NLEV - 2], lev_inv = 1.0f / lev_delta, lev_off = -amp[0] * lev_inv;   // the (equidistant) level grid
 
     // ---- zero the halo'd buffers once; load taps; owner lanes load their Adam moments
     for (int i = gl; i < (lay.W - lay.X) / 8; i += NT) Xs[i] = make_float2(0.f, 0.f);     // X, E, U, PSv
@@ -416,6 +421,26 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                     // both symbols of the lane at once: every add/mul/fma below is one packed instruction (v_pk_*_f32)
                     const v2f yy = c ? v2f{y[0][o].y, y[1][o].y} : v2f{y[0][o].x, y[1][o].x};
                     v2f z[NLEV], q[NLEV];
+                    v2f ssum = {0.f, 0.f};
+#if VAEQ_DEMAP_SHIFT
+                    // softmax shift without a maximum search: the squared distance to the NEAREST level (found by rounding on the equidistant level
+                    // grid) is taken out of every d^2 -- z_i = -c2 (d_i^2 - dmin^2) - b2_i <= 0 for every level and >= -max b2 for the nearest one
+                    // (no overflow, the sum never underflows); it rides in the FMA that squares d: 8 subtractions and 8 maxima per axis gone
+                    v2f dm2;
+                    {
+                        const v2f t = yy * lev_inv + lev_off;  // level index coordinate (y - amp[0]) / delta
+                        const v2f r = {__builtin_amdgcn_fmed3f(__builtin_rintf(t.x), 0.f, (float)(NLEV - 1)), __builtin_amdgcn_fmed3f(__builtin_rintf(t.y), 0.f, (float)(NLEV - 1))};
+                        const v2f dm = (t - r) * lev_delta;
+                        dm2 = dm * dm;
+                    }
+#pragma unroll
+                    for (int i = 0; i < NLEV; i++) {
+                        const v2f d = yy - amp[i];
+                        z[i] = -((d * d - dm2) * c2 + b2[i]);
+                        q[i] = v2f{__builtin_amdgcn_exp2f(z[i].x), __builtin_amdgcn_exp2f(z[i].y)};
+                        ssum += q[i];
+                    }
+#else
                     float zm0 = -3.0e38f, zm1 = -3.0e38f;
 #pragma unroll
                     for (int i = 0; i < NLEV; i++) {
@@ -425,13 +450,13 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                         zm1 = fmaxf(zm1, z[i].y);
                     }
                     const v2f zmax = {zm0, zm1};
-                    v2f ssum = {0.f, 0.f};
 #pragma unroll
                     for (int i = 0; i < NLEV; i++) {
                         z[i] -= zmax;
                         q[i] = v2f{__builtin_amdgcn_exp2f(z[i].x), __builtin_amdgcn_exp2f(z[i].y)};
                         ssum += q[i];
                     }
+#endif
                     const v2f rs = {__builtin_amdgcn_rcpf(ssum.x), __builtin_amdgcn_rcpf(ssum.y)};
                     v2f m1 = {0.f, 0.f};
 #pragma unroll

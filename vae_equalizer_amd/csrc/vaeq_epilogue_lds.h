@@ -382,7 +382,10 @@ __global__ __launch_bounds__(EPI_NT, 3) void dp_epilogue_compact_kernel(int N, i
     // walk<R>(load, comp): every group g = tid, tid + 256, ... with a kept member, in that order, EPI_U groups per round: first the loads of all
     // EPI_U groups (load(tag, n0, kp, R&), tag = true_type for interior groups), then their arithmetic (comp(n0, kp, R)) -- a walk is bound by
     // the HBM round trip per round (2-3 us under load), so what counts is how many loads a wave has in flight per round trip
-    constexpr int EPI_U = 2;
+#ifndef VAEQ_EPI_U
+#define VAEQ_EPI_U 2
+#endif
+    constexpr int EPI_U = VAEQ_EPI_U;
     auto walk = [&](int s0, int ms, auto rtag, auto load, auto comp) {
         using R = decltype(rtag);
         KeepWalk4 kw(4 * tid, N, batch_len, s0, ms);

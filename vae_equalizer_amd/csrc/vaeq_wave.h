@@ -4,6 +4,10 @@
 #include <stdint.h>
 #include <type_traits>
 
+#ifndef VAEQ_SUM_BCAST
+#define VAEQ_SUM_BCAST 1                               // wave sums finish on two DPP broadcasts + one v_readlane (0: four v_readlane + three adds; A/B knob)
+#endif
+
 namespace vaeq {
 
 // One wave per workgroup: LDS instructions of a wave execute in issue order, so a later ds_read of any lane sees an earlier
@@ -185,6 +189,13 @@ __device__ __forceinline__ float wave_sum_dpp(float v)    // sum over the 64 lan
     v += dpp_f<0x4E>(v);                                   // quad_perm:[2,3,0,1]
     v += dpp_f<0x141>(v);                                  // row_half_mirror
     v += dpp_f<0x140>(v);                                  // row_mirror: every lane of a 16-lane row holds the row's sum
+#if VAEQ_SUM_BCAST
+    // the four row sums r0..r3 meet in lane 63 as (r3 + r2) + (r1 + r0) -- the same additions as below (IEEE addition commutes: bitwise the same
+    // result) with two DPP broadcasts and ONE v_readlane instead of four v_readlane and three adds
+    v += dpp_f<0x142, 0xA>(v);                             // row_bcast:15 into rows 1 and 3: r1 + r0, r3 + r2
+    v += dpp_f<0x143, 0xC>(v);                             // row_bcast:31 into rows 2 and 3: lane 63 = (r3 + r2) + (r1 + r0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#endif
     const int b = __builtin_bit_cast(int, v);
     const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
     const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
