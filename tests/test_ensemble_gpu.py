@@ -34,13 +34,19 @@ TAU_PMD = 0.1e-12 * np.sqrt(1000)
 M, B, SPS, LR, N_LRHALF = 25, 100, 2, 2.5e-3, 170
 
 
-def run_ensemble(K, nu, SNR, F, N, theta_diff, seed):
-    """K runs x F frames x N symbols: (SER[K,4,F], Var_est[K,2,F]) of the HIP path and of the oracle on the same frames."""
+def run_ensemble(K, nu, SNR, F, N, theta_diff, seed, flex_step=None):
+    """K runs x F frames x N symbols: (SER[K,4,F], Var_est[K,2,F]) of the HIP path and of the oracle on the same frames.
+    flex_step: VAEflex (func_VAEflex_DP_MQAM_shaping.py:37-84: windows of B symbols advancing by flex_step, the centre flex_step outputs kept)."""
     t = sfun.qam_tables("64-QAM", nu)
     h_ch = sfun.upsampled_channel("h0", SPS)
     amps, P, nu_sc = t["amps"], t["P"], float(t["nu_sc"])
     var = float(t["pow_mean"] / 10 ** (SNR / 10) / 2)
-    n, steps = len(amps), N // B
+    n = len(amps)
+    if flex_step:
+        N_out = (N - B) // flex_step * flex_step
+        steps, stride, k0, klen, bl = N_out // flex_step, flex_step, (B - flex_step) // 2, flex_step, None
+    else:
+        N_out, steps, stride, k0, klen, bl = N, N // B, B, 0, B, B
     amp32 = amps.astype(np.float32)
     # product side
     eng = DPEngine(K, M, amps, P, [var, var], nu_sc, DEV, SPS)
@@ -52,7 +58,7 @@ def run_ensemble(K, nu, SNR, F, N, theta_diff, seed):
     h[:, 0, 0, 0, M // 2] = h[:, 1, 1, 0, M // 2] = 1
     mW, vW, mh, vh, step = np.zeros_like(W), np.zeros_like(W), np.zeros_like(h), np.zeros_like(h), np.zeros(K, np.int32)
     Pk, vark, nuk = np.tile(P.astype(np.float32), (K, 1)), np.full((K, 2), var, np.float32), np.full(K, nu_sc, np.float32)
-    q, y = np.zeros((K, 2, 2 * n, N), np.float32), np.zeros((K, 2, 2, N), np.float32)
+    q, y = np.zeros((K, 2, 2 * n, N_out), np.float32), np.zeros((K, 2, 2, N_out), np.float32)
     loss, ve = np.zeros((K, steps), np.float32), np.zeros((K, 2, steps), np.float32)
     cores = host_threads()
     pool = ThreadPoolExecutor(cores)
@@ -61,15 +67,17 @@ def run_ensemble(K, nu, SNR, F, N, theta_diff, seed):
     for f in range(F):
         lr_W = LR * 0.5 if f >= N_LRHALF else LR                                # group 0 only (func_VAELE_DP_MQAM_shaping.py:45-46)
         rx, data = ch.generate_batch_hip(K, N, amps, P, SNR, h_ch, 90e9, SPS, -26e-24, TAU_PMD, PHI, np.pi / 10 + f * theta_diff, DEV, seed, f)
-        out = eng.train(rx, B, steps, lr_W, LR, want_q=False, want_compact=True)
-        res = dp_epilogue_compact(out["eq"][:, 0], out["dec"][:, 0], out["y"][:, 0], data, amp_t, nu_t, var_t, B)
+        if flex_step:
+            data = data[:, :, :, B // 2:N_out + B // 2].contiguous()             # func_VAEflex_DP_MQAM_shaping.py:51
+        out = eng.train(rx, B, steps, lr_W, LR, stride=stride, keep_off=k0, keep_len=klen, want_q=False, want_compact=True)
+        res = dp_epilogue_compact(out["eq"][:, 0], out["dec"][:, 0], out["y"][:, 0], data, amp_t, nu_t, var_t, bl)
         SER[0, :, :, f] = res["SER"].cpu().numpy()
         VE[0, :, :, f] = out["var_est"][:, 0].mean(dim=2).cpu().numpy()        # :69
         rx_h, data_h = np.ascontiguousarray(rx.cpu().numpy()), data.cpu().numpy()
         lrw, lrh = np.full(K, lr_W, np.float32), np.full(K, LR, np.float32)
-        oracle.dp_train_batch_f32(K, cores, steps, B, SPS, M, n, B, 0, B, rx_h, W, h, mW, vW, mh, vh, step, amp32, Pk, vark, nuk, lrw, lrh, q, y, loss, ve)
+        oracle.dp_train_batch_f32(K, cores, steps, B, SPS, M, n, stride, k0, klen, rx_h, W, h, mW, vW, mh, vh, step, amp32, Pk, vark, nuk, lrw, lrh, q, y, loss, ve)
         VE[1, :, :, f] = ve.mean(axis=2)
-        sers = list(pool.map(lambda i: oracle.dp_frame_epilogue(q[i], y[i], data_h[i], amp32, nu_sc, vark[i], B)["SER"], range(K)))
+        sers = list(pool.map(lambda i: oracle.dp_frame_epilogue(q[i], y[i], data_h[i], amp32, nu_sc, vark[i], bl)["SER"], range(K)))
         SER[1, :, :, f] = np.stack(sers)
     pool.shutdown()
     return SER, VE, var
@@ -115,11 +123,16 @@ def mc_agree(a, b, nsig=3.0, floor=0.0):
     return d, nsig * se + floor
 
 
-@pytest.mark.parametrize("case", ["pcs_G10", "vaele_G7"])
+@pytest.mark.parametrize("case", ["pcs_G10", "vaele_G7", "flex_G9"])
 def test_locking_runs_ensemble_vs_oracle(case):
     """Light shaping / uniform 64-QAM at 23 dB: every run locks.  G10 = config 5's PCS shape (200 frames x 3000 symbols, nu = 0.0270955), G7 = the
-    VAE-LE trajectory capture (140 frames x 1000 symbols, nu = 0)."""
-    if case == "pcs_G10":
+    VAE-LE trajectory capture (140 frames x 1000 symbols, nu = 0), G9 = config 4, VAEflex (70 frames x 2000 symbols = 13 300 window steps per run)."""
+    flex_step = None
+    if case == "flex_G9":
+        g = load_golden("G9_flex_run")
+        nu, F, N, td, ref_SER, ref_VE, K = 0.0, int(g["num_frames"]), int(g["N_frame_max"]), float(g["theta_diff"]), g["SER"], g["Var_est"], 32
+        min_locked, flex_step = 0.9, 10
+    elif case == "pcs_G10":
         g = load_golden("G10_pcs_run")
         nu, F, N, td, ref_SER, ref_VE, K = float(g["nu"]), int(g["num_frames"]), int(g["N_frame_max"]), float(g["theta_diff"]), g["SER"], g["Var_est"], 48
         min_locked = 0.9                                                        # 200 frames: (nearly) every run has locked by the end
@@ -127,11 +140,13 @@ def test_locking_runs_ensemble_vs_oracle(case):
         g = load_golden("G7_runs")
         nu, F, N, td, ref_SER, ref_VE, K = 0.0, int(g["vaele_num_frames"]), int(g["vaele_N_frame_max"]), float(g["vaele_theta_diff"]), g["vaele_SER"], g["vaele_Var_est"], 64
         min_locked = 0.6          # the capture ends at frame 140, inside the escape distribution (oracle: 108 .. beyond 140, the reference's run: 118): censored at F
-    SER, VE, var = run_ensemble(K, nu, 23.0, F, N, td, seed=20260 + len(case))
+    SER, VE, var = run_ensemble(K, nu, 23.0, F, N, td, seed=20260 + len(case), flex_step=flex_step)
     hip, orc = SER[0], SER[1]
-    # (a) same frames, before chaos: frame 0 run by run (N / 100 steps from the Dirac start)
-    assert np.max(np.abs(VE[0][:, :, 0] - VE[1][:, :, 0]) / VE[1][:, :, 0]) < 2e-3
-    assert np.max(np.abs(hip[:, :, 0] - orc[:, :, 0])) < 0.02
+    # (a) same frames, before chaos: frame 0 run by run (N / 100 steps from the Dirac start; a VAEflex frame is already 190 window steps, past the
+    #     horizon of run-by-run agreement: there the frame's mean noise estimate within 5 %)
+    tol_ve, tol_ser = (5e-2, 0.05) if flex_step else (2e-3, 0.02)
+    assert np.max(np.abs(VE[0][:, :, 0] - VE[1][:, :, 0]) / VE[1][:, :, 0]) < tol_ve
+    assert np.max(np.abs(hip[:, :, 0] - orc[:, :, 0])) < tol_ser
     # (b) escape frames: same distribution
     eh, eo = escape_frames(hip), escape_frames(orc)
     ks = stats.ks_2samp(eh, eo)
