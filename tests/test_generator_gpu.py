@@ -111,6 +111,7 @@ def test_hip_generator_padded_fft_differs_only_at_the_frame_edges():
     assert np.max(np.abs(e - p)[..., 64:-64]) < 1e-3 * scale                   # interior: equal up to the tails of the response
     assert np.max(np.abs(e - p)) < 0.5 * scale                                 # edges: wrapped-around vs. absent neighbours
     assert ch.fast_fft_len(20034 + 64) == 20480 and ch.fast_fft_len(1024) == 1024 and ch.fast_fft_len(1025) == 1280
+    assert ch.padded_row_len(20034 + 64) == 20480 and ch.padded_row_len(2098) == 4096 and ch.padded_row_len(6098) == 8192 and ch.padded_row_len(40098) == 40960
 
 
 @pytest.mark.parametrize("n1", [4, 5, 8, 10, 16, 20])
@@ -122,7 +123,7 @@ def test_fused_frame_matches_staged_chain(n1, monkeypatch):
     h_est, h_ch, P, amp_levels, amps, pol, nu_sc, var, pow_mean = sfun.init("h1", "64-QAM", "cpu", 0.0270955, sps, 25, 23)
     N = (1024 * n1 - 64 - ch.dp_frame_geometry(100, h_ch, sps)["Ls"] + 200) // 2       # the longest frame whose padded row is N1 * 1024
     geo = ch.dp_frame_geometry(N, h_ch, sps)
-    assert ch.fast_fft_len(geo["Ls"] + 64) == 1024 * n1 and geo["Ls"] + 64 >= 1024 * n1 - 1
+    assert ch.padded_row_len(geo["Ls"] + 64) == 1024 * n1 and geo["Ls"] + 64 >= 1024 * n1 - 1
     Pr = np.stack([P if r % 2 == 0 else np.full_like(P, 1 / len(P)) for r in range(R)])
     theta = np.linspace(-1.2, 2.9, R)
     SNR = np.linspace(14.0, 30.0, R).astype(np.float32)
@@ -153,7 +154,7 @@ def test_fused_frame_long_pulse_and_last_stripe_ownership():
     h_long = np.concatenate([np.asarray(h_ch), 0.05 * np.exp(1j * np.arange(50))]).astype(np.complex64)
     N = (1024 * 4 - 64 - ch.dp_frame_geometry(100, h_long, sps)["Ls"] + 200) // 2
     geo = ch.dp_frame_geometry(N, h_long, sps)
-    assert geo["Lg"] > 64 and ch.fast_fft_len(geo["Ls"] + 64) == 4096
+    assert geo["Lg"] > 64 and ch.padded_row_len(geo["Ls"] + 64) == 4096
     args = (R, N, amps, P, 21.0, h_long, DP["symb_rate"], sps, DP["tau_cd"], DP["tau_pmd"], DP["phiIQ"], np.array([0.1, 0.5, 2.0]), "cuda:0", seed, frame)
     os.environ.pop("VAEQ_GEN_STAGED", None)
     rxf, df = ch.generate_batch_hip(*args)

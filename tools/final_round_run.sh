@@ -1,5 +1,5 @@
 cd /root/repo
-python -m pytest tests -m gpu -x -q > gpurun_out/r03_gputests.log 2>&1; echo rc=$? >> gpurun_out/r03_gputests.log; tail -4 gpurun_out/r03_gputests.log
+rm -f gpurun_out/r03_ensemble_parity.txt; VAEQ_ENSEMBLE_LOG=gpurun_out/r03_ensemble_parity.txt python -m pytest tests -m gpu -x -q > gpurun_out/r03_gputests.log 2>&1; echo rc=$? >> gpurun_out/r03_gputests.log; tail -4 gpurun_out/r03_gputests.log
 python bench.py > gpurun_out/r03_bench_line.json 2> gpurun_out/r03_bench.err; tail -c 600 gpurun_out/r03_bench_line.json
 python bench.py --config5 --no-cpu-baseline > gpurun_out/r03_bench_config5_line.json 2>> gpurun_out/r03_bench.err; tail -c 300 gpurun_out/r03_bench_config5_line.json
 python bench.py --config5 --iter 5 --no-cpu-baseline > gpurun_out/r03_bench_config5_iter5_line.json 2>> gpurun_out/r03_bench.err

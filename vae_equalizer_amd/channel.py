@@ -288,6 +288,19 @@ STREAM_BLOCK = 8192   # runs per vaeq_gen_dp_frame call.  Part of the DEFINITION
                       # depend on how much workspace a caller wants to spend (8192 runs = a 2.7 GB workspace for the default frame)
 
 
+FUSED_ROWS = (4096, 5120, 8192, 10240, 16384, 20480)   # N1 * 1024, N1 in {4, 5, 8, 10, 16, 20}: the rows vaeq_gen_dp_frame transforms itself
+
+
+def padded_row_len(n):
+    """Row length of the "padded" DP frame: the smallest row the library's own three-pass form covers (FUSED_ROWS) when there is one -- for
+    frames up to ~10 000 symbols no hipFFT plan is ever created (3.6 s on a process's first call) and no five-pass chain runs, at the price of a
+    longer transform for lengths between the supported ones (N = 3000: 8192 instead of 6144) --, else the next {1,3,5} * 2^a length (hipFFT)."""
+    for L in FUSED_ROWS:
+        if L >= n:
+            return L
+    return fast_fft_len(n)
+
+
 def generate_batch_hip(R, N, amps, P, SNR, h_channel, symb_rate, sps, tau_cd, tau_pmd, phiIQ, theta, device, seed, frame,
                        return_sigma=False, fft="padded"):
     """The DP channel model for R runs on the device: one vaeq_gen_dp_frame call per STREAM_BLOCK runs (the padded default frame takes the
@@ -295,8 +308,8 @@ def generate_batch_hip(R, N, amps, P, SNR, h_channel, symb_rate, sps, tau_cd, ta
 
     fft: "exact"  -- dispersion applied on the FFT of the exact sequence length Ls like the reference (circular filtering; Ls = 20034 =
                      2*3^3*7*53 for the default frame costs hipFFT 4x the time of a 20480-point transform);
-         "padded" -- rows zero-padded to the next {1,3,5} * 2^a length >= Ls + 64 (linear filtering): the dispersion's impulse response
-                     spans a few samples, so only samples that close to the frame edges differ from "exact".
+         "padded" -- rows zero-padded to padded_row_len(Ls + 64) (linear filtering; the library's own split-FFT rows wherever one fits): the
+                     dispersion's impulse response spans a few samples, so only samples that close to the frame edges differ from "exact".
     Deterministic in (seed, frame, run): counter-based Philox streams.  Returns (rx[R,2,2,sps*N] f32, data[R,2,2,N] f16[, sigma_n[R]])."""
     import ctypes as C
 
@@ -317,7 +330,7 @@ def generate_batch_hip(R, N, amps, P, SNR, h_channel, symb_rate, sps, tau_cd, ta
     st = nat.current_stream(dev)
     if fft not in ("exact", "padded"):
         raise ValueError(f"fft must be 'exact' or 'padded', got {fft!r}")
-    Lrow = geo["Ls"] if fft == "exact" else fast_fft_len(geo["Ls"] + 64)
+    Lrow = geo["Ls"] if fft == "exact" else padded_row_len(geo["Ls"] + 64)
     with torch.cuda.device(dev):
         for r0 in range(0, R, STREAM_BLOCK):
             r1 = min(R, r0 + STREAM_BLOCK)
