@@ -222,3 +222,26 @@ def test_stream_seeds_differ_across_ranks_batches_and_unseeded_invocations():
     s = {sweep.stream_seed(5, r, b) for r in range(8) for b in range(4)}
     assert len(s) == 32 and sweep.stream_seed(5, 1, 2) == sweep.stream_seed(5, 1, 2)
     assert sweep.stream_seed(None, 0, 0) != sweep.stream_seed(None, 0, 0)
+
+
+def test_default_generator_follows_the_seed():
+    """generator=None (the default of every entry point): unseeded runs -- the reference seeds nothing (shared_funcs.py:75,84) -- take the on-device channel
+    simulator, seeded runs the reference-faithful host simulator; an explicit choice is never overridden.  The sweep scripts ship with generator = None."""
+    from vae_equalizer_amd import Eval_run_DP, Eval_run_shaping_vaele
+    from vae_equalizer_amd.dp_runs import resolve_generator
+    assert resolve_generator(None, False) == "hip" and resolve_generator(None, True) == "numpy"
+    assert resolve_generator("numpy", False) == "numpy" and resolve_generator("hip", True) == "hip" and resolve_generator("torch", False) == "torch"
+    assert Eval_run_DP.generator is None and Eval_run_DP.base_seed is None and Eval_run_shaping_vaele.generator is None
+    import inspect
+    from vae_equalizer_amd import func_VAELE_DP_MQAM_shaping as f1, func_VAEflex_DP_MQAM_shaping as f2, func_VAELE_MQAM_shaping as f3
+    for f in (f1, f2, f3):
+        assert inspect.signature(f.processing).parameters["generator"].default is None
+
+
+def test_padded_rows_prefer_the_librarys_own_fft_lengths():
+    """channel.padded_row_len: the smallest N1 x 1024 row the three-pass generator covers (N1 in {4, 5, 8, 10, 16, 20}) whenever one fits -- frames up to
+    ~10 200 symbols never need a hipFFT plan --, else the next {1, 3, 5} x 2^a length."""
+    from vae_equalizer_amd import channel as ch
+    assert [ch.padded_row_len(n) for n in (1, 2098, 4096, 4097, 6098, 10098, 12098, 16385, 20098, 20480)] == [4096, 4096, 4096, 5120, 8192, 10240, 16384, 20480, 20480, 20480]
+    assert ch.padded_row_len(20481) == ch.fast_fft_len(20481) == 24576 and ch.padded_row_len(40098) == 40960
+    assert ch.STREAM_BLOCK == 8192 and "chunk" not in ch.generate_batch_hip.__code__.co_varnames[:ch.generate_batch_hip.__code__.co_argcount]

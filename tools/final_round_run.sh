@@ -7,3 +7,5 @@ tools/profile_round.sh r03prof > gpurun_out/r03_profile_round.log 2>&1; tail -8 
 tools/profile_pmc.sh dp 8192 /root/repo/gpurun_out/r03prof/pmc_dp > gpurun_out/r03_pmc_dp.log 2>&1; tail -6 gpurun_out/r03_pmc_dp.log
 python tools/probe_small_sweep.py 60 > gpurun_out/r03_small_sweep.txt 2>&1; cat gpurun_out/r03_small_sweep.txt
 python tools/probe_pipeline.py 8192 compact > gpurun_out/r03_pipeline_probe.txt 2>&1; cat gpurun_out/r03_pipeline_probe.txt
+tools/profile_pmc.sh awgn 8192 /root/repo/gpurun_out/r03prof/pmc_awgn > gpurun_out/r03_pmc_awgn.log 2>&1; tail -3 gpurun_out/r03_pmc_awgn.log
+tools/profile_pmc_nn.sh 2048 /root/repo/gpurun_out/r03prof/pmc_nn > gpurun_out/r03_pmc_nn.log 2>&1; tail -4 gpurun_out/r03_pmc_nn.log
