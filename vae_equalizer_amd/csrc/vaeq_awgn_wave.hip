@@ -119,11 +119,39 @@ __device__ __forceinline__ void wave_fir(cacc (&acc)[NR][2], const float2 *(&xp)
 // (one polarisation), i.e. one LDS read per packed FMA and 4 x the loop trips.  NG groups x PARTS parts <= 64 NW threads; trip counts are uniform
 // (a scalar loop), terms past the end of a part's range are masked.  The partial sums go through LDS (XP); the tap's owner lane adds its
 // PARTS partials in a fixed order: bitwise reproducible.
-template <int M, int NW> struct TapBlocks {
+//
+// Bank conflicts (tools/lds_bank_model.py restates the loops' addresses): a part starts `trips` symbol pairs after the previous one, and with
+// lane = group * parts + part both 32-lane halves of a wave hold parts whose operand windows alias the same banks -- at M = 25, B = 350
+// (7 groups x 9 parts x 19 / 20 trips) the 7 + 8 operand reads of a trip take 26 + 36 half-wave passes instead of 14 + 16: that is the kernel's
+// 33 % LDS conflict rate.  CF ("conflict-free", -DVAEQ_AWGN_CF=1; B = 350 baked only): 8 parts, parts 0..3 in the first half-wave and 4..7 in the
+// second, 23 (dL/dh) / 24 (dL/dw) trips per part -- strides of 46 / 48 dwords put the four 14-dword windows of a half-wave on disjoint banks --
+// and dL/dy stored planar (even / odd symbols): every read one pass per half-wave, 42 % fewer LDS passes, 21 % more trips.  MEASURED SLOWER
+// (2.78 vs 2.66 ms per 8192 runs x 30 steps, three alternations on one box, profiles/r03/awgn_conflict_free_blocks_ab.txt): the two phases are
+// bound by their packed FMAs, not by LDS -- the conflicts hide behind the arithmetic, the extra trips do not.  Off.
+#ifndef VAEQ_AWGN_CF
+#define VAEQ_AWGN_CF 0
+#endif
+template <int M, int NW, int BL = 0> struct TapBlocks {
     static constexpr int mh = M / 2;
+    static constexpr bool CF = VAEQ_AWGN_CF && M == 25 && NW == 1 && BL == 350;
     static constexpr int NG0 = (mh + 1 + 3) / 4, NG1 = (mh + 3) / 4;     // dL/dh: groups of even taps (a = 0..mh) / odd taps (a = 0..mh-1)
-    static constexpr int NGH = NG0 + NG1, PH = 64 * NW / NGH;            // parts per group (all NW waves of the run take part)
-    static constexpr int NGW = (M + 3) / 4, PW = 64 * NW / NGW;          // dL/dw: groups of 4 consecutive taps
+    static constexpr int NGH = NG0 + NG1, PH = CF ? 8 : 64 * NW / NGH;   // parts per group (all NW waves of the run take part)
+    static constexpr int NGW = (M + 3) / 4, PW = CF ? 8 : 64 * NW / NGW; // dL/dw: groups of 4 consecutive taps
+    static constexpr int NITH = 23, NITW = 24;                           // CF: trips per part
+    // thread -> (group, part); lanes without a block shadow a working lane of their own half-wave (same address: a broadcast, no extra pass)
+    static __device__ __forceinline__ void map(int gl, int NG, int P, int &grp, int &prt, bool &gv)
+    {
+        if constexpr (CF) {
+            const int hw = gl >> 5, li = gl & 31, pp = li / NG;
+            gv = pp < 4;
+            grp = gv ? li - pp * NG : 0;
+            prt = 4 * hw + (gv ? pp : 0);
+        } else {
+            grp = gl / P; prt = gl - grp * P;
+            gv = grp < NG;
+            if (!gv) grp = 0;
+        }
+    }
 };
 
 __device__ __forceinline__ void amsgrad_fast(float &p, float &m, float &v, float &vmax, float g, float step_size, float rbc2s)
@@ -478,11 +506,12 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
         {
             float2 acc;
             {
-                using TB = TapBlocks<M, NW>;
-                const int grp = gl / TB::PH, prt = gl - grp * TB::PH;
-                const bool gv = grp < TB::NGH;                             // lanes beyond NGH * PH idle (they shadow group 0)
-                const int g = gv ? grp : 0, par = g >= TB::NG0 ? 1 : 0, a0 = 4 * (par ? g - TB::NG0 : g);
-                const int T = nm >> 1, Tm = (T + 1) >> 1, nit = (Tm + TB::PH - 1) / TB::PH;   // terms per tap (nm is even: both parities alike), tau pairs, pairs per part
+                using TB = TapBlocks<M, NW, BL>;
+                int g, prt;
+                bool gv;                                                   // lanes without a block idle (they shadow group 0)
+                TB::map(gl, TB::NGH, TB::PH, g, prt, gv);
+                const int par = g >= TB::NG0 ? 1 : 0, a0 = 4 * (par ? g - TB::NG0 : g);
+                const int T = nm >> 1, Tm = (T + 1) >> 1, nit = TB::CF ? TB::NITH : (Tm + TB::PH - 1) / TB::PH;   // terms per tap (nm is even: both parities alike), tau pairs, pairs per part
                 const int m0 = prt * nit;
                 const int ceA = par + Mh, ceB = par + Mh + 2, n0 = mh - a0 - 3;                            // U window of the 4 taps: n0 + 2m + (0..4)
                 const float2 *eA = Es + (ceA & 3) * Lph + (ceA >> 2) + m0, *eB = Es + (ceB & 3) * Lph + (ceB >> 2) + m0;
@@ -571,8 +600,13 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
 #pragma unroll
         for (int r = 0; r < NR; r++)
             if (act[r]) {
-                GY[2 * (l0 + 64 * r)] = gy[r][0];
-                GY[2 * (l0 + 64 * r) + 1] = gy[r][1];
+                if constexpr (TapBlocks<M, NW, BL>::CF) {             // planar: even symbols | odd symbols (Uph >= B / 2 apart)
+                    GY[l0 + 64 * r] = gy[r][0];
+                    GY[Uph + l0 + 64 * r] = gy[r][1];
+                } else {
+                    GY[2 * (l0 + 64 * r)] = gy[r][0];
+                    GY[2 * (l0 + 64 * r) + 1] = gy[r][1];
+                }
             }
         if (hown && !a.no_update) Ht[tk] = make_float2(p0, p1);
         sync_lds<NW>();
@@ -582,18 +616,21 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
         {
             float2 acc;
             {
-                using TB = TapBlocks<M, NW>;
-                const int grp = gl / TB::PW, prt = gl - grp * TB::PW;
-                const bool gv = grp < TB::NGW;
-                const int k0 = 4 * (gv ? grp : 0);                         // taps k0 .. k0 + 3: x[4m + k0 + (0..5)] for the symbol pair (2m, 2m+1)
-                const int Bp = B >> 1, nit = (Bp + TB::PW - 1) / TB::PW, m0 = prt * nit;
+                using TB = TapBlocks<M, NW, BL>;
+                int grp, prt;
+                bool gv;
+                TB::map(gl, TB::NGW, TB::PW, grp, prt, gv);
+                const int k0 = 4 * grp;                                    // taps k0 .. k0 + 3: x[4m + k0 + (0..5)] for the symbol pair (2m, 2m+1)
+                const int Bp = B >> 1, nit = TB::CF ? TB::NITW : (Bp + TB::PW - 1) / TB::PW, m0 = prt * nit;
+                const float2 *gya = TB::CF ? GY + m0 : GY + 2 * m0, *gyb = TB::CF ? GY + Uph + m0 : GY + 2 * m0 + 1;
+                constexpr int gst = TB::CF ? 1 : 2;
                 const float2 *xw = Xs + (k0 >> 2) + m0;                    // sample c = 4m + k0 + j sits at [(j & 3) Lph + m + (k0 >> 2) + (j >> 2)]
                 cacc c4[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) c4[i] = cacc0();
 #pragma unroll 1
                 for (int m = 0; m < nit; m++) {                // uniform trip count: a scalar loop
-                    v2f g0_ = lds2(GY + 2 * (m0 + m)), g1_ = lds2(GY + 2 * (m0 + m) + 1);                  // gy[2m], gy[2m+1]
+                    v2f g0_ = lds2(gya + gst * m), g1_ = lds2(gyb + gst * m);                              // gy[2m], gy[2m+1]
                     const v2f x0 = lds2(xw + m), x1 = lds2(xw + Lph + m), x2 = lds2(xw + 2 * Lph + m), x3 = lds2(xw + 3 * Lph + m);
                     const v2f x4 = lds2(xw + m + 1), x5 = lds2(xw + Lph + m + 1);
                     if (m0 + m >= Bp) { g0_ = v2f{0.f, 0.f}; g1_ = v2f{0.f, 0.f}; }
