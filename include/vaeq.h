@@ -337,6 +337,21 @@ int vaeq_awgn_validate(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_l
                        const float *amp, const float *amp_mean, const float *var, const void *data_f16, float *y_ws, float *ser,
                        int32_t *shift, void *stream);
 
+/* The validation frame of an epoch without its round trip through HBM (func_VAELE_MQAM_shaping.py:310 generate_data followed by :311-318): the
+ * reference draws N_valid = 15 000 fresh symbols per evaluated epoch, 12.5 x what it trains on, and reads them once.
+ * vaeq_gen_awgn_clean = vaeq_gen_awgn's first stage alone (sps == 2 only): the noise-free channel output sig[R][Ls] (complex64), the power sums
+ * power_ws[R][ceil(Ls / 2048)] of its tiles and the TX reference data_f16[R][2][N].
+ * vaeq_awgn_validate_gen = vaeq_awgn_validate on x = sig + noise, the noise added where a tile is staged: the Philox words, sigma_n (from
+ * power_ws and snr_db, or sigma_fixed) and the arithmetic of vaeq_gen_awgn -- ser / shift / y_ws are bit for bit what vaeq_gen_awgn followed by
+ * vaeq_awgn_validate return for the same (seed, frame) (sps == 2, M in {9, 17, 25}; VAEQ_ERR_SHAPE otherwise); sigma_out[R] nullable. */
+int vaeq_gen_awgn_clean(int32_t R, int32_t N, int32_t N_conv, int32_t sps, int32_t n_lev, int32_t Lg, int32_t Ls, int32_t ref_offset,
+                        const float *amp, const float *cdf, const float *g_complex, uint64_t seed, uint32_t frame, float *sig,
+                        float *power_ws, void *data_f16, void *stream);
+int vaeq_awgn_validate_gen(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, int32_t n_shift, const float *sig, int32_t Ls,
+                           const float *power_ws, const float *snr_db, const float *sigma_fixed, uint64_t seed, uint32_t frame,
+                           const float *W, const float *amp, const float *amp_mean, const float *var, const void *data_f16, float *y_ws,
+                           float *ser, int32_t *shift, float *sigma_out, void *stream);
+
 /* ------------------------------------------------------------------------
  * the constant-modulus baselines of the DP scripts and their carrier phase estimation.
  * vaeq_cma: CMA (shared_funcs.py:341-383, mode 0) / CMAbatch (:385-433, mode 1 with symb_step = batchlen) / CMAflex (:435-488,

@@ -216,3 +216,57 @@ def test_awgn_operator_mirrors_against_golden():
         h0 = torch.from_numpy(g["theta0"][-2 * M:].reshape(2, M)).to(DEV)
         loss = nn_.loss_function(torch.from_numpy(g["q0"]).to(DEV), x, h0, DEV, torch.from_numpy(g["amp_levels"]).to(DEV))
         assert abs(float(loss) - g["loss"][0]) / abs(g["loss"][0]) < 1e-5
+
+
+# ------------------------------------------------------------------ validation on a clean frame, noise added while it is read (vaeq_awgn_validate_gen)
+@pytest.mark.parametrize("mod,M,N,fixed", [("64-QAM", 25, 15000, False), ("16-QAM", 17, 4001, False), ("4-QAM", 9, 2050, True), ("64-QAM", 25, 1022, False)])
+def test_awgn_validate_on_clean_frame_equals_generate_then_validate(mod, M, N, fixed):
+    """vaeq_gen_awgn_clean + vaeq_awgn_validate_gen == vaeq_gen_awgn + vaeq_awgn_validate for the same (seed, frame), BIT FOR BIT: the same
+    symbols and TX reference, the same noise level, the same noisy samples (y is the equaliser's output on them), hence the same shift and SER.
+    Frame lengths that are no multiple of the 1024-symbol tile or of four samples, power-derived and fixed noise levels, per-run SNRs."""
+    from vae_equalizer_amd import channel as ch
+    from vae_equalizer_amd.engine import AWGNEngine
+    from vae_equalizer_amd.func_VAELE_MQAM_shaping import awgn_tables
+    sps, R = 2, 6
+    t = awgn_tables(mod, 0.02 if mod == "64-QAM" else 0.0, 22, "h1", sps)
+    snr = np.array([14, 18, 22, 26, 30, 22], np.float32)
+    sf = (0.05 + 0.01 * np.arange(R)).astype(np.float32) if fixed else None
+    eng = AWGNEngine(R, M, t["amps"], np.tile(t["P"], (R, 1)), t["amp_mean"], t["var"], DEV, sps)
+    rx0, _ = ch.generate_awgn_batch_hip(R, 4200, t["amps"], t["P"], snr, t["h_channel"], sps, DEV, 91, 0)
+    for _ in range(25):                                                       # some training so that the equaliser is no Dirac
+        eng.train(rx0, 350, 12, 5e-3)
+    for frame in (1, 7):
+        rx, data, sigma = ch.generate_awgn_batch_hip(R, N, t["amps"], t["P"], snr, t["h_channel"], sps, DEV, 91, frame, return_sigma=True, sigma_fixed=sf)
+        ser_a, sh_a, y_a = eng.validate(rx, data, 21)
+        clean = ch.generate_awgn_clean_batch_hip(R, N, t["amps"], t["P"], snr, t["h_channel"], sps, DEV, 91, frame, sigma_fixed=sf)
+        ser_b, sh_b, y_b, sigma_b = eng.validate_clean(clean, 21, return_sigma=True)
+        torch.cuda.synchronize()
+        assert torch.equal(clean.data, data)
+        assert torch.equal(sigma_b, sigma)
+        assert torch.equal(y_b, y_a)
+        assert torch.equal(sh_b, sh_a) and torch.equal(ser_b, ser_a)
+        # and the clean frame is what the noisy one was made from: their difference is noise of the requested level
+        c = clean.sig[:, :sps * N].cpu().numpy().astype(np.float64)
+        nz = rx.cpu().numpy().astype(np.float64) - np.stack([c[..., 0], c[..., 1]], 1)
+        s = sigma.cpu().numpy()
+        assert np.all(np.abs(nz.std(axis=2) / s[:, None] - 1) < 0.06), (nz.std(axis=2), s)
+    assert float(ser_a.min()) < 0.2                                           # the comparison is not between two garbage outputs
+
+
+def test_awgn_sweep_uses_the_clean_validation_frame_and_matches_the_two_step_form(monkeypatch):
+    """run_awgn_batch with the device generator validates on a clean frame (noise added on load); forcing the two-step form gives the same
+    SER_valid bit for bit (same seed: same Philox draws in both forms)."""
+    from vae_equalizer_amd import channel as ch
+    from vae_equalizer_amd.func_VAELE_MQAM_shaping import run_awgn_batch
+    runs = [dict(SNR=s, nu=0.0270955, lr_optim=lr) for s in (20, 24) for lr in (3e-3, 5e-3)]
+    kw = dict(mod="64-QAM", sps=2, M_est=25, batch_len=350, N_valid=3000, N_train=1200, num_epochs=8, epe=2, channel="h1", device=DEV,
+              generator="hip", seed=1234)
+    calls = {"n": 0}
+    orig = ch.generate_awgn_clean_batch_hip
+    monkeypatch.setattr(ch, "generate_awgn_clean_batch_hip", lambda *a, **k: (calls.__setitem__("n", calls["n"] + 1), orig(*a, **k))[1])
+    a = run_awgn_batch(runs, **kw)
+    assert calls["n"] == 4
+    monkeypatch.setattr(ch, "awgn_clean_supported", lambda sps, M: False)
+    b = run_awgn_batch(runs, **kw)
+    assert calls["n"] == 4 and torch.equal(a, b)
+

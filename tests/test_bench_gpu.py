@@ -48,6 +48,7 @@ def test_bench_line_contract():
     assert c2["kernel"].startswith("vaeq::awgn_wave_kernel<25, 8, 3, 1, 350>") and c2["value"] > 0 and 0 < c2["flop_frac"] < 1
     ep = c2["epoch_pipeline"]
     assert ep["ms_train_part"] > 0 and ep["ms_validation_part"] > ep["ms_train_part"] and ep["run_epochs_per_s_epe2"] > 0
+    assert ep["validation_forms_agree_bitwise"] and ep["ms_validation_part"] < ep["ms_validation_part_two_step"]   # noise on load: same SER, no noisy frame in HBM
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "2170" in cb["sample"] and cb["reference_dp_symbols_per_s"] == 2170.0
 

@@ -29,5 +29,10 @@ tg2, (rxv, dv) = timed(lambda: ch.generate_awgn_batch_hip(R, 15000, t["amps"], t
 tt, _ = timed(lambda: eng.train(rx, 350, 3, 5e-3))
 tv, _ = timed(lambda: eng.validate(rxv, dv, 21))
 tf, _ = timed(lambda: eng.forward(rxv))
+del rxv, dv
+tc, clean = timed(lambda: ch.generate_awgn_clean_batch_hip(R, 15000, t["amps"], t["P"], snr, t["h_channel"], sps, dev, 1, 1))
+tvc, _ = timed(lambda: eng.validate_clean(clean, 21))
 print(f"R={R}: gen(1200) {tg1:.3f} ms  gen(15000) {tg2:.3f} ms  train(3x350) {tt:.3f} ms  validate(15000, fused) {tv:.3f} ms  "
       f"[forward with q: {tf:.3f} ms]  epoch total {tg1 + tg2 + tt + tv:.3f} ms -> {R / (tg1 + tg2 + tt + tv) * 1e3:.0f} run-epochs/s", flush=True)
+print(f"R={R}: validation frame clean + noise on load: gen_clean(15000) {tc:.3f} ms  validate_gen {tvc:.3f} ms = {tc + tvc:.3f} ms "
+      f"(two-step: {tg2 + tv:.3f} ms)  epoch total {tg1 + tt + tc + tvc:.3f} ms", flush=True)

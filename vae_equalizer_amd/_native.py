@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("VAEQ_LIB") or os.path.join(_PKG, "libvaeq_hip.so")   # VAEQ_LIB: A/B builds of the kernels (tools/build_variant.sh)
 SOURCES = ["vaeq_dp.hip", "vaeq_dp_wave.hip", "vaeq_dp_wave_mw.hip", "vaeq_dp_wave_mw8.hip", "vaeq_dp_wave_bk.hip", "vaeq_dp_wave_b128.hip", "vaeq_dp_wave_fl.hip", "vaeq_awgn.hip", "vaeq_awgn_wave.hip", "vaeq_misc.hip", "vaeq_nn.hip", "vaeq_cma.hip", "vaeq_epilogue.hip", "vaeq_gen.hip"]
-HEADERS = ["vaeq_common.h", "vaeq_wave.h", "vaeq_validate.h", "vaeq_dp_wave_kernel.h", "vaeq_gen_fused.h", "vaeq_epilogue_lds.h"]
+HEADERS = ["vaeq_common.h", "vaeq_wave.h", "vaeq_validate.h", "vaeq_dp_wave_kernel.h", "vaeq_gen_fused.h", "vaeq_epilogue_lds.h", "vaeq_noise.h"]
 _LIB = None
 
 
@@ -104,7 +104,7 @@ class NNArgs(C.Structure):
 
 # every symbol include/vaeq.h declares; tests check the library exports all of them
 EXPORTS = ["vaeq_dp_train", "vaeq_dp_step_debug", "vaeq_dp_lds_bytes", "vaeq_dp_resident_runs", "vaeq_soft_demap", "vaeq_dp_forward", "vaeq_dp_loss", "vaeq_dp_loss_bwd", "vaeq_dp_forward_bwd", "vaeq_dp_epilogue", "vaeq_dp_epilogue_ws_bytes", "vaeq_dp_epilogue_compact", "vaeq_gen_dp_tx", "vaeq_gen_dp_disperse", "vaeq_gen_dp_finish", "vaeq_gen_dp_frame", "vaeq_awgn_train",
-           "vaeq_awgn_lds_bytes", "vaeq_awgn_forward", "vaeq_awgn_validate", "vaeq_awgn_loss", "vaeq_awgn_loss_bwd", "vaeq_awgn_forward_bwd", "vaeq_gen_awgn", "vaeq_nn_train", "vaeq_nn_param_count", "vaeq_nn_lds_bytes", "vaeq_nn_forward", "vaeq_nn_validate", "vaeq_cma", "vaeq_cpe", "vaeq_version", "vaeq_strerror", "vaeq_last_kernel", "vaeq_stream_copy", "vaeq_gen_dp_power_parts", "vaeq_cma_epilogue"]
+           "vaeq_awgn_lds_bytes", "vaeq_awgn_forward", "vaeq_awgn_validate", "vaeq_awgn_validate_gen", "vaeq_gen_awgn_clean", "vaeq_awgn_loss", "vaeq_awgn_loss_bwd", "vaeq_awgn_forward_bwd", "vaeq_gen_awgn", "vaeq_nn_train", "vaeq_nn_param_count", "vaeq_nn_lds_bytes", "vaeq_nn_forward", "vaeq_nn_validate", "vaeq_cma", "vaeq_cpe", "vaeq_version", "vaeq_strerror", "vaeq_last_kernel", "vaeq_stream_copy", "vaeq_gen_dp_power_parts", "vaeq_cma_epilogue"]
 
 
 def lib():
@@ -188,6 +188,11 @@ def lib():
                                         + [C.c_void_p] * 6)
         L.vaeq_awgn_validate.restype = C.c_int
         L.vaeq_awgn_validate.argtypes = [C.c_int32, C.c_int64] + [C.c_int32] * 4 + [C.c_void_p] * 10
+        L.vaeq_gen_awgn_clean.restype = C.c_int
+        L.vaeq_gen_awgn_clean.argtypes = [C.c_int32] * 8 + [C.c_void_p] * 3 + [C.c_uint64, C.c_uint32] + [C.c_void_p] * 4
+        L.vaeq_awgn_validate_gen.restype = C.c_int
+        L.vaeq_awgn_validate_gen.argtypes = ([C.c_int32, C.c_int64] + [C.c_int32] * 4 + [C.c_void_p, C.c_int32] + [C.c_void_p] * 3 +
+                                             [C.c_uint64, C.c_uint32] + [C.c_void_p] * 10)
         L.vaeq_gen_awgn.restype = C.c_int
         L.vaeq_gen_awgn.argtypes = [C.c_int32] * 8 + [C.c_void_p] * 4 + [C.c_uint64, C.c_uint32] + [C.c_void_p] * 7
         _LIB = L

@@ -393,6 +393,49 @@ def generate_awgn_batch_hip(R, N, amps, P, SNR, h_channel, sps, device, seed, fr
     return (rx, data, sigma) if return_sigma else (rx, data)
 
 
+class CleanAwgnFrame:
+    """A frame of generate_awgn_clean_batch_hip: the noise-free channel output and what the consumer needs to add vaeq_gen_awgn's noise to it
+    while reading (engine.AWGNEngine.validate_clean)."""
+    __slots__ = ("sig", "power", "data", "snr", "sigma_fixed", "seed", "frame", "R", "N", "sps", "Ls")
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+def awgn_clean_supported(sps, M_est):
+    """Shapes for which the validation pass can add the noise itself (vaeq_awgn_validate_gen: sps == 2, baked tap counts)."""
+    return sps == 2 and M_est in (9, 17, 25)
+
+
+def generate_awgn_clean_batch_hip(R, N, amps, P, SNR, h_channel, sps, device, seed, frame, sigma_fixed=None):
+    """generate_awgn_batch_hip without its last stage (vaeq_gen_awgn_clean, sps == 2): symbols, pulse shaping and channel once; the noise of
+    the same (seed, frame) is added by the kernel that reads the frame.  The reference's validation frame (func_VAELE_MQAM_shaping.py:310,
+    N_valid = 15 000 fresh symbols per evaluated epoch) is read exactly once, so it never needs to exist in its noisy form."""
+    import ctypes as C
+
+    from . import _native as nat
+    if sps != 2:
+        raise ValueError("the clean-frame form of the AWGN generator exists for sps == 2 only")
+    dev = torch.device(device)
+    geo = awgn_frame_geometry(N, h_channel, sps)
+    n = len(amps)
+    amp_t = _dev_const(amps, torch.float32, dev)
+    cdf = _cdf_dev(P, R, n, dev)
+    g_t = _dev_const(np.stack([geo["g"].real, geo["g"].imag], -1), torch.float32, dev)
+    snr = _dev_const(np.broadcast_to(np.asarray(SNR, np.float32), (R,)), torch.float32, dev)
+    sig = torch.empty(R, geo["Ls"], 2, dtype=torch.float32, device=dev)
+    data = torch.empty(R, 2, N, dtype=torch.float16, device=dev)
+    pw = torch.empty(R, (geo["Ls"] + 2047) // 2048, dtype=torch.float32, device=dev)
+    key = _mix_seed(seed, 0)
+    with torch.cuda.device(dev):
+        nat.check(nat.lib().vaeq_gen_awgn_clean(R, N, geo["N_conv"], sps, n, geo["Lg"], geo["Ls"], geo["ref_offset"], nat.ptr(amp_t), nat.ptr(cdf),
+                                                nat.ptr(g_t), C.c_uint64(key), C.c_uint32(frame), nat.ptr(sig), nat.ptr(pw),
+                                                nat.ptr(data, torch.float16), nat.current_stream(dev)), "vaeq_gen_awgn_clean")
+    sf = None if sigma_fixed is None else _dev_const(np.broadcast_to(np.asarray(sigma_fixed, np.float32), (R,)), torch.float32, dev)
+    return CleanAwgnFrame(sig=sig, power=pw, data=data, snr=snr, sigma_fixed=sf, seed=key, frame=int(frame), R=R, N=N, sps=sps, Ls=geo["Ls"])
+
+
 def _mix_seed(seed, r0):
     """Key of the Philox streams of the chunk that starts at run r0 (runs inside a chunk are told apart by the run counter word)."""
     return (int(seed) * 0x9E3779B97F4A7C15 + int(r0) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF

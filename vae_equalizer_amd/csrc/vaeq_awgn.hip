@@ -17,6 +17,7 @@
 
 #include "vaeq.h"
 #include "vaeq_common.h"
+#include "vaeq_noise.h"
 #include "vaeq_wave.h"
 #include "vaeq_validate.h"
 
@@ -332,13 +333,26 @@ __global__ __launch_bounds__(256) void awgn_forward_kernel(int64_t N, int sps, i
 //   find_shift (:188-204): E_q[x_I] of the first 1000 symbols against the TX I (else Q) row over n_shift circular lags
 //   SER_q (:97-123) on q[:, 11+sh : -11] vs data[:, 11 : -11-sh], minimum over the four quadrant rotations
 // MT > 0: tap count baked in, four symbols per thread from one register window (sps == 2).
+// GEN (MT > 0 only): x is not read but made -- the clean frame of vaeq_gen_awgn_clean plus the noise vaeq_gen_awgn would have added (vaeq_noise.h:
+// same Philox words, same sigma_n, same fused multiply-adds), four samples = two noise words per staged chunk.  The 15 000-symbol validation frame
+// of an epoch is then written once (clean) and read once instead of computed twice, written noisy and read (vaeq_awgn_validate_gen).
+struct ValGen {
+    const float2 *sig;           // [R][Ls] clean samples
+    const float *part;           // [R][n_parts] tile power sums
+    const float *snr_db;         // [R]
+    const float *sigma_fixed;    // nullable [R]
+    float *sigma_out;            // nullable [R]
+    uint64_t seed;
+    uint32_t frame;
+    int Ls, n_parts;
+};
 
-template <int NLEV, int MT>
+template <int NLEV, int MT, bool GEN = false>
 __global__ __launch_bounds__(256, 4) void awgn_validate_kernel(int N, int sps, int Mrt, int n_shift, const float *__restrict__ x,
                                                             const float *__restrict__ W, const float *__restrict__ amp_g,
                                                             const float *__restrict__ amp_mean, const float *__restrict__ var,
                                                             const __half *__restrict__ data, float *__restrict__ yws, float *__restrict__ ser_out,
-                                                            int *__restrict__ shift_out)
+                                                            int *__restrict__ shift_out, ValGen vg)
 {
     extern __shared__ unsigned char decs[];            // [N] level decisions, I in the low and Q in the high nibble
     __shared__ float Ws[2 * 64];
@@ -352,9 +366,16 @@ __global__ __launch_bounds__(256, 4) void awgn_validate_kernel(int N, int sps, i
     __syncthreads();
     const int64_t L = (int64_t)N * sps;
     const int pad = (M - 1) / 2;
-    const float *x0 = x + (size_t)run * 2 * L, *x1 = x0 + L;
+    const float *x0 = GEN ? nullptr : x + (size_t)run * 2 * L, *x1 = GEN ? nullptr : x0 + L;
     float *y0 = yws + (size_t)run * 2 * N, *y1 = y0 + N;
     float sa0 = 0.f, sa1 = 0.f;
+    float sigma = 0.f;
+    const float2 *cs = nullptr;
+    if (GEN) {
+        sigma = vg.sigma_fixed ? vg.sigma_fixed[run] : awgn_sigma_from_parts(vg.part + (size_t)run * vg.n_parts, vg.n_parts, vg.Ls, sps, vg.snr_db[run]);
+        if (vg.sigma_out && tid == 0) vg.sigma_out[run] = sigma;
+        cs = vg.sig + (size_t)run * vg.Ls;
+    }
     if (MT) {
         // Tiles of 1024 symbols staged in LDS as (I, Q) pairs, 8-way polyphase (sample c -> [c & 7][c >> 3]): thread g computes the
         // four symbols 4g..4g+3 of the tile from one window of MT + 6 samples; for a fixed window position all lanes read the same
@@ -369,7 +390,27 @@ __global__ __launch_bounds__(256, 4) void awgn_validate_kernel(int N, int sps, i
             for (int v = tid; v < NCH; v += 256) {
                 const int64_t s4 = sb + 4 * v;
                 float a4[4], b4[4];
-                if (s4 >= 0 && s4 + 3 < L) {                                   // one 16-byte load per row (any 4-byte alignment)
+                if (GEN) {                                                     // s4 is even: the chunk = noise words s4 / 2 and s4 / 2 + 1
+                    float2 c[4];
+                    if (s4 >= 0 && s4 + 3 < L) {
+                        const f4u ua = *reinterpret_cast<const f4u *>(cs + s4), ub = *reinterpret_cast<const f4u *>(cs + s4 + 2);
+                        c[0] = make_float2(ua.x, ua.y); c[1] = make_float2(ua.z, ua.w);
+                        c[2] = make_float2(ub.x, ub.y); c[3] = make_float2(ub.z, ub.w);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) c[i] = (s4 + i >= 0 && s4 + i < L) ? cs[s4 + i] : make_float2(0.f, 0.f);
+                    }
+                    if (s4 + 3 >= 0 && s4 < L) {
+                        awgn_noise_pair((uint32_t)(s4 >> 1), run, vg.frame, 0, vg.seed, sigma, c[0], c[1]);
+                        awgn_noise_pair((uint32_t)(s4 >> 1) + 1u, run, vg.frame, 0, vg.seed, sigma, c[2], c[3]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const bool ok = s4 + i >= 0 && s4 + i < L;             // outside the frame: the equalizer's zero padding, not noise
+                        a4[i] = ok ? c[i].x : 0.f;
+                        b4[i] = ok ? c[i].y : 0.f;
+                    }
+                } else if (s4 >= 0 && s4 + 3 < L) {                            // one 16-byte load per row (any 4-byte alignment)
                     const f4u ua = *reinterpret_cast<const f4u *>(x0 + s4), ub = *reinterpret_cast<const f4u *>(x1 + s4);
                     a4[0] = ua.x; a4[1] = ua.y; a4[2] = ua.z; a4[3] = ua.w;
                     b4[0] = ub.x; b4[1] = ub.y; b4[2] = ub.z; b4[3] = ub.w;
@@ -506,22 +547,23 @@ __global__ __launch_bounds__(256, 4) void awgn_validate_kernel(int N, int sps, i
     validate_tail<256, NLEV>(N, n_shift, decs, E, NE, data + (size_t)run * 2 * N, red, corr, &sh_s, ser_out + run, shift_out ? shift_out + run : nullptr);
 }
 
-template <int NLEV>
+template <int NLEV, bool GEN = false>
 static int launch_validate(int R, int N, int sps, int M, int n_shift, const float *x, const float *W, const float *amp, const float *amp_mean,
-                           const float *var, const __half *data, float *yws, float *ser, int *shift, hipStream_t st)
+                           const float *var, const __half *data, float *yws, float *ser, int *shift, hipStream_t st, const ValGen &vg = ValGen{})
 {
     const size_t lds = ((size_t)N + 15) & ~(size_t)15;
 #define VAEQ_VAL(MM)                                                                                                         \
     {                                                                                                                        \
-        auto k = awgn_validate_kernel<NLEV, MM>;                                                                             \
+        auto k = awgn_validate_kernel<NLEV, MM, GEN && (MM > 0)>;                                                            \
         if (lds > 32 * 1024 &&                                                                                               \
             hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
             return VAEQ_ERR_LDS;                                                                                             \
-        hipLaunchKernelGGL(k, dim3(R), dim3(256), lds, st, N, sps, M, n_shift, x, W, amp, amp_mean, var, data, yws, ser, shift); \
+        hipLaunchKernelGGL(k, dim3(R), dim3(256), lds, st, N, sps, M, n_shift, x, W, amp, amp_mean, var, data, yws, ser, shift, vg); \
     }
     if (sps == 2 && M == 25) VAEQ_VAL(25)
     else if (sps == 2 && M == 17) VAEQ_VAL(17)
     else if (sps == 2 && M == 9) VAEQ_VAL(9)
+    else if (GEN) return VAEQ_ERR_SHAPE;                       // the noise-on-load form exists for the baked tap counts only
     else VAEQ_VAL(0)
 #undef VAEQ_VAL
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
@@ -855,6 +897,27 @@ extern "C" int vaeq_awgn_validate(int32_t R, int64_t N, int32_t sps, int32_t M, 
     case 2: return vaeq::launch_validate<2>(R, (int)N, sps, M, n_shift, x, W, amp, amp_mean, var, d, y_ws, ser, shift, st);
     case 4: return vaeq::launch_validate<4>(R, (int)N, sps, M, n_shift, x, W, amp, amp_mean, var, d, y_ws, ser, shift, st);
     case 8: return vaeq::launch_validate<8>(R, (int)N, sps, M, n_shift, x, W, amp, amp_mean, var, d, y_ws, ser, shift, st);
+    }
+    return VAEQ_ERR_SHAPE;
+}
+
+// vaeq_awgn_validate on x = clean frame + noise made while staging (include/vaeq.h)
+extern "C" int vaeq_awgn_validate_gen(int32_t R, int64_t N, int32_t sps, int32_t M, int32_t n_lev, int32_t n_shift, const float *sig, int32_t Ls,
+                                      const float *power_ws, const float *snr_db, const float *sigma_fixed, uint64_t seed, uint32_t frame,
+                                      const float *W, const float *amp, const float *amp_mean, const float *var, const void *data_f16,
+                                      float *y_ws, float *ser, int32_t *shift, float *sigma_out, void *stream)
+{
+    if (R == 0) return VAEQ_OK;
+    if (!sig || !power_ws || (!snr_db && !sigma_fixed) || !W || !amp || !amp_mean || !var || !data_f16 || !y_ws || !ser) return VAEQ_ERR_NULL;
+    if (R < 0 || sps != 2 || (M != 9 && M != 17 && M != 25) || n_shift <= 0 || n_shift > vaeq::VAL_MAXSHIFT) return VAEQ_ERR_SHAPE;
+    if (N < 64 || N > 65536 || Ls < sps * N) return VAEQ_ERR_SHAPE;      // the clean frame holds at least the sps * N samples vaeq_gen_awgn keeps
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const __half *d = reinterpret_cast<const __half *>(data_f16);
+    vaeq::ValGen vg{reinterpret_cast<const float2 *>(sig), power_ws, snr_db, sigma_fixed, sigma_out, seed, frame, Ls, (Ls + 2047) / 2048};
+    switch (n_lev) {
+    case 2: return vaeq::launch_validate<2, true>(R, (int)N, sps, M, n_shift, nullptr, W, amp, amp_mean, var, d, y_ws, ser, shift, st, vg);
+    case 4: return vaeq::launch_validate<4, true>(R, (int)N, sps, M, n_shift, nullptr, W, amp, amp_mean, var, d, y_ws, ser, shift, st, vg);
+    case 8: return vaeq::launch_validate<8, true>(R, (int)N, sps, M, n_shift, nullptr, W, amp, amp_mean, var, d, y_ws, ser, shift, st, vg);
     }
     return VAEQ_ERR_SHAPE;
 }

@@ -26,27 +26,10 @@
 
 #include "vaeq.h"
 #include "vaeq_common.h"
+#include "vaeq_noise.h"
 #include "vaeq_wave.h"
 
 namespace vaeq {
-
-struct Philox4 { uint32_t x, y, z, w; };
-
-__host__ __device__ inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
-{
-    for (int r = 0; r < 10; r++) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    return Philox4{c0, c1, c2, c3};
-}
-
-__host__ __device__ inline float u01(uint32_t x) { return ((x >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0,1), 24 bits
-
-enum { STREAM_SYMBOLS = 0, STREAM_NOISE = 1 };
 
 // level indices of symbols n (even) and n + 1 of (run, pol): one Philox call, inverse CDF of the PCS pmf on u ~ U(0,1)
 __device__ __forceinline__ void draw_symbol_pair(uint64_t seed, uint32_t frame, uint32_t run, int pol, uint32_t n_even, const float *cdf,
@@ -74,6 +57,8 @@ constexpr int TX_TILE = 2048, TX_NT = 256, TX_MAXG = 96, TX_SYMPH = (TX_TILE / 2
 //         Single-polarisation path without any sig round trip through HBM:
 // MODE 1: only the tile's sum |sig|^2 -> part[run][tile] (fixed-order block reduction);
 // MODE 2: sigma from the tile sums (or sigma_fixed), noise added in registers (same Philox words as gen_finish_kernel), planar rx out.
+// MODE 3: MODE 1 + the clean samples out as sig[run][s] (complex64, s < Ls) and the TX reference: the frame of vaeq_gen_awgn_clean, whose noise is
+//         added where the samples are read (vaeq_awgn_validate_gen) -- symbols drawn and FIR computed once, the noisy frame never written.
 struct TxFuse {
     float *part;                 // [R][n_tiles]
     const float *snr_db;         // [R]
@@ -146,7 +131,8 @@ __device__ __forceinline__ void tx_tile_fir(TxShared &sh, int s0, bool last, int
         }
     }
 }
-// AWGN: sample pairs (sb + 2u, sb + 2u + 1) of one tile + noise -> planar rx (noise word j = sample / 2: the same Philox words as gen_finish_kernel)
+// AWGN: sample pairs (sb + 2u, sb + 2u + 1) of one tile + noise -> planar rx (noise word j = sample / 2: the same Philox words as gen_finish_kernel;
+// the arithmetic of one word lives in awgn_noise_pair, vaeq_noise.h, shared with the validation kernel that adds the noise on load)
 __device__ __forceinline__ void tx_noise_store(const cacc (&acc)[8], int sb, float sigma, int run, int pol, uint64_t seed, uint32_t frame, int Lout,
                                                float *__restrict__ rI, float *__restrict__ rQ)
 {
@@ -154,17 +140,13 @@ __device__ __forceinline__ void tx_noise_store(const cacc (&acc)[8], int sb, flo
     for (int u = 0; u < 4; u++) {
         const int i0 = sb + 2 * u;
         if (i0 >= Lout) break;
-        const Philox4 r = philox4x32_10((uint32_t)(i0 >> 1), run, frame, (uint32_t)(STREAM_NOISE * 2 + pol), (uint32_t)seed, (uint32_t)(seed >> 32));
-        float sn0, cs0, sn1, cs1;
-        const float rad0 = sigma * sqrtf(-2.0f * __logf(u01(r.x))), rad1 = sigma * sqrtf(-2.0f * __logf(u01(r.z)));
-        __sincosf(6.283185307179586f * u01(r.y), &sn0, &cs0);
-        __sincosf(6.283185307179586f * u01(r.w), &sn1, &cs1);
-        const float2 v0 = cfin(acc[2 * u]), v1 = cfin(acc[2 * u + 1]);
-        rI[i0] = v0.x + rad0 * cs0;
-        rQ[i0] = v0.y + rad0 * sn0;
+        float2 v0 = cfin(acc[2 * u]), v1 = cfin(acc[2 * u + 1]);
+        awgn_noise_pair((uint32_t)(i0 >> 1), run, frame, pol, seed, sigma, v0, v1);
+        rI[i0] = v0.x;
+        rQ[i0] = v0.y;
         if (i0 + 1 < Lout) {
-            rI[i0 + 1] = v1.x + rad1 * cs1;
-            rQ[i0 + 1] = v1.y + rad1 * sn1;
+            rI[i0 + 1] = v1.x;
+            rQ[i0 + 1] = v1.y;
         }
     }
 }
@@ -207,7 +189,7 @@ __global__ __launch_bounds__(TX_NT) void gen_tx_kernel(int N_conv, int n_lev, in
         }
         return;
     }
-    if (MODE == 1) {
+    if (MODE == 1 || MODE == 3) {
         float pw = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -216,14 +198,24 @@ __global__ __launch_bounds__(TX_NT) void gen_tx_kernel(int N_conv, int n_lev, in
         }
         block_reduce3<TX_NT>(pw, 0.f, 0.f, red);
         if (tid == 0) fz.part[(size_t)run * gridDim.x + blockIdx.x] = red[0];
+        if (MODE == 3) {                                       // clean samples out, through LDS like MODE 0 (rows of consecutive 8-byte words)
+            __shared__ float2 outs3[TX_NT * 9];
+#pragma unroll
+            for (int i = 0; i < 8; i++) outs3[9 * tid + i] = cfin(acc[i]);
+            __syncthreads();
+            float2 *o = sig + (size_t)run * Lrow + s0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int k = j * TX_NT + tid;
+                if (s0 + k < Ls) o[k] = outs3[9 * (k >> 3) + (k & 7)];
+            }
+        }
         return;
     }
     float sigma;                                               // MODE 2
     if (fz.sigma_fixed) sigma = fz.sigma_fixed[run];
     else {
-        float pw = 0.f;
-        for (unsigned t = 0; t < gridDim.x; t++) pw += fz.part[(size_t)run * gridDim.x + t];      // fixed order
-        sigma = sqrtf(pw / (float)Ls * (float)fz.sps * 0.5f / exp10f(fz.snr_db[run] * 0.1f));
+        sigma = awgn_sigma_from_parts(fz.part + (size_t)run * gridDim.x, (int)gridDim.x, Ls, fz.sps, fz.snr_db[run]);
     }
     if (fz.sigma_out && blockIdx.x == 0 && tid == 0) fz.sigma_out[run] = sigma;
     float *rI = fz.rx + (size_t)run * 2 * fz.Lout, *rQ = rI + fz.Lout;
@@ -506,6 +498,24 @@ extern "C" int vaeq_gen_awgn(int32_t R, int32_t N, int32_t N_conv, int32_t sps, 
     vaeq::launch_tx(R, 1, N, N_conv, sps, n_lev, Lg, Ls, Ls, ref_offset, amp, cdf, reinterpret_cast<const float2 *>(g_complex), seed, frame, sig,
                     reinterpret_cast<__half *>(data_f16), st);
     vaeq::launch_finish(R, 1, N, sps, Ls, Ls, snr_db, seed, frame, sig, power_ws, rx, sigma_out, st, sigma_fixed);
+    return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+}
+
+// First stage of vaeq_gen_awgn alone: clean samples, tile power sums, TX reference (include/vaeq.h; consumed by vaeq_awgn_validate_gen)
+extern "C" int vaeq_gen_awgn_clean(int32_t R, int32_t N, int32_t N_conv, int32_t sps, int32_t n_lev, int32_t Lg, int32_t Ls, int32_t ref_offset,
+                                   const float *amp, const float *cdf, const float *g_complex, uint64_t seed, uint32_t frame, float *sig_out,
+                                   float *power_ws, void *data_f16, void *stream)
+{
+    if (R == 0) return VAEQ_OK;
+    if (!amp || !cdf || !g_complex || !sig_out || !power_ws) return VAEQ_ERR_NULL;
+    if (sps != 2 || !tx_shape_ok(R, N, N_conv, sps, n_lev, Lg, Ls, Ls, ref_offset)) return VAEQ_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((Ls + vaeq::TX_TILE - 1) / vaeq::TX_TILE, 1, R);
+    vaeq::TxFuse fz{};
+    fz.part = power_ws;
+    hipLaunchKernelGGL(vaeq::gen_tx_kernel<3>, grid, dim3(vaeq::TX_NT), 0, st, N_conv, n_lev, Lg, Ls, Ls, amp, cdf,
+                       reinterpret_cast<const float2 *>(g_complex), seed, frame, 1, reinterpret_cast<float2 *>(sig_out), N, ref_offset,
+                       reinterpret_cast<__half *>(data_f16), fz);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
 

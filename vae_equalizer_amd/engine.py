@@ -258,6 +258,27 @@ class AWGNEngine:
                                                    nat.current_stream(self.device)), "vaeq_awgn_validate")
         return ser, shift, y
 
+    def validate_clean(self, frame, n_shift=21, return_sigma=False):
+        """validate() on a channel.CleanAwgnFrame: the noise of the frame's (seed, frame index) is added while the samples are staged
+        (vaeq_awgn_validate_gen) -- bit for bit validate(*generate_awgn_batch_hip(...)) without the noisy frame's round trip through HBM."""
+        import ctypes as C
+        R, N = frame.R, frame.N
+        if R != self.R or frame.sps != self.sps:
+            raise ValueError(f"frame of {R} runs at {frame.sps} sps for an engine of {self.R} runs at {self.sps} sps")
+        ser = torch.empty(R, dtype=torch.float32, device=self.device)
+        shift = torch.empty(R, dtype=torch.int32, device=self.device)
+        y = torch.empty(R, 2, N, dtype=torch.float32, device=self.device)
+        sigma = torch.empty(R, dtype=torch.float32, device=self.device) if return_sigma else None
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().vaeq_awgn_validate_gen(R, N, self.sps, self.M, self.n_lev, int(n_shift), nat.ptr(frame.sig), frame.Ls,
+                                                       nat.ptr(frame.power), nat.ptr(frame.snr),
+                                                       None if frame.sigma_fixed is None else nat.ptr(frame.sigma_fixed),
+                                                       C.c_uint64(frame.seed), C.c_uint32(frame.frame), nat.ptr(self.W), nat.ptr(self.amp),
+                                                       nat.ptr(self.amp_mean), nat.ptr(self.var), nat.ptr(frame.data, torch.float16), nat.ptr(y),
+                                                       nat.ptr(ser), nat.ptr(shift, torch.int32), None if sigma is None else nat.ptr(sigma),
+                                                       nat.current_stream(self.device)), "vaeq_awgn_validate_gen")
+        return (ser, shift, y, sigma) if return_sigma else (ser, shift, y)
+
 
 class NNEngine:
     """R independent AWGN VAE-NN runs (AWGN_channel/func_VAENN_MQAM.py): flat per-run parameter vectors

@@ -149,8 +149,13 @@ def run_awgn_batch(runs, mod, sps, M_est, batch_len, N_valid, N_train, num_epoch
         rx, _ = draw(N_train)
         out = eng.train(rx, batch_len, steps, lr)
         if epoch % epe == 0 and epoch // epe < n_eval:                           # :308-318
-            rxv, datav = draw(N_valid)
-            ser, sh, _ = eng.validate(rxv, datav, 21)
+            if generator == "hip" and ch.awgn_clean_supported(sps, M_est):       # the validation frame is read once: its noise goes on while it is read
+                draws[0] += 1
+                ser, sh, _ = eng.validate_clean(ch.generate_awgn_clean_batch_hip(R, N_valid, t0["amps"], P_all, snr_all, t0["h_channel"], sps,
+                                                                                 device, seed, draws[0] - 1), 21)
+            else:
+                rxv, datav = draw(N_valid)
+                ser, sh, _ = eng.validate(rxv, datav, 21)
             SER_dev[:, epoch // epe] = ser
             if verbose:
                 loss, ser_h, sh_h = out["loss"][:, -1].cpu(), ser.cpu(), sh.cpu()
