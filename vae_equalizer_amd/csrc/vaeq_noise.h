@@ -40,6 +40,10 @@ __device__ __forceinline__ void awgn_noise_pair(uint32_t j, uint32_t run, uint32
     v1.y = __fmaf_rn(rad1, sn1, v1.y);
 }
 
+// |v|^2 onto a running power sum, as explicit fused multiply-adds: the one-pass, two-pass and clean-frame forms of the AWGN generator must agree
+// on sigma_n to the bit, whatever else their loops do around this expression
+__device__ __forceinline__ float awgn_power_add(float pw, float2 v) { return __fmaf_rn(v.y, v.y, __fmaf_rn(v.x, v.x, pw)); }
+
 // sigma_n of one run from the power sums of its 2048-sample tiles (added in tile order: every kernel gets the same bits) and the run's SNR
 // (:54: sqrt(mean |x|^2 * sps / 2 / 10^(SNR/10)))
 __device__ __forceinline__ float awgn_sigma_from_parts(const float *part, int n_parts, int Ls, int sps, float snr_db)
