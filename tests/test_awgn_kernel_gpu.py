@@ -270,3 +270,23 @@ def test_awgn_sweep_uses_the_clean_validation_frame_and_matches_the_two_step_for
     b = run_awgn_batch(runs, **kw)
     assert calls["n"] == 4 and torch.equal(a, b)
 
+
+
+def test_awgn_validate_clean_refuses_what_it_cannot_do():
+    """The noise-on-load form exists for sps = 2 and the baked tap counts: anything else is refused loudly (VAEQ_ERR_SHAPE), never silently
+    computed another way; run_awgn_batch asks channel.awgn_clean_supported first and takes the two-step form otherwise."""
+    from vae_equalizer_amd import _native as nat, channel as ch
+    from vae_equalizer_amd.engine import AWGNEngine
+    from vae_equalizer_amd.func_VAELE_MQAM_shaping import awgn_tables
+    t = awgn_tables("16-QAM", 0.0, 20, "h1", 2)
+    R, N = 3, 2000
+    clean = ch.generate_awgn_clean_batch_hip(R, N, t["amps"], t["P"], 20.0, t["h_channel"], 2, DEV, 5, 0)
+    assert ch.awgn_clean_supported(2, 25) and not ch.awgn_clean_supported(2, 13) and not ch.awgn_clean_supported(3, 25)
+    eng13 = AWGNEngine(R, 13, t["amps"], np.tile(t["P"], (R, 1)), t["amp_mean"], t["var"], DEV, 2)
+    with pytest.raises(nat.VaeqError, match="unsupported sizes"):
+        eng13.validate_clean(clean, 21)
+    eng4 = AWGNEngine(R + 1, 25, t["amps"], np.tile(t["P"], (R + 1, 1)), t["amp_mean"], t["var"], DEV, 2)
+    with pytest.raises(ValueError):
+        eng4.validate_clean(clean, 21)
+    with pytest.raises(ValueError):
+        ch.generate_awgn_clean_batch_hip(R, N, t["amps"], t["P"], 20.0, awgn_tables("16-QAM", 0.0, 20, "h1", 3)["h_channel"], 3, DEV, 5, 0)

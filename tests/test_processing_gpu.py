@@ -348,6 +348,26 @@ def test_eval_run_dp_untouched_defaults_are_fast(tmp_path):
     assert abs(tail[:, locked].mean() - 0.0314) < 4e-3, tail[:, locked].mean()  # the reference's converged SER at 23 dB (G7_full_runs)
 
 
+def test_eval_run_shaping_vaele_untouched_defaults_are_fast(tmp_path):
+    """The AWGN drop-in script with its constants untouched (Eval_run_shaping_vaele.py:9-22: iter 20 unseeded runs x 500 epochs, a validation on
+    15 000 fresh symbols every second epoch) on the device end to end, validation frames generated clean and noised while they are read
+    (vaeq_gen_awgn_clean -> vaeq_awgn_validate_gen): seconds, every run locks."""
+    import json
+    import subprocess
+    import scipy.io as io
+    d = str(tmp_path) + "/"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_run_eval_awgn_defaults.py"), d], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    info = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert info["generator"] is None and info["base_seed"] is None
+    assert info["seconds"] < 10.0, info
+    SER = io.loadmat(info["mat"])["dict"]["SER"][0, 0]
+    assert SER.shape == (1, 1, 1, 1, 1, 1, 20, 250)
+    tail = SER.reshape(20, 250)[:, -50:]
+    assert (tail.mean(axis=1) < 0.01).all(), tail.mean(axis=1)                   # uniform 64-QAM at 24 dB over h1: every run locks (SER ~ 1e-3)
+    assert SER.reshape(20, 250)[:, 0].min() > 0.3                                # and starts unconverged: the curve is a training curve
+
+
 def test_awgn_config2_device_pipeline_monte_carlo():
     """Config 2 end to end on the device -- vaeq_gen_awgn -> vaeq_awgn_train (wave kernel) -> vaeq_awgn_validate -- for 24 independent
     runs: every run locks, and the converged SER agrees with the reference's curve (G7_awgn_cfg2, ~1.1e-3) within Monte-Carlo error."""
