@@ -191,6 +191,43 @@ def test_multi_frame_call_equals_frame_by_frame():
     assert torch.equal(e1.W, e2.W) and torch.equal(e1.h, e2.h) and int(e1.step[0]) == 15
 
 
+@pytest.mark.parametrize("B,threads,flex", [(100, 0, False), (200, 0, False), (100, 64, False), (100, 0, True), (50, 0, False)])
+def test_frames_per_launch_do_not_change_the_results(B, threads, flex):
+    """How many frames a launch holds is a scheduling choice (dp_runs groups the frames of small sweeps): 6 frames x 40 steps as ONE launch, as
+    launches of 4 + 2 and frame by frame leave the same taps, Adam state and outputs, bit for bit -- beta^t of the Adam bias corrections restarts
+    from pow() at every frame head exactly as at a launch (wave kernel, two-wave kernel, generic kernel, VAEflex windows; runs that are 40 and
+    4000 steps old, where 1 - 0.999^t still moves)."""
+    from vae_equalizer_amd import shared_funcs as sfun
+    from vae_equalizer_amd.engine import DPEngine
+    t = sfun.qam_tables("64-QAM", 0.0270955)
+    R, F, steps = 5, 6, 40
+    stride, klen, k0 = (10, 10, (B - 10) // 2) if flex else (B, B, 0)
+    S = 2 * ((steps - 1) * stride + B)
+    g = torch.Generator(device="cpu").manual_seed(B + threads)
+    rx = (0.35 * torch.randn(R, F, 2, 2, S, generator=g)).to(DEV)
+    var = t["pow_mean"] / 10 ** 2.3 / 2
+
+    def run(groups):
+        eng = DPEngine(R, 25, t["amps"], t["P"], [var, var], t["nu_sc"], DEV, 2, threads)
+        eng.step[1:] = 4000                                                       # bias corrections of old runs: 0.999^t = 0.018 ... 0.015
+        eng.train(rx[:, 0].contiguous(), B, steps, 2.5e-3, stride=stride, keep_off=k0, keep_len=klen, want_q=False, want_compact=True)   # warm state
+        outs = []
+        for lo, hi in groups:
+            o = eng.train(rx[:, lo:hi].contiguous(), B, steps, 2.5e-3, stride=stride, keep_off=k0, keep_len=klen, want_q=False, want_compact=True)
+            outs.append({k: o[k] for k in ("loss", "var_est", "eq", "dec", "y")})
+        torch.cuda.synchronize()
+        cat = {k: torch.cat([o[k] for o in outs], dim=1) for k in outs[0]}
+        return eng, cat
+    ea, a = run([(0, 6)])
+    for groups in ([(0, 4), (4, 6)], [(f, f + 1) for f in range(6)]):
+        eb, b = run(groups)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (k, groups)
+        for k in ("W", "h", "mW", "vW", "mh", "vh", "step"):
+            assert torch.equal(getattr(ea, k), getattr(eb, k)), (k, groups)
+    assert torch.isfinite(a["loss"]).all() and int(ea.step[0]) == 7 * steps and int(ea.step[1]) == 4000 + 7 * steps
+
+
 def test_deterministic_bitwise():
     g = load_golden("G2_dp_freerun")
     rx = torch.from_numpy(g["rx"][None]).to(DEV)

@@ -116,13 +116,23 @@ __global__ __launch_bounds__(NT) void dp_train_kernel(const vaeq_dp_args a)
         vHs[i] = a.adam_vh[g];
     }
     int step = a.step[run];
-    double b1t = pow(0.9, (double)step), b2t = pow(0.999, (double)step);  // beta^t carried in double
+    __shared__ double BT[2][16];                               // beta^t at the start of the launch's first 16 frames (as in vaeq_dp_wave_kernel.h)
+    if (tid < 16 && tid < a.n_frames) {
+        const double t = (double)(step + tid * a.steps);
+        BT[0][tid] = pow(0.9, t);
+        BT[1][tid] = pow(0.999, t);
+    }
     __syncthreads();
+    double b1t = BT[0][0], b2t = BT[1][0];                     // carried in double, a running product inside a frame
 
     const int klen = a.keep_len, k0 = a.keep_off;
     const size_t No = (size_t)a.steps * klen;
 
     for (int f = 0; f < a.n_frames; f++) {
+        if (f && f < 16) {                                     // restart beta^t like a launch does: frames per launch do not change the results
+            b1t = BT[0][f];
+            b2t = BT[1][f];
+        }
         const float *rxf = a.rx + ((size_t)run * a.n_frames + f) * 4 * (size_t)a.S;
         float *qf = a.q_out ? a.q_out + ((size_t)run * a.n_frames + f) * (4 * NLEV) * No : nullptr;
         float *yf = a.y_out ? a.y_out + ((size_t)run * a.n_frames + f) * 4 * No : nullptr;

@@ -55,6 +55,7 @@
 #ifndef VAEQ_ROW_STEP
 #define VAEQ_ROW_STEP 1                                // q row offsets as one running scalar (0: products row * No4, A/B knob)
 #endif
+#define VAEQ_BT_FRAMES 16                              // frames per launch whose Adam bias corrections restart exactly like a launch's (vaeq_dp_train)
 #ifndef VAEQ_DEMAP_SHIFT
 #define VAEQ_DEMAP_SHIFT 0                             // 1: softmax shift from the nearest level instead of a maximum search -- 32 instructions fewer per step, but
                                                        // the fused form spills 7 VGPRs at the 254-register limit: 8.65 vs 8.45 ms (profiles/r03/kernel_variants_ab.txt); off
@@ -293,8 +294,16 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
         }
     }
     int step = a.step[run];
-    double b1t = pow(0.9, (double)step), b2t = pow(0.999, (double)step);
+    // beta^t at the start of each of the launch's first VAEQ_BT_FRAMES frames, evaluated here, where no register is under pressure yet (one pow call
+    // site, a lane per frame), and picked up at the frame heads; inside a frame it is a running product in double
+    __shared__ double BTW[2][VAEQ_BT_FRAMES];
+    if (gl < VAEQ_BT_FRAMES && gl < a.n_frames) {
+        const double t = (double)(step + gl * a.steps);
+        BTW[0][gl] = pow(0.9, t);
+        BTW[1][gl] = pow(0.999, t);
+    }
     __syncthreads();
+    double b1t = BTW[0][0], b2t = BTW[1][0];
 
     const int klen = a.keep_len, k0 = a.keep_off;
     const size_t No = (size_t)a.steps * klen;
@@ -322,6 +331,10 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
     fetch(frame_rsrc(0), 0);
     for (int f = 0; f < a.n_frames; f++) {
         const __amdgpu_buffer_rsrc_t xr = frame_rsrc(f), xn = frame_rsrc(f + 1 < a.n_frames ? f + 1 : f);   // this frame's rows, the next frame's
+        if (f && f < VAEQ_BT_FRAMES) {                         // beta^t restarts from pow() at every frame, as it does at a launch: how many frames a
+            b1t = BTW[0][f];                                    // launch holds is a scheduling choice, the results are bit-identical either way
+            b2t = BTW[1][f];                                    // (dp_runs.run_dp_batch groups the frames of small sweeps)
+        }
         // one buffer descriptor per output array and frame; rows are addressed by scalar offsets (row * No4) folded into the stores
         const bool qf = OUT != 2 && a.q_out, yf = a.y_out, ef = OUT != 1 && a.eq_out, df = OUT != 1 && a.dec_out;
         const uint32_t No4 = (uint32_t)No * 4u;

@@ -120,7 +120,8 @@ def run_dp_batch(runs, mod, sps, M_est, batch_len, N_frame_max, num_frames, flex
     R = len(runs)
     generator = resolve_generator(generator, any(r.seed is not None for r in runs))
     check_one_symb_rate(runs, generator)
-    tabs = [sfun.qam_tables(mod, r.nu) for r in runs]
+    tab_of = {nu: sfun.qam_tables(mod, nu) for nu in {r.nu for r in runs}}          # a sweep has a handful of shaping factors, not one per run
+    tabs = [tab_of[r.nu] for r in runs]
     h_channel = sfun.upsampled_channel(channel, sps)
     amps = tabs[0]["amps"]
     amp = torch.tensor(amps, dtype=torch.float32, device=device)

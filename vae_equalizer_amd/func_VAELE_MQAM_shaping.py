@@ -117,7 +117,8 @@ def run_awgn_batch(runs, mod, sps, M_est, batch_len, N_valid, N_train, num_epoch
     if seed is None:                                                             # Philox key of the device generator: fresh entropy when not given
         from .dp_runs import fresh_seed
         seed = fresh_seed()
-    tabs = [awgn_tables(mod, r["nu"], r["SNR"], channel, sps) for r in runs]
+    tab_of = {k: awgn_tables(mod, k[0], k[1], channel, sps) for k in {(r["nu"], r["SNR"]) for r in runs}}   # one table set per sweep point, not per run
+    tabs = [tab_of[(r["nu"], r["SNR"])] for r in runs]
     t0 = tabs[0]
     amp = torch.tensor(t0["amps"], dtype=torch.float32, device=device)
     eng = AWGNEngine(R, M_est, amp, np.stack([t["P"] for t in tabs]), [t["amp_mean"] for t in tabs], [t["var"] for t in tabs],
