@@ -57,7 +57,8 @@ enum {
  */
 typedef struct vaeq_dp_args {
     int32_t R;           /* independent runs in this call (one workgroup each) */
-    int32_t n_frames;    /* frames per run held in rx (taps/Adam state carry across frames) */
+    int32_t n_frames;    /* frames per run held in rx (taps/Adam state carry across frames; a launch of up to 16 frames is bit-identical to
+                            the same frames launched one by one: the Adam bias corrections restart at every frame head as at a launch) */
     int32_t steps;       /* minibatch steps per frame */
     int32_t B;           /* batch_len: symbols per minibatch window */
     int32_t sps;         /* samples per symbol (reference: 2) */
