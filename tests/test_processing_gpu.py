@@ -364,7 +364,14 @@ def test_eval_run_shaping_vaele_untouched_defaults_are_fast(tmp_path):
     SER = io.loadmat(info["mat"])["dict"]["SER"][0, 0]
     assert SER.shape == (1, 1, 1, 1, 1, 1, 20, 250)
     tail = SER.reshape(20, 250)[:, -50:]
-    assert (tail.mean(axis=1) < 0.01).all(), tail.mean(axis=1)                   # uniform 64-QAM at 24 dB over h1: every run locks (SER ~ 1e-3)
+    lvl = tail.mean(axis=1)
+    # uniform 64-QAM at 24 dB over h1: a run either locks (SER 0.0088 ... 0.0100 over the last 50 validations) or is still on the blind
+    # equaliser's initial plateau (0.867) after 500 epochs -- about one run in ten, different runs every sweep, the same in the two-step form
+    # (measured: 1, 3, 1, 4 of 40, 1); the lock statistics themselves are tests/test_ensemble_gpu.py's subject (HIP vs oracle)
+    locked = lvl < 0.1
+    assert locked.sum() >= 14, lvl
+    assert lvl[locked].max() < 1.25 * np.median(lvl[locked]) and 0.004 < np.median(lvl[locked]) < 0.015, lvl
+    assert (np.abs(lvl[~locked] - 0.867) < 0.02).all(), lvl
     assert SER.reshape(20, 250)[:, 0].min() > 0.3                                # and starts unconverged: the curve is a training curve
 
 
