@@ -3,6 +3,7 @@
 #   dp   = the bench kernel (VAE-LE, B = 100, 100 steps per launch)      tools/probe_scaling.py 1 <runs> 100
 #   flex = the VAEflex launch (window 100, stride 10, 990 steps)          tools/probe_flex.py <runs>
 #   awgn = the AWGN training kernel (B = 350, 30 steps per launch)        tools/probe_awgn.py <runs> 30 0
+#   epi  = the compact DP epilogue (one workgroup per run)                tools/probe_epilogue.py <runs>   ("step" = the whole kernel)
 # Counter passes are separate rocprofv3 runs (SQ: 8 slots per pass); --pmc is never combined with another trace domain.  Prints (and writes to
 # <outdir>/summary.txt) the raw per-launch means and the figures DESIGN.md quotes (per wave-step counts, VALU / LDS busy, bank conflicts, waits).
 MODE=${1:-dp}; R=${2:-8192}; OUT=${3:-/root/repo/gpurun_out/pmc_$MODE}
@@ -10,7 +11,8 @@ case $MODE in
   dp)   CMD="/root/repo/tools/probe_scaling.py 1 $R 100"; PAT="dp_wave_kernel|dp_train_kernel"; STEPS=100;;
   flex) CMD="/root/repo/tools/probe_flex.py $R"; PAT="dp_wave_kernel|dp_train_kernel"; STEPS=990;;
   awgn) CMD="/root/repo/tools/probe_awgn.py $R 30 0"; PAT="awgn_wave_kernel|awgn_train_kernel"; STEPS=30;;
-  *) echo "dp|flex|awgn"; exit 1;;
+  epi)  CMD="/root/repo/tools/probe_epilogue.py $R"; PAT="dp_epilogue_compact_kernel<8, true>"; STEPS=1;;
+  *) echo "dp|flex|awgn|epi"; exit 1;;
 esac
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $OUT
