@@ -369,7 +369,7 @@ def test_eval_run_shaping_vaele_untouched_defaults_are_fast(tmp_path):
     # equaliser's initial plateau (0.867) after 500 epochs -- about one run in ten, different runs every sweep, the same in the two-step form
     # (measured: 1, 3, 1, 4 of 40, 1); the lock statistics themselves are tests/test_ensemble_gpu.py's subject (HIP vs oracle)
     locked = lvl < 0.1
-    assert locked.sum() >= 14, lvl
+    assert locked.sum() >= 12, lvl                                              # P(more than 8 of 20 stuck) < 1e-4 at one in ten
     assert lvl[locked].max() < 1.25 * np.median(lvl[locked]) and 0.004 < np.median(lvl[locked]) < 0.015, lvl
     assert (np.abs(lvl[~locked] - 0.867) < 0.02).all(), lvl
     assert SER.reshape(20, 250)[:, 0].min() > 0.3                                # and starts unconverged: the curve is a training curve
