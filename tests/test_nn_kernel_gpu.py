@@ -217,3 +217,41 @@ def test_nnbn_free_run_and_eval_forward(name):
     Ne = B * min(ns, 3)
     q = eng.forward(torch.from_numpy(g["rx"][None, :, :Ne * sps]).to(DEV).expand(2, -1, -1).contiguous())
     assert np.max(np.abs(_np(q)[0] - g["q_eval"])) < 1e-5
+
+
+def test_nn_half_minibatch_kernel_matches_whole_minibatch_kernel(monkeypatch):
+    """VAEQ_NN_HALF=1 runs 64-QAM `Net` at the sweep script's shape on nn_train_half_kernel (fc1 activations of half a minibatch in LDS, one
+    recomputation, AMSGrad vectors streamed from the caller's arrays, two workgroups per CU) instead of nn_train_kernel (everything of a minibatch in
+    LDS; the default: the half-minibatch form measured no faster).  Same math, different summation order of the weight gradients (half by half): teacher-forced gradients agree to rounding, five free steps
+    of 40 independently initialised runs to 2e-5 in the parameters, the AMSGrad vectors and the step counts likewise; both are deterministic."""
+    from vae_equalizer_amd.engine import NNEngine
+    from vae_equalizer_amd.func_VAENN_MQAM import vaenn_tables
+    t = vaenn_tables("64-QAM", "h1", 2)
+    R, B, steps = 40, 300, 5
+    gen = torch.Generator(device=DEV); gen.manual_seed(5)
+    rx = 0.5 * torch.randn(R, 2, steps * B * 2, device=DEV, generator=gen)
+
+    def run(half, no_update=False, n=steps):
+        monkeypatch.setenv("VAEQ_NN_HALF", "1" if half else "0")
+        eng = NNEngine(R, 25, 25, 3, t["amps"], DEV, 2)
+        g2 = torch.Generator(device=DEV); g2.manual_seed(11)
+        eng.init_parameters(g2)
+        r = eng.train(rx, B, n, 4e-3, want_q=True, debug_grads=True, no_update=no_update)
+        torch.cuda.synchronize()
+        return eng, r
+
+    _, a = run(True, no_update=True, n=1)
+    _, b = run(False, no_update=True, n=1)
+    assert torch.equal(a["q"], b["q"])                                                 # the forward pass is the same arithmetic;
+    assert np.max(np.abs(_np(a["loss"]) - _np(b["loss"])) / np.abs(_np(b["loss"]))) < 1e-6    # the loss sums meet in a different number of waves
+    ga, gb = _np(a["g"]), _np(b["g"])
+    assert np.max(np.abs(ga - gb)) < 2e-6 * np.max(np.abs(gb))
+    ea, a = run(True)
+    eb, b = run(False)
+    assert np.max(np.abs(_np(a["loss"]) - _np(b["loss"])) / np.abs(_np(b["loss"]))) < 2e-5
+    assert np.max(np.abs(_np(ea.theta) - _np(eb.theta))) < 2e-5
+    for x, y in ((ea.m, eb.m), (ea.v, eb.v), (ea.vmax, eb.vmax)):
+        assert np.max(np.abs(_np(x) - _np(y))) < 1e-5 * max(1.0, float(y.abs().max()))
+    assert torch.equal(ea.step, eb.step) and int(ea.step[0]) == steps
+    ec, c = run(True)
+    assert torch.equal(a["loss"], c["loss"]) and torch.equal(ea.theta, ec.theta) and torch.equal(ea.vmax, ec.vmax)   # bitwise reproducible

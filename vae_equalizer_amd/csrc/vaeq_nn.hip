@@ -168,7 +168,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // wt is zero-padded to a multiple of 8 rows.  A wave takes TB column tiles at once: one weight read feeds all of them, and the operands
 // of the next two k-steps are fetched from LDS while the 2 TB MFMAs of the current two run (straight-line code, no division).
 // out(c0, col, acc): the lane's channels c0 .. c0 + 3 of column col.
-template <int NT, int TB, typename OutF>
+// LEAN: the k-step loop stays a loop when its trip count is a constant (unrolled it keeps every trip's operands in flight: + 60 registers).
+template <int NT, int TB, bool LEAN = false, typename OutF>
 __device__ __forceinline__ void mfma_conv16(const float *wt, int K, int kd, int rstride, const float *in, int cstep, int ncols, const float *bias,
                                             OutF out)
 {
@@ -203,7 +204,7 @@ __device__ __forceinline__ void mfma_conv16(const float *wt, int K, int kd, int 
         float a0, a1, b0[TB], b1[TB];
         ld(0, i, k, a0, b0, colb); adv(i, k);
         ld(1, i, k, a1, b1, colb); adv(i, k);
-        for (int t2 = 0; t2 < K8; t2++) {
+        auto trip = [&](int t2) {
             const float x0 = a0, x1 = a1;
             float y0[TB], y1[TB];
 #pragma unroll
@@ -216,6 +217,12 @@ __device__ __forceinline__ void mfma_conv16(const float *wt, int K, int kd, int 
             for (int u = 0; u < TB; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, y0[u], acc[u], 0, 0, 0);
 #pragma unroll
             for (int u = 0; u < TB; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, y1[u], acc[u], 0, 0, 0);
+        };
+        if constexpr (LEAN) {
+#pragma unroll 1
+            for (int t2 = 0; t2 < K8; t2++) trip(t2);
+        } else {
+            for (int t2 = 0; t2 < K8; t2++) trip(t2);
         }
 #pragma unroll
         for (int u = 0; u < TB; u++) {
@@ -342,17 +349,59 @@ __device__ __forceinline__ void mfma_convT16(const float *w2u, int k2, int p2, i
     }
 }
 
+// The same for the samples s in [s_lo, s_lo + s_cnt) only (s_lo a multiple of sps): the half-minibatch kernel below.  out(cc0, s, acc) with the absolute s.
+template <int NT, int TB, typename OutF>
+__device__ __forceinline__ void mfma_convT16_range(const float *w2u, int k2, int p2, int sps, const float *g2, int B, int s_lo, int s_cnt, OutF out)
+{
+    constexpr int NWV = NT / 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lc = lane & 15, lg = lane >> 4;
+    const int m_lo = s_lo / sps;
+    for (int ph = 0; ph < sps; ph++) {
+        const int kf = (ph + p2) % sps, nk = kf < k2 ? (k2 - kf + sps - 1) / sps : 0;
+        const int ncols = (s_cnt - ph + sps - 1) / sps, ntile = (ncols + 15) >> 4;
+        for (int tg = wv * TB; tg < ntile; tg += NWV * TB) {
+            f32x4 acc[TB];
+#pragma unroll
+            for (int u = 0; u < TB; u++) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int kj = 0; kj < nk; kj++) {
+                const int k = kf + kj * sps, nsh = (ph + p2 - k) / sps;             // exact division (may be negative)
+                float av[4], bv[4][TB];
+#pragma unroll
+                for (int cb = 0; cb < 4; cb++) {
+                    const int c = 4 * cb + lg;
+                    av[cb] = w2u[(k * 16 + c) * 16 + lc];
+#pragma unroll
+                    for (int u = 0; u < TB; u++) {
+                        const int n = m_lo + (tg + u) * 16 + lc + nsh, nc = n < 0 ? 0 : (n < B ? n : B - 1);
+                        const float b_ = g2[c * B + nc];
+                        bv[cb][u] = (n >= 0 && n < B) ? b_ : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+                    for (int u = 0; u < TB; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb], bv[cb][u], acc[u], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < TB; u++) {
+                const int m = (tg + u) * 16 + lc;
+                if (m < ncols) out(4 * lg, sps * (m_lo + m) + ph, acc[u]);
+            }
+        }
+    }
+}
+
 // ---- forward on one LDS-resident window: xs (zero-haloed input) -> z1 (ELU output, zero-haloed) -> a2 (logits).
 // item = (channel quad, sample): consecutive lanes take consecutive samples (conflict-free x reads and z1 writes), the four
 // channels' weights of a tap come from one 16-byte broadcast read.
-template <int NT, int NLEV>
+template <int NT, int NLEV, bool LEAN = false>
 __device__ __forceinline__ void nn_fc1_elu(const NNLayout &l, int k1, const float *xs, const float *th, const float *w1t, float *z1, int Lvalid,
                                            int zlo, int zhi, const float *aff = nullptr)
 {
     // z1p[c][p2 + s] for s in [0, Lvalid); entries whose absolute position (zlo + s) lies outside [0, zhi) are fc2's zero padding
     constexpr int C = 2 * NLEV, CQ = C / 4;
     if constexpr (C == 16) {
-        mfma_conv16<NT, (NT >= 1024 ? 2 : 5)>(w1t, 2 * k1, k1, l.Lx, xs, 1, Lvalid, th + l.oB1, [&](int c0, int sy, f32x4 acc) {
+        mfma_conv16<NT, (NT >= 1024 ? 2 : 5), LEAN>(w1t, 2 * k1, k1, l.Lx, xs, 1, Lvalid, th + l.oB1, [&](int c0, int sy, f32x4 acc) {
             const int pos = zlo + sy;
             const bool in = pos >= 0 && pos < zhi;
             const float av[4] = {acc.x, acc.y, acc.z, acc.w};
@@ -400,13 +449,13 @@ __device__ __forceinline__ void nn_fc1_elu(const NNLayout &l, int k1, const floa
     }
 }
 
-template <int NT, int NLEV>
+template <int NT, int NLEV, bool LEAN = false>
 __device__ __forceinline__ void nn_fc2(const NNLayout &l, int sps, int k2, int Bt, int astride, const float *z1, const float *th, const float *w2t,
                                        float *a2)
 {
     constexpr int C = 2 * NLEV, CQ = C / 4;
     if constexpr (C == 16) {
-        mfma_conv16<NT, (NT >= 1024 ? 1 : 3)>(w2t, C * k2, k2, l.Lz, z1, sps, Bt, th + l.oB2, [&](int c0, int n, f32x4 acc) {
+        mfma_conv16<NT, (NT >= 1024 ? 1 : 3), LEAN>(w2t, C * k2, k2, l.Lz, z1, sps, Bt, th + l.oB2, [&](int c0, int n, f32x4 acc) {
             a2[(c0 + 0) * astride + n] = acc.x; a2[(c0 + 1) * astride + n] = acc.y;
             a2[(c0 + 2) * astride + n] = acc.z; a2[(c0 + 3) * astride + n] = acc.w;
         });
@@ -656,7 +705,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
                 for (int i = 0; i < NLEV; i++) {
                     q[i] = a2[(axq * NLEV + i) * B + n];
                     gq[i] = amp[i] * gmu + amp[i] * amp[i] * gv;
-                    if (inr) gq[i] += __logf(q[i] + 1e-12f) + q[i] / (q[i] + 1e-12f);
+                    if (inr) gq[i] += __logf(q[i] + 1e-12f) + q[i] * __builtin_amdgcn_rcpf(q[i] + 1e-12f);   // (1-ulp reciprocal: the factor is 1 - 1e-12 / q)
                     dot = fmaf(q[i], gq[i], dot);
                 }
 #pragma unroll
@@ -794,6 +843,349 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
     if (tid == 0 && !a.no_update) a.step[run] = step;
     if (BN && !a.no_update)
         for (int i = tid; i < 2 * C; i += NT) a.bn_running[(size_t)run * 2 * C + i] = bnst[2 * C + i];
+}
+
+// ---- 64-QAM `Net` (C = 16, sps = 2, B even) with the fc1 activations of HALF a minibatch in LDS: two workgroups per CU.
+// nn_train_kernel keeps z1 = ELU(fc1) of the whole minibatch (41 KB) and the three AMSGrad vectors (20 KB) in LDS: 118 KB, one 512-thread
+// workgroup per CU, whose eight wavefronts all wait at the same 12 barriers of a step (MFMA pipe 21 % busy, waves waiting 46 % of their cycles).
+// Here a workgroup is 256 threads and owns 77 KB: z1 exists for one half of the symbols at a time (forward: half 0, half 1; backward: half 1
+// -- still in LDS from the forward pass --, then half 0 after ONE recomputation of fc1 + ELU for it: + 0.24 of the step's 2.1 MMAC, on a kernel
+// whose MFMA issue time is a quarter of its step), the AMSGrad vectors stream through registers from / to the caller's arrays once per step
+// (40 KB per step and run, loads issued before the last gradient phase), the next minibatch waits in registers.  Two workgroups share a CU,
+// each SIMD holds one wave of either: while one waits at a barrier or on LDS the other issues.  Weight-gradient sums run half by half in a
+// fixed order (bitwise reproducible; the order differs from nn_train_kernel's, results agree to rounding).
+__host__ __device__ inline NNLayout nn_layout_half(int B, int sps, int M, int k1, int k2)
+{
+    NNLayout l = nn_layout(B, sps, M, 8, k1, k2);
+    const int nh = B / 2;
+    // z1h[c][j] holds position b0 - p2 + j of the half starting at sample b0 = n0 sps: what fc2 reads for the half's symbols and what ELU' needs
+    const int wa = nh * sps, wb = (nh - 1) * sps + l.p2 + 1;
+    const int W = l.p2 + (wa > wb ? wa : wb);
+    l.Lz = npad4(W + 3);
+    while ((l.Lz & 7) != 4) l.Lz += 4;                 // an odd multiple of 4: 16 channel rows x 4 consecutive samples hit 64 different banks
+    int o = npad4(l.p2 + 1);                           // front pad: fc1 of half 0 addresses xs[-p2 ...] (masked to fc2's zero padding)
+    auto take = [&](int cnt) { int r = o; o += npad4(cnt); return r; };
+    l.xs = take(2 * l.Lx);
+    l.z1 = take(l.C * l.Lz); l.zb = l.z1; l.bnst = o;
+    l.a2 = take(l.C * B);
+    l.mu = take(2 * B); l.vr = take(2 * B);
+    l.es = take(2 * l.nm);
+    l.VS = take(M);
+    l.th = take(l.NP);
+    l.gr = take(l.NP); l.am = l.av = l.ax = o;
+    l.w1t = take(l.NW1 + 7 * l.C);
+    l.w2t = take(l.C * l.C * k2 + 7 * l.C);
+    l.w2u = take(l.C * l.C * k2);
+    l.red = take(64);
+    l.total = o;
+    return l;
+}
+
+template <int NT, int BK>
+__global__ __launch_bounds__(NT, 2) void nn_train_half_kernel(const vaeq_nn_args a)
+{
+    extern __shared__ float4 smem4[];
+    float *sm = reinterpret_cast<float *>(smem4);
+    constexpr int NLEV = 8, C = 16, sps = 2;
+    const int tid = threadIdx.x, run = blockIdx.x;
+    const int B = BK ? 300 : a.B, M = BK ? 25 : a.M, k1 = BK ? 25 : a.k1, k2 = BK ? 3 : a.k2;
+    const NNLayout l = BK ? nn_layout_half(300, 2, 25, 25, 3) : nn_layout_half(B, sps, M, k1, k2);
+    const int L = l.L, p1 = l.p1, p2 = l.p2, Lx = l.Lx, Lz = l.Lz, mh = l.mh, Mh = l.Mh, nm = l.nm, NP = l.NP;
+    const int nh = B / 2, Lh = nh * sps, W = p2 + max(Lh, Lh - sps + p2 + 1);
+    float *xs = sm + l.xs, *z1 = sm + l.z1, *a2 = sm + l.a2, *mu = sm + l.mu, *vr = sm + l.vr, *es = sm + l.es, *VS = sm + l.VS;
+    float *th = sm + l.th, *gr = sm + l.gr, *w1t = sm + l.w1t, *w2t = sm + l.w2t, *w2u = sm + l.w2u, *red = sm + l.red;
+    const float *hs = th + l.oH;
+
+    float amp[NLEV];
+#pragma unroll
+    for (int i = 0; i < NLEV; i++) amp[i] = a.amp[i];
+    const double lr = (double)a.lr[run];
+    const size_t pbase = (size_t)run * NP;
+    for (int i = tid; i < NP; i += NT) th[i] = a.theta[pbase + i];
+    for (int i = tid; i < l.xs + 2 * Lx; i += NT) sm[i] = 0.f;  // front pad and halos stay zero
+    for (int i = tid; i < C * Lz; i += NT) z1[i] = 0.f;
+    int step = a.step[run];
+    double b1t = pow(0.9, (double)step), b2t = pow(0.999, (double)step);
+    __syncthreads();
+    nn_transpose_weights<NT, NLEV>(l, k1, k2, th, w1t, w2t, w2u);
+
+    const size_t No = (size_t)a.steps * B;
+    const float *rxr = a.rx + (size_t)run * 2 * (size_t)a.S;
+    float *qf = a.q_out ? a.q_out + (size_t)run * C * No : nullptr;
+    const int lane = tid & 63, wv = tid >> 6;
+    constexpr int NWV = NT / 64;
+    constexpr int NPRE = BK ? (1200 + NT - 1) / NT : 8;        // minibatch samples a thread carries to the next step
+    constexpr int NADAM = BK ? (1650 + NT - 1) / NT : 0;       // parameters a thread owns in the Adam phase (run-time shapes: a plain loop)
+    float pre[NPRE];
+    const bool pre_ok = 2 * L <= NPRE * NT;
+
+    auto load_minibatch = [&](int s) {                         // issued early, parked in registers: xs is read until the last gradient phase
+#pragma unroll
+        for (int u = 0; u < NPRE; u++) {
+            const int i = tid + u * NT, row = i >= L, c = i - row * L;
+            pre[u] = i < 2 * L ? rxr[(size_t)row * a.S + (size_t)s * L + c] : 0.f;
+        }
+    };
+    auto store_minibatch = [&]() {
+#pragma unroll
+        for (int u = 0; u < NPRE; u++) {
+            const int i = tid + u * NT, row = i >= L, c = i - row * L;
+            if (i < 2 * L) xs[row * Lx + p1 + c] = pre[u];
+        }
+    };
+    auto fc1_half = [&](int b0) {                              // z1h[c][j] = ELU(fc1)(position b0 - p2 + j), zero outside [0, L)
+        nn_fc1_elu<NT, NLEV, true>(l, k1, xs + (b0 - p2), th, w1t, z1 - p2, W, b0 - p2, L);
+    };
+    if (pre_ok) { load_minibatch(0); store_minibatch(); }
+    __syncthreads();
+
+#ifdef VAEQ_NN_HALF_STAMPS
+    __shared__ long long tstamp[16];
+#define NNH_STAMP(i) do { __syncthreads(); if (tid == 0 && run == 0 && s == a.steps - 1) tstamp[i] = wall_clock64(); } while (0)
+#else
+#define NNH_STAMP(i) do { } while (0)
+#endif
+    for (int s = 0; s < a.steps; s++) {
+        NNH_STAMP(0);
+        if (!pre_ok) {
+            for (int i = tid; i < 2 * L; i += NT) {
+                const int row = i / L, c = i - row * L;
+                xs[row * Lx + p1 + c] = rxr[(size_t)row * a.S + (size_t)s * L + c];
+            }
+            __syncthreads();
+        }
+        // ---- forward, half by half: fc1 + ELU -> z1h, fc2 -> the half's logits
+        for (int hf = 0; hf < 2; hf++) {
+            fc1_half(hf * Lh);
+            __syncthreads();
+            nn_fc2<NT, NLEV, true>(l, sps, k2, nh, B, z1, th, w2t, a2 + hf * nh);
+            __syncthreads();
+        }
+        NNH_STAMP(1);
+        if (pre_ok && s + 1 < a.steps) load_minibatch(s + 1);
+        // ---- softmax -> q (in place), moments, entropy term; item = (axis, n)
+        float klsum = 0.f, vtot = 0.f;
+        for (int it = tid; it < 2 * B; it += NT) {
+            const int axq = it / B, n = it - axq * B;
+            float z[NLEV], zmax = -3.0e38f;
+#pragma unroll
+            for (int i = 0; i < NLEV; i++) { z[i] = a2[(axq * NLEV + i) * B + n]; zmax = fmaxf(zmax, z[i]); }
+            float ssum = 0.f;
+#pragma unroll
+            for (int i = 0; i < NLEV; i++) { z[i] = __expf(z[i] - zmax); ssum += z[i]; }
+            const float rs = 1.0f / ssum;
+            float e1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NLEV; i++) { z[i] *= rs; e1 = fmaf(amp[i], z[i], e1); }
+            float e2 = 0.f;
+            const bool inr = (n >= mh) && (n < B - mh);        // entropy slice (:90)
+#pragma unroll
+            for (int i = 0; i < NLEV; i++) {
+                const float d = amp[i] - e1;
+                e2 = fmaf(z[i] * d, d, e2);
+                if (inr) klsum = fmaf(z[i], __logf(z[i] + 1e-12f), klsum);
+                a2[(axq * NLEV + i) * B + n] = z[i];
+                if (qf) qf[(size_t)(axq * NLEV + i) * No + (size_t)s * B + n] = z[i];
+            }
+            mu[it] = e1; vr[it] = e2;
+            vtot += e2;
+        }
+        __syncthreads();
+        NNH_STAMP(2);
+        // ---- residual e = x - D (a pair of outputs shares every U read; item = tau), VS, C
+        float se = 0.f;
+        for (int tau = tid; 2 * tau < nm; tau += NT) {
+            float d0r = 0.f, d0i = 0.f, d1r = 0.f, d1i = 0.f;
+            const float *ur = mu + tau + mh, *ui = ur + B;
+#pragma unroll 1
+            for (int aa = 0; aa < mh; aa++) {
+                const float a_ = ur[-aa], b_ = ui[-aa];
+                const float c0 = hs[2 * aa], e0 = hs[M + 2 * aa], c1 = hs[2 * aa + 1], e1 = hs[M + 2 * aa + 1];
+                d0r = fmaf(c0, a_, d0r); d0r = fmaf(-e0, b_, d0r);
+                d0i = fmaf(c0, b_, d0i); d0i = fmaf(e0, a_, d0i);
+                d1r = fmaf(c1, a_, d1r); d1r = fmaf(-e1, b_, d1r);
+                d1i = fmaf(c1, b_, d1i); d1i = fmaf(e1, a_, d1i);
+            }
+            {
+                const float a_ = ur[-mh], b_ = ui[-mh], c0 = hs[Mh], e0 = hs[M + Mh];
+                d0r = fmaf(c0, a_, d0r); d0r = fmaf(-e0, b_, d0r);
+                d0i = fmaf(c0, b_, d0i); d0i = fmaf(e0, a_, d0i);
+            }
+            const int t = 2 * tau;
+            const float er0 = xs[p1 + mh + t] - d0r, ei0 = xs[Lx + p1 + mh + t] - d0i;
+            es[t] = er0; es[nm + t] = ei0;
+            se += er0 * er0 + ei0 * ei0;
+            if (t + 1 < nm) {
+                const float er1 = xs[p1 + mh + t + 1] - d1r, ei1 = xs[Lx + p1 + mh + t + 1] - d1i;
+                es[t + 1] = er1; es[nm + t + 1] = ei1;
+                se += er1 * er1 + ei1 * ei1;
+            }
+        }
+        block_reduce3<NT>(se, klsum, vtot, red);
+        float hterm = 0.f;
+        if (tid < M) {
+            const int j = tid, lo = (Mh - j + sps - 1) / sps, hi_ = (nm - 1 + Mh - j) / sps;
+            float miss = 0.f;
+            for (int np = 0; np < lo; np++) miss += vr[np] + vr[B + np];
+            for (int np = hi_ + 1; np < B; np++) miss += vr[np] + vr[B + np];
+            VS[j] = red[2] - miss;
+            hterm = (hs[j] * hs[j] + hs[M + j] * hs[M + j]) * VS[j];
+        }
+        if (tid < 64) {
+            hterm = wave_sum(hterm);
+            if (tid == 0) red[3] = hterm;
+        }
+        __syncthreads();
+        const float Cc = red[0] + red[3];
+        const float gC = (float)nm / Cc;
+        if (tid == 0 && a.loss) a.loss[(size_t)run * a.steps + s] = (float)nm * logf(Cc) + red[1];
+        NNH_STAMP(3);
+        // ---- dL/dh: one wave per group of 4 taps
+        for (int jg = wv; 4 * jg < M; jg += NWV) {
+            const int j0 = 4 * jg, jl = min(j0 + 3, M - 1);
+            const int lo = max(0, (Mh - jl + sps - 1) / sps), hi_ = min(B - 1, (nm - 1 + Mh - j0) / sps);
+            float acc[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) acc[q] = 0.f;
+            for (int np = lo + lane; np <= hi_; np += 64) {
+                const int t0 = np * sps - Mh + j0;
+                const float c_ = mu[np], d_ = mu[B + np];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int t = t0 + q, tc = t < 0 ? 0 : (t < nm ? t : nm - 1);
+                    const bool ok = t >= 0 && t < nm && j0 + q < M;
+                    const float a_ = ok ? es[tc] : 0.f, b_ = ok ? es[nm + tc] : 0.f;
+                    acc[2 * q] = fmaf(a_, c_, acc[2 * q]); acc[2 * q] = fmaf(b_, d_, acc[2 * q]);
+                    acc[2 * q + 1] = fmaf(b_, c_, acc[2 * q + 1]); acc[2 * q + 1] = fmaf(-a_, d_, acc[2 * q + 1]);
+                }
+            }
+            const float sum = wave_reduce_scatter<8>(acc, lane);
+            const int idx = wave_reduce_channel<8>(lane), j = j0 + (idx >> 1), im = idx & 1;
+            if ((lane & 7) == 0 && j < M) gr[l.oH + im * M + j] = gC * (-2.0f * sum + 2.0f * hs[im * M + j] * VS[j]);
+        }
+        // ---- dL/dmu, dL/drho -> dL/dq -> softmax backward -> dL/dlogits in place of q; item = n (both axes)
+        for (int n = tid; n < B; n += NT) {
+            const int sx = n * sps;
+            const int jlo = max(0, Mh - sx), jhi = min(Mh, nm - 1 + Mh - sx);
+            const float *er = es + (sx - Mh), *ei = er + nm;
+            float pr = 0.f, pi = 0.f, ph = 0.f;
+            for (int j = jlo; j <= jhi; j++) {
+                const float a_ = er[j], b_ = ei[j], c_ = hs[j], d_ = hs[M + j];
+                pr = fmaf(a_, c_, pr); pr = fmaf(b_, d_, pr);
+                pi = fmaf(b_, c_, pi); pi = fmaf(-a_, d_, pi);
+                ph = fmaf(c_, c_, ph); ph = fmaf(d_, d_, ph);
+            }
+            const float gv = gC * ph;
+            const bool inr = (n >= mh) && (n < B - mh);
+#pragma unroll
+            for (int axq = 0; axq < 2; axq++) {
+                const float gmu = -2.0f * gC * (axq ? pi : pr) - 2.0f * mu[axq * B + n] * gv;
+                float q[NLEV], gq[NLEV], dot = 0.f;
+#pragma unroll
+                for (int i = 0; i < NLEV; i++) {
+                    q[i] = a2[(axq * NLEV + i) * B + n];
+                    gq[i] = amp[i] * gmu + amp[i] * amp[i] * gv;
+                    if (inr) gq[i] += __logf(q[i] + 1e-12f) + q[i] * __builtin_amdgcn_rcpf(q[i] + 1e-12f);   // (1-ulp reciprocal: the factor is 1 - 1e-12 / q)
+                    dot = fmaf(q[i], gq[i], dot);
+                }
+#pragma unroll
+                for (int i = 0; i < NLEV; i++) a2[(axq * NLEV + i) * B + n] = q[i] * (gq[i] - dot);
+            }
+        }
+        __syncthreads();
+        NNH_STAMP(4);
+        // ---- backward through the network: half 1 (its z1 is still in LDS), then half 0 (fc1 + ELU recomputed)
+        float pm[NADAM > 0 ? NADAM : 1], pv[NADAM > 0 ? NADAM : 1], px[NADAM > 0 ? NADAM : 1];
+        for (int hb = 1; hb >= 0; hb--) {
+            const int b0 = hb * Lh, n0 = hb * nh;
+            const bool first = hb == 1;
+            if (!first) {
+                NNH_STAMP(8);
+                fc1_half(b0);
+                __syncthreads();
+                NNH_STAMP(9);
+            }
+            // fc2 weight / bias gradients: gw2[c][cc][k] += sum_{n in half} g2[c][n] z1[cc][n sps + k - p2]
+            mfma_wgrad16<NT>(a2 + n0, B, nh, z1, sps, C * k2, k2, Lz, mu, 4 * B + 2 * nm, [&](int c0, int j, f32x4 acc) {
+                const float av_[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    float *gp = j == C * k2 ? gr + l.oB2 + c0 + t : gr + l.oW2 + (c0 + t) * C * k2 + j;
+                    *gp = first ? av_[t] : *gp + av_[t];
+                }
+            });
+            __syncthreads();
+            if (first) NNH_STAMP(5); else NNH_STAMP(10);
+            // dL/dz1 through fc2, times ELU' -> dL/da1 in place of z1h, for the samples [b0, b0 + Lh)
+            mfma_convT16_range<NT, 3>(w2u, k2, p2, sps, a2, B, b0, Lh, [&](int cc0, int sx, f32x4 acc) {
+                const float gg[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int ix = (cc0 + u) * Lz + p2 + (sx - b0);
+                    const float z = z1[ix];
+                    z1[ix] = gg[u] * (z > 0.f ? 1.0f : z + 1.0f);
+                }
+            });
+            __syncthreads();
+            if (first) NNH_STAMP(6); else NNH_STAMP(11);
+            if (!first && NADAM > 0 && !a.no_update) {         // the AMSGrad vectors of this thread's parameters: in flight during the last gradient phase
+#pragma unroll
+                for (int u = 0; u < NADAM; u++) {
+                    const int i = tid + u * NT;
+                    const size_t g = pbase + (i < NP ? i : 0);
+                    pm[u] = a.adam_m[g]; pv[u] = a.adam_v[g]; px[u] = a.adam_x[g];
+                }
+            }
+            // fc1 weight / bias gradients: gw1[c][i][k] += sum_{s in half} gz[c][s] x[i][s + k - p1]
+            mfma_wgrad16<NT>(z1 + p2, Lz, Lh, xs + b0, 1, 2 * k1, k1, Lx, mu, 4 * B + 2 * nm, [&](int c0, int j, f32x4 acc) {
+                const float av_[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    float *gp = j == 2 * k1 ? gr + l.oB1 + c0 + t : gr + l.oW1 + (c0 + t) * 2 * k1 + j;
+                    *gp = first ? av_[t] : *gp + av_[t];
+                }
+            });
+            __syncthreads();
+            if (first) NNH_STAMP(7);
+        }
+        NNH_STAMP(12);
+        // ---- Adam(amsgrad) on every parameter (:285); the next minibatch goes to LDS
+        step += 1;
+        b1t *= 0.9;
+        b2t *= 0.999;
+        if (pre_ok && s + 1 < a.steps) store_minibatch();
+        if (!a.no_update) {
+            const float bc2s = (float)sqrt(1.0 - b2t), ss = (float)(lr / (1.0 - b1t));
+            if constexpr (NADAM > 0) {
+#pragma unroll
+                for (int u = 0; u < NADAM; u++) {
+                    const int i = tid + u * NT;
+                    if (i < NP) {
+                        adam_update_amsgrad(th[i], pm[u], pv[u], px[u], gr[i], ss, bc2s);
+                        a.adam_m[pbase + i] = pm[u]; a.adam_v[pbase + i] = pv[u]; a.adam_x[pbase + i] = px[u];
+                    }
+                }
+            } else {
+                for (int i = tid; i < NP; i += NT) {
+                    float m_ = a.adam_m[pbase + i], v_ = a.adam_v[pbase + i], x_ = a.adam_x[pbase + i];
+                    adam_update_amsgrad(th[i], m_, v_, x_, gr[i], ss, bc2s);
+                    a.adam_m[pbase + i] = m_; a.adam_v[pbase + i] = v_; a.adam_x[pbase + i] = x_;
+                }
+            }
+            __syncthreads();
+            nn_transpose_weights<NT, NLEV>(l, k1, k2, th, w1t, w2t, w2u);
+        }
+        __syncthreads();
+        NNH_STAMP(13);
+#ifdef VAEQ_NN_HALF_STAMPS
+        if (tid < 13 && run == 0 && s == a.steps - 1 && a.loss) a.loss[tid] = (float)(tstamp[tid + 1] - tstamp[tid]);
+#endif
+    }
+    for (int i = tid; i < NP; i += NT) {
+        if (!a.no_update) a.theta[pbase + i] = th[i];
+        if (a.dbg_g) a.dbg_g[pbase + i] = gr[i];
+    }
+    if (tid == 0 && !a.no_update) a.step[run] = step;
 }
 
 // ---- eval-mode forward over N symbols in tiles (validation, :293-301): q[R][C][N]
@@ -957,9 +1349,30 @@ static int launch_nn_train(const vaeq_nn_args &a, size_t lds, hipStream_t st)
         constexpr int BK = NLEV == 8 ? 1 : NLEV == 4 ? 2 : 0;
         k = a.batch_norm ? nn_train_kernel<512, NLEV, true, 2, BK> : nn_train_kernel<512, NLEV, false, 2, BK>;
     }
+    int nt = 512;
+    if constexpr (NLEV == 8) {
+        // VAEQ_NN_HALF=1: 64-QAM `Net` at the script's shape on half-minibatch activations, two 256-thread workgroups per CU.  Built, parity-green and
+        // MEASURED (profiles/r03/vaenn_half_minibatch_ab.txt): 27.8 vs 28.3 us per run-step at 2048 runs, 48.7 vs 31.9 at <= 256 runs -- not the default.
+        const char *he = getenv("VAEQ_NN_HALF");
+        if (k == nn_train_kernel<512, NLEV, false, 2, 1> && he && atoi(he) == 1) {
+            const size_t ldh = (size_t)nn_layout_half(300, 2, 25, 25, 3).total * 4;
+            auto kh = nn_train_half_kernel<256, 1>;
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kh), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldh) != hipSuccess)
+                return VAEQ_ERR_LDS;
+            hipLaunchKernelGGL(kh, dim3(a.R), dim3(256), ldh, st, a);
+            return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
+        }
+        if (const char *e = getenv("VAEQ_NN_NT")) {            // experiment knob: the baked 64-QAM `Net` kernel on 256 / 1024 threads per run
+            const int v = atoi(e);
+            if ((v == 256 || v == 1024) && k == nn_train_kernel<512, NLEV, false, 2, 1>) {
+                nt = v;
+                k = v == 256 ? nn_train_kernel<256, NLEV, false, 2, 1> : nn_train_kernel<1024, NLEV, false, 2, 1>;
+            }
+        }
+    }
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VAEQ_ERR_LDS;
-    hipLaunchKernelGGL(k, dim3(a.R), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(k, dim3(a.R), dim3(nt), lds, st, a);
     return hipGetLastError() == hipSuccess ? VAEQ_OK : VAEQ_ERR_LAUNCH;
 }
 
