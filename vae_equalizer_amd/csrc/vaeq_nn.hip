@@ -24,6 +24,13 @@
 #include "vaeq_common.h"
 #include "vaeq_validate.h"
 
+#ifndef VAEQ_NN_PREF
+#define VAEQ_NN_PREF 0                                 // 1: baked 64-QAM `Net` kernel fetches the next minibatch into registers during the step (measured: no gain, 16 spilled registers)
+#endif
+#ifndef VAEQ_NN_LEAN
+#define VAEQ_NN_LEAN 0                                 // 1: ... its forward convolutions with the k-step loop kept a loop (measured: -4 %)
+#endif
+
 namespace vaeq {
 
 struct NNLayout {
@@ -533,15 +540,38 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
     const int lane = tid & 63, wv = tid >> 6;
     constexpr int NWV = NT / 64, CQ = C / 4;
 
+    // BK = 1: the next minibatch is fetched while the current step computes (its 1200 samples = three per thread wait in registers: xs is read until
+    // the last gradient phase) -- a step no longer starts with an exposed HBM round trip
+    constexpr int NPRE = BK == 1 ? (1200 + NT - 1) / NT : 1;
+    constexpr bool PREF = BK == 1 && !BN && VAEQ_NN_PREF;
+    float pre[NPRE];
+    auto load_minibatch = [&](int s) {
+#pragma unroll
+        for (int u = 0; u < NPRE; u++) {
+            const int i = tid + u * NT, row = i >= L, c = i - row * L;
+            pre[u] = i < 2 * L ? rxr[(size_t)row * a.S + (size_t)s * L + c] : 0.f;
+        }
+    };
+    auto store_minibatch = [&]() {
+#pragma unroll
+        for (int u = 0; u < NPRE; u++) {
+            const int i = tid + u * NT, row = i >= L, c = i - row * L;
+            if (i < 2 * L) xs[row * Lx + p1 + c] = pre[u];
+        }
+    };
+    if constexpr (PREF) { load_minibatch(0); store_minibatch(); __syncthreads(); }
+
     for (int s = 0; s < a.steps; s++) {
         // ---- P0: minibatch -> LDS (:276)
-        for (int i = tid; i < 2 * L; i += NT) {
-            const int row = i / L, c = i - row * L;
-            xs[row * Lx + p1 + c] = rxr[(size_t)row * a.S + (size_t)s * L + c];
+        if constexpr (!PREF) {
+            for (int i = tid; i < 2 * L; i += NT) {
+                const int row = i / L, c = i - row * L;
+                xs[row * Lx + p1 + c] = rxr[(size_t)row * a.S + (size_t)s * L + c];
+            }
+            __syncthreads();
         }
-        __syncthreads();
         // ---- P1/P2: fc1 + ELU, fc2
-        nn_fc1_elu<NT, NLEV>(l, k1, xs, th, w1t, z1, L, 0, L);
+        nn_fc1_elu<NT, NLEV, BK == 1 && VAEQ_NN_LEAN>(l, k1, xs, th, w1t, z1, L, 0, L);
         __syncthreads();
         if (BN) {                                              // BatchNorm1d in training mode (:203): batch statistics over the L samples
             for (int c = wv; c < C; c += NWV) {
@@ -568,7 +598,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
             }
             __syncthreads();
         }
-        nn_fc2<NT, NLEV>(l, sps, k2, B, B, zb, th, w2t, a2);
+        nn_fc2<NT, NLEV, BK == 1 && VAEQ_NN_LEAN>(l, sps, k2, B, B, zb, th, w2t, a2);
         __syncthreads();
         // ---- P3: per-axis softmax -> q (in place), moments, entropy term; item = (axis, n)
         float klsum = 0.f, vtot = 0.f;
@@ -713,6 +743,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
             }
         }
         __syncthreads();
+        if constexpr (PREF) { if (s + 1 < a.steps) load_minibatch(s + 1); }
         // ---- P7a: fc2 weight / bias gradients: one wave per (input channel, group of 4 taps); pseudo group at the end: the biases
         if constexpr (C == 16) {
             // gw2[c][cc][k] = sum_n g2[c][n] zb[cc][n sps + k]: columns j = cc k2 + k, plus the bias column
@@ -827,6 +858,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
         step += 1;
         b1t *= 0.9;
         b2t *= 0.999;
+        if constexpr (PREF) { if (s + 1 < a.steps) store_minibatch(); }
         if (!a.no_update) {
             const float bc2s = (float)sqrt(1.0 - b2t), ss = (float)(lr / (1.0 - b1t));
             for (int i = tid; i < NP; i += NT) adam_update_amsgrad(th[i], am[i], av[i], ax[i], gr[i], ss, bc2s);
