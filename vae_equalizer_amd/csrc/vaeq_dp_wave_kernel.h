@@ -27,9 +27,6 @@
 // eight wavefronts per run (NW = 2, 4, 8: same code, thread 64 wv + lane owns the pair, see dp_wave_kernel).  Instantiated in
 // vaeq_dp_wave.hip (NW = 1), vaeq_dp_wave_mw.hip (NW = 2, 4) and vaeq_dp_wave_mw8.hip (NW = 8).
 #pragma once
-#ifndef VAEQ_DP_STAGGER
-#define VAEQ_DP_STAGGER 0
-#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -307,14 +304,6 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
     }
     __syncthreads();
     double b1t = BTW[0][0], b2t = BTW[1][0];
-#if VAEQ_DP_STAGGER
-    // experiment: the two wavefronts that share a SIMD start half a minibatch step apart (the one in the odd wave slot waits VAEQ_DP_STAGGER x 3.4 us),
-    // so that one's packed-FMA tap loops run beside the other's latency-bound phases instead of both being in the same phase
-    if constexpr (NW == 1) {
-        if (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1)     // HW_ID.WAVE_ID bit 0
-            for (int i = 0; i < VAEQ_DP_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
 
     const int klen = a.keep_len, k0 = a.keep_off;
     const size_t No = (size_t)a.steps * klen;
