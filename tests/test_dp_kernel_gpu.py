@@ -267,11 +267,14 @@ def test_error_codes():
 
 
 @pytest.mark.parametrize("B,M,n", [(20, 25, 8), (14, 25, 4), (24, 25, 8), (10, 9, 8), (8, 13, 2), (16, 31, 4), (100, 25, 8), (64, 25, 4), (128, 13, 2), (50, 9, 8), (26, 25, 8), (100, 31, 8), (80, 17, 4), (60, 21, 2),
-                                   (128, 25, 8), (64, 25, 8), (128, 25, 2), (50, 25, 8), (98, 25, 4), (126, 25, 8), (254, 25, 8), (300, 25, 8), (770, 25, 4), (130, 25, 8), (200, 25, 8), (256, 13, 2), (258, 31, 4), (300, 9, 8), (384, 21, 2), (512, 25, 8), (154, 17, 4), (600, 13, 4), (1000, 31, 2), (1024, 25, 8)])
+                                   (128, 25, 8), (64, 25, 8), (128, 25, 2), (50, 25, 8), (98, 25, 4), (126, 25, 8), (254, 25, 8), (300, 25, 8), (770, 25, 4), (130, 25, 8), (200, 25, 8), (256, 13, 2), (258, 31, 4), (300, 9, 8), (384, 21, 2), (512, 25, 8), (154, 17, 4), (600, 13, 4), (1000, 31, 2), (1024, 25, 8),
+                                   # odd minibatch lengths (the last lane's symbol pair is half empty; rows start 8-byte aligned): every size class and tap count
+                                   (99, 25, 8), (101, 25, 8), (127, 25, 4), (25, 25, 8), (15, 9, 8), (13, 25, 2), (77, 17, 4), (33, 31, 4), (129, 25, 8), (255, 13, 2), (257, 31, 4),
+                                   (301, 9, 8), (511, 25, 8), (513, 21, 2), (999, 17, 4), (1023, 25, 8)])
 def test_wave_kernel_equals_generic_kernel(B, M, n):
     """The wave-per-run fast path (threads=1; one wavefront per run up to B = 128, two up to 256, four up to 512, eight up to 1024; M = 25: B = 100 /
-    128 / 200 / 400 baked, every other B on the fixed LDS layout of its size class, other M on run-time layouts) and the generic kernel
-    (threads=256) agree on ragged shapes, 5 free steps, R=9."""
+    128 / 200 / 400 baked, every other B -- even or odd -- on the fixed LDS layout of its size class, like all B of the other tap counts) and the generic
+    kernel (threads=256) agree on ragged shapes, 5 free steps, R=9."""
     from vae_equalizer_amd.engine import DPEngine
     rng = np.random.default_rng(B + M)
     R, sps, steps = 9, 2, 5
@@ -301,7 +304,7 @@ def test_wave_kernel_equals_generic_kernel(B, M, n):
     assert torch.equal(ea.step, eb.step)
 
 
-@pytest.mark.parametrize("B,k0,klen", [(200, 95, 11), (200, 90, 20), (300, 145, 10), (140, 65, 11), (700, 345, 11), (128, 59, 11), (64, 26, 12)])
+@pytest.mark.parametrize("B,k0,klen", [(200, 95, 11), (200, 90, 20), (300, 145, 10), (140, 65, 11), (700, 345, 11), (128, 59, 11), (64, 26, 12), (99, 44, 10), (255, 122, 11), (513, 250, 12)])
 def test_multiwave_flex_windows_equal_generic_kernel(B, k0, klen):
     """VAEflex windows (stride 10, centre slice kept; odd offsets take the scalar-store variant) on the two- / four-wave kernels (and the baked B = 64 / 128 single-wave shapes),
     with the compact epilogue outputs, against the generic kernel: 12 free steps, R = 5."""
@@ -367,10 +370,13 @@ def test_multiwave_against_oracle_frames_and_determinism(B, M, n):
 def test_wave_kernel_refused_for_unsupported_shape():
     from vae_equalizer_amd import _native as nat
     from vae_equalizer_amd.engine import DPEngine
-    g = load_golden("G1_dp_step_4qam")          # B = 37 is odd
-    eng = DPEngine(1, int(g["M_est"]), g["amp_levels"], g["P"], g["var"], float(g["nu_sc"]), DEV, 2, threads=1)
+    g = load_golden("G1_dp_step_4qam")          # (B = 37: odd minibatch lengths run on the wave kernel since round 3)
+    eng = DPEngine(1, 11, g["amp_levels"], g["P"], g["var"], float(g["nu_sc"]), DEV, 2, threads=1)       # a tap count without an instantiation
     with pytest.raises(nat.VaeqError):
         eng.train(torch.from_numpy(g["rx"][None]).to(DEV), int(g["B"]), 1, 1e-3)
+    eng = DPEngine(1, int(g["M_est"]), g["amp_levels"], g["P"], g["var"], float(g["nu_sc"]), DEV, 3, threads=1)   # sps = 3
+    with pytest.raises(nat.VaeqError):
+        eng.train(torch.zeros(1, 1, 2, 2, 3 * int(g["B"]), device=DEV), int(g["B"]), 1, 1e-3)
 
 
 # ------------------------------------------------------------------ compact epilogue inputs (eq_out / dec_out)

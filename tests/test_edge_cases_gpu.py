@@ -67,11 +67,12 @@ def test_null_and_inconsistent_arguments_are_refused():
                                C.c_uint32(0), p, p, p, None, None, None) == ERR_SHAPE                              # Lg > 96 taps
 
 
-@pytest.mark.parametrize("M,B,sps,n", [(63, 150, 2, 8), (31, 600, 2, 4), (9, 41, 3, 2), (5, 33, 1, 8), (25, 20, 2, 8), (25, 14, 2, 4), (9, 10, 2, 8)])
+@pytest.mark.parametrize("M,B,sps,n", [(63, 150, 2, 8), (31, 600, 2, 4), (9, 41, 3, 2), (5, 33, 1, 8), (25, 20, 2, 8), (25, 14, 2, 4), (9, 10, 2, 8),
+                                       (25, 99, 2, 8), (25, 21, 2, 8), (13, 155, 2, 4), (31, 333, 2, 2), (25, 777, 2, 8)])
 def test_dp_extreme_shapes_against_oracle(M, B, sps, n):
     """Largest tap count (M = 63), a 600-symbol minibatch (42 KB of LDS), sps = 3 and sps = 1: the generic kernel; minibatches SHORTER than the filter
-    (the reference's commented-out batch_len options, Eval_run_DP.py:38: B = 20 with M = 25 -- an empty KL slice, 16 residual samples): the wave kernel;
-    3 free steps."""
+    (the reference's commented-out batch_len options, Eval_run_DP.py:38: B = 20 with M = 25 -- an empty KL slice, 16 residual samples) and ODD minibatch
+    lengths at one to eight wavefronts per run: the wave kernel; 3 free steps."""
     from vae_equalizer_amd.engine import DPEngine
     rng = np.random.default_rng(M * B)
     R, steps = 2, 3

@@ -22,9 +22,13 @@ bool dp_wave_supported(const vaeq_dp_args &a)
     // minibatches down to the shortest one with a residual (nm = 2 B - 2 (M / 2) >= 2 samples: the reference's short batch_len options, Eval_run_DP.py:38,
     // e.g. B = 20 with M = 25 -- the KL slice mh <= n < B - mh is then empty, as in the reference): ten of the 64 lanes own a symbol pair, still
     // several times the generic kernel's rate (one workgroup of 256 threads and seven barriers per step for 20 symbols)
-    if (a.sps != 2 || (a.B & 1) || a.B > 1024 || 2 * a.B - 2 * (a.M / 2) < 2 || a.B < 4) return false;
+    if (a.sps != 2 || a.B > 1024 || 2 * a.B - 2 * (a.M / 2) < 2 || a.B < 4) return false;
     if (!(a.M == 25 || a.M == 31 || a.M == 21 || a.M == 17 || a.M == 13 || a.M == 9)) return false;
-    if ((a.S & 3) || ((a.stride_sym * 2) & 3) || (reinterpret_cast<uintptr_t>(a.rx) & 15)) return false;   // 16-byte window loads
+    // odd minibatch lengths run on the class layouts (the last lane's pair is half empty, vaeq_dp_wave_kernel.h: ODDB), i.e. not on M = 25's
+    // run-time-layout A/B form; their windows start 8-byte aligned (16-byte buffer loads need dword alignment only)
+    if ((a.B & 1) && (a.B > 1023 || (a.M == 25 && !dp_wave_fixl(a.B, 25)))) return false;
+    if ((a.S & 1) || (reinterpret_cast<uintptr_t>(a.rx) & 15)) return false;
+    if (!(a.B & 1) && ((a.S & 3) || ((a.stride_sym * 2) & 3))) return false;                             // even B: 16-byte aligned window loads as before
     if (a.q_out && (reinterpret_cast<uintptr_t>(a.q_out) & 7)) return false;
     if (a.y_out && (reinterpret_cast<uintptr_t>(a.y_out) & 7)) return false;
     if (a.eq_out && (reinterpret_cast<uintptr_t>(a.eq_out) & 7)) return false;
@@ -46,7 +50,7 @@ int launch_dp_wave(const vaeq_dp_args &a, hipStream_t st)
 {
     if (a.B > 128) return launch_dp_wave_mw(a, st);
     if (const char *e = getenv("VAEQ_DP_FORCE_NW")) {          // experiment knob: B <= 128 on two / four wavefronts per run (run-time layout)
-        if (e[0] == '2' || e[0] == '4') return launch_dp_wave_nw(a, st, e[0] - '0');
+        if ((e[0] == '2' || e[0] == '4') && !(a.B & 1)) return launch_dp_wave_nw(a, st, e[0] - '0');   // (run-time layout: even B only)
     }
     if (a.M == 25 && a.B == 128 && dp_wave_fixl(64, 25)) return launch_dp_wave_b128(a, st);
     if (dp_wave_fixl(a.B, a.M)) return launch_dp_wave_bk(a, st);

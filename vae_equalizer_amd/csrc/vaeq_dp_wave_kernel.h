@@ -233,7 +233,10 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
     constexpr bool PIPE_DU = VAEQ_PIPE_DU;                 // dL/dU runs at the kernel's register peak (moments of the demapper still live): no second operand set there
     const int B = BT ? BT : a.B;
     const int BS = BT ? BT : BL ? BL : B;                      // the minibatch length the LDS layout (offsets, row strides) is made for
-    const int L = 2 * B, nm = L - Mh, P2 = B / 2;
+    // ODDB: on a class layout (BL) the minibatch length may be odd -- the last lane's pair is (B - 1, phantom): the phantom symbol is computed like
+    // any other (from zero-padded cells) and masked wherever it would be stored or summed (v1 below); baked shapes are even and unchanged
+    constexpr bool ODDB = BT == 0 && BL > 0;
+    const int L = 2 * B, nm = L - Mh, P2 = ODDB ? (B + 1) / 2 : B / 2;
     const float rnm = 1.0f / (float)nm;
     const WaveLayout lay = wave_layout(BS, M, NW);
     const int Lph = lay.Lph, Uph = lay.Uph;
@@ -311,12 +314,13 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
     const bool act = gl < P2;                                  // thread owns symbols 2*gl, 2*gl+1
     const int nq = (nm + 3) / 4;                               // residual quads t = 4l' .. 4l'+3
     const int n0 = 2 * gl;
+    const bool v1 = ODDB ? act && (n0 + 1 < B) : act;       // the lane's second symbol exists
     const float2 *Xl = Xs + gl, *El = Es + gl, *Ul = Us + gl;
     const float2 *Xa = Xs + (act ? gl : 0), *Ea = Es + (act ? gl : 0);   // symbol-pair phases: idle lanes shadow lane 0 (results unused)
 
     // The window of the NEXT step is fetched into registers while the current step computes (one 16-byte load per lane and
     // row: B <= 128 means L/4 <= 64 lanes), so a step never waits for HBM after the first.
-    const bool ldl = gl < L / 4;
+    const bool ldl = gl < (ODDB ? (L + 3) / 4 : L / 4);         // odd B: L = 2 (mod 4), the last lane's upper two samples belong to the next minibatch
     float4 pf[4];
     const uint32_t S4 = (uint32_t)a.S * 4u;                    // bytes per received row; a frame of a run = 4 rows
     auto frame_rsrc = [&](int f) { return make_rsrc(a.rx + ((size_t)run * a.n_frames + f) * 4 * (size_t)a.S, 4u * S4); };
@@ -357,7 +361,8 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const int c = mh + i;                  // + 4*lane: phase (c & 3) is lane independent
-                        Xs[(p * 4 + (c & 3)) * Lph + gl + (c >> 2)] = make_float2(xi[i], xq[i]);
+                        const bool in = !ODDB || 4 * gl + i < L;
+                        Xs[(p * 4 + (c & 3)) * Lph + gl + (c >> 2)] = in ? make_float2(xi[i], xq[i]) : make_float2(0.f, 0.f);
                     }
                 }
             }
@@ -534,10 +539,10 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                     }
                 }
                 vv[o][0] = act ? mv[0][o][0] + mv[0][o][1] : 0.f;
-                vv[o][1] = act ? mv[1][o][0] + mv[1][o][1] : 0.f;
+                vv[o][1] = v1 ? mv[1][o][0] + mv[1][o][1] : 0.f;
                 if (act) {                                     // U[nu=o][n]: even symbols in phase 0, odd in phase 1
                     Us[(o * 2 + 0) * Uph + gl] = muv[0];
-                    Us[(o * 2 + 1) * Uph + gl] = muv[1];
+                    Us[(o * 2 + 1) * Uph + gl] = v1 ? muv[1] : make_float2(0.f, 0.f);
                 }
             }
             VAEQ_STAMP(4);
@@ -853,7 +858,7 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
 #pragma unroll
                 for (int v = 0; v < 2; v++) {
                     GY[v * BS + n0] = gy[0][v];
-                    GY[v * BS + n0 + 1] = gy[1][v];
+                    GY[v * BS + n0 + 1] = v1 ? gy[1][v] : make_float2(0.f, 0.f);
                 }
             }
             if (owner && !a.no_update) {
@@ -880,8 +885,9 @@ __global__ __launch_bounds__(64 * NW, VAEQ_WPS) void dp_wave_kernel(const vaeq_d
                 {
                     // sum over n of gy[o, n] conj(x[p, 2n + k]); n runs in pairs (2m, 2m+1): x phase fixed per lane, gy pair = 16 bytes
                     const int tkc = worker ? tk : 0;           // lanes beyond the M taps shadow tap 0
-                    const int Bq = ((B + 2 * NP - 1) / (2 * NP)) << 1;                   // even split points (B is even)
-                    const int ma = (part * Bq) >> 1, mb = min(B, part * Bq + Bq) >> 1;
+                    const int Be = ODDB ? B + (B & 1) : B;     // odd B: the last pair's second symbol has dL/dy = 0
+                    const int Bq = ((Be + 2 * NP - 1) / (2 * NP)) << 1;                  // even split points
+                    const int ma = (part * Bq) >> 1, mb = min(Be, part * Bq + Bq) >> 1;
                     const int cA = tkc, cB = tkc + 2;
                     const float2 *xA = Xs + (cA & 3) * Lph + (cA >> 2) + ma, *xB = Xs + (cB & 3) * Lph + (cB >> 2) + ma;
                     const float2 *G0 = GY + 2 * ma, *G1 = GY + BS + 2 * ma;
