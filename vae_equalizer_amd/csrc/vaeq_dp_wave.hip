@@ -1,5 +1,5 @@
 // vaeq_dp_wave.hip -- dispatch of the wave-per-run DP kernel (vaeq_dp_wave_kernel.h): one wavefront per run for B <= 128 (M = 25: B = 100 and 128 baked,
-// every other even B on the fixed layout of B = 128 -- like all B of the other tap counts; the run-time layout only as M = 25's A/B form); the
+// every other B -- even or odd -- on the fixed layout of B = 128, like all B of the other tap counts; the run-time layout only as M = 25's A/B form); the
 // multi-wave variants for 128 < B <= 1024 are instantiated in vaeq_dp_wave_mw.hip / vaeq_dp_wave_mw8.hip.
 #include <stdlib.h>
 
