@@ -35,6 +35,7 @@ namespace vaeq {
 
 struct NNLayout {
     int C, L, p1, p2, Lx, Lz, mh, Mh, nm, NP, NW1, oW1, oB1, oW2, oB2, oG, oBt, oH;
+    int AS, A0;                                        // row stride / first column of a2 (training, C = 16: zero guard columns around the B logits of a row)
     int xs, z1, zb, bnst, a2, mu, vr, es, VS, th, gr, am, av, ax, w1t, w2t, w2u, red, total;
 };
 
@@ -60,7 +61,16 @@ __host__ __device__ inline NNLayout nn_layout(int B, int sps, int M, int n, int 
     l.zb = bn && !eval ? take(l.C * l.Lz) : l.z1;      // Net_BN: BatchNorm output (fc2's input); z1 then holds the normalised zhat
                                                        // (eval mode folds the running statistics into fc1's epilogue: no second buffer)
     l.bnst = take(bn ? 6 * l.C : 0);                   // mean, rstd (batch) | running_mean, running_var | eval scale, shift
-    l.a2 = take(l.C * B);
+    // training on the MFMA path: the backward pass through fc2 reads dL/dlogits at n + shift, shift in [-4, 4], for whole 16-column tiles -- with
+    // A0 zero columns in front, the row padded to whole tiles + A0 behind and a stride = 4 (mod 8) (conflict-free MFMA operand reads) no read needs a
+    // clamp or a condition (a conditional LDS read costs a branch and an exposed round trip each: mfma_convT16)
+    l.A0 = (n == 8 && !eval) ? 4 : 0;
+    l.AS = B;
+    if (n == 8 && !eval) {
+        l.AS = 16 * ((B + 15) / 16) + 2 * l.A0;
+        while ((l.AS & 7) != 4) l.AS += 4;
+    }
+    l.a2 = take(l.C * l.AS + 2 * l.A0);
     l.mu = take(2 * B); l.vr = take(2 * B);
     l.es = take(2 * l.nm);
     l.VS = take(M);
@@ -171,6 +181,36 @@ __device__ __forceinline__ void nn_transpose_weights(const NNLayout &l, int k1, 
 // D[m = 4 (lane >> 4) + reg][n = lane & 15].  M is always the 16 channels.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ldsv: a 4-byte LDS read the compiler must leave where the source puts it (volatile, LDS address space -- as lds2 in vaeq_wave.h).  Used wherever a
+// read from a CLAMPED (always valid) address feeds a select: an ordinary load is sunk into a branch of its own behind its own s_waitcnt lgkmcnt(0)
+// (the backend will not speculate it), i.e. one exposed LDS round trip per operand -- the pattern round 3 found in the epilogue kernel and, with the ISA
+// in hand, here: 35 such branches per tile group of the transposed convolution.
+// lds1 = ldsv under -DVAEQ_NN_PIN=1: the MFMA loops below fetch the operands of the NEXT k-steps before the matrix instructions of the current ones, and
+// the backend's occupancy-driven scheduler undoes that (each operand read lands directly in front of its v_mfma).  Pinning reads + scheduling fences
+// restores the source order (ISA: twelve reads in flight behind ten back-to-back v_mfma) -- and MEASURES 3.7 % SLOWER (212.6 vs 205.0 us per 2048-run
+// step): with two waves per SIMD the load-use order of one wave interleaves with the other's matrix passes well enough.  Off by default.
+#ifndef VAEQ_NN_PIN
+#define VAEQ_NN_PIN 0                                  // measured: the pinned pipeline is 3.7 % SLOWER than the backend's load-use order (see lds1 below)
+#endif
+typedef const volatile __attribute__((address_space(3))) float lds_cvf;
+__device__ __forceinline__ float ldsv(const float *p) { return *(lds_cvf *)p; }
+__device__ __forceinline__ float lds1(const float *p)
+{
+#if VAEQ_NN_PIN
+    return *(lds_cvf *)p;
+#else
+    return *p;
+#endif
+}
+// ... and the matrix instructions must not be hoisted up to "their" loads either (pure operations: the scheduler places each directly behind the
+// read that feeds it, which is the same exposed round trip again): nothing crosses this fence
+__device__ __forceinline__ void sched_fence()
+{
+#if VAEQ_NN_PIN
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // Conv1d with 16 output channels:  D[c][col] = bias[c] + sum_{kk < K} wt[kk 16 + c] * in[(kk / kd) rstride + kk % kd + col cstep].
 // wt is zero-padded to a multiple of 8 rows.  A wave takes TB column tiles at once: one weight read feeds all of them, and the operands
 // of the next two k-steps are fetched from LDS while the 2 TB MFMAs of the current two run (straight-line code, no division).
@@ -193,10 +233,10 @@ __device__ __forceinline__ void mfma_conv16(const float *wt, int K, int kd, int 
         i += w; k -= w ? kd : 0;
     };
     auto ld = [&](int t, int i, int k, float &a, float (&b)[TB], const int (&colb)[TB]) {
-        a = wt[64 * t + lane];
+        a = lds1(wt + 64 * t + lane);
         const float *bp = in + (4 * t + lg < K ? i * rstride + k : 0);  // padded rows: weight 0, any finite sample
 #pragma unroll
-        for (int u = 0; u < TB; u++) b[u] = bp[colb[u]];
+        for (int u = 0; u < TB; u++) b[u] = lds1(bp + colb[u]);
     };
     for (int tg = wv * TB; tg < ntile; tg += NWV * TB) {
         f32x4 acc[TB];
@@ -220,10 +260,12 @@ __device__ __forceinline__ void mfma_conv16(const float *wt, int K, int kd, int 
                                                                         // wt's padding (another LDS array) are fetched and never used
             ld(tn, i, k, a0, b0, colb); adv(i, k);
             ld(tn + 1, i, k, a1, b1, colb); adv(i, k);
+            sched_fence();
 #pragma unroll
             for (int u = 0; u < TB; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, y0[u], acc[u], 0, 0, 0);
 #pragma unroll
             for (int u = 0; u < TB; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, y1[u], acc[u], 0, 0, 0);
+            sched_fence();
         };
         if constexpr (LEAN) {
 #pragma unroll 1
@@ -273,23 +315,25 @@ __device__ __forceinline__ void mfma_wgrad16(const float *g, int gstride, int nr
             const int sa = 4, sb = 4 * rstep;
             float an[4], bn[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) { an[q] = pa[q * sa]; bn[q] = pb[q * sb]; }       // (in range even when nmain == 0: rows < 4 t0 + 16 <= padded arrays)
+            for (int q = 0; q < 4; q++) { an[q] = lds1(pa + q * sa); bn[q] = lds1(pb + q * sb); }       // (in range even when nmain == 0: rows < 4 t0 + 16 <= padded arrays)
             for (int m = 0; m < nmain; m++) {
                 float av[4], bv[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) { av[q] = an[q]; bv[q] = ones ? 1.0f : bn[q]; }
                 if (m + 1 < nmain) { pa += 4 * sa; pb += 4 * sb; }
 #pragma unroll
-                for (int q = 0; q < 4; q++) { an[q] = pa[q * sa]; bn[q] = pb[q * sb]; }
+                for (int q = 0; q < 4; q++) { an[q] = lds1(pa + q * sa); bn[q] = lds1(pb + q * sb); }
+                sched_fence();
 #pragma unroll
                 for (int q = 0; q < 4; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc[q], 0, 0, 0);
+                sched_fence();
             }
             for (int t = t0 + 4 * nmain; t < t1; t += 4) {
                 float av[4], bv[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {                      // rows past the end (of the array or of this part): clamped reads, zero gradient
                     const int r = 4 * (t + q) + lg, rb = r < nrows ? r : nrows - 1;
-                    const float a_ = gp[rb], b_ = in[joff + rb * rstep];
+                    const float a_ = ldsv(gp + rb), b_ = ldsv(in + joff + rb * rstep);
                     av[q] = (r < nrows && t + q < t1) ? a_ : 0.f;
                     bv[q] = ones ? 1.0f : b_;
                 }
@@ -314,10 +358,14 @@ __device__ __forceinline__ void mfma_wgrad16(const float *g, int gstride, int nr
     }
 }
 
-// Backward through the strided Conv1d fc2 (16 -> 16 channels):  gz[cc][s] = sum_{c, k : (s + p2 - k) % sps == 0} w2u[(k 16 + c) 16 + cc] * g2[c B + (s + p2 - k) / sps],
-// one polyphase component of s at a time (for each only every sps-th tap contributes).  out(cc0, s, acc).
-template <int NT, int TB, typename OutF>
-__device__ __forceinline__ void mfma_convT16(const float *w2u, int k2, int p2, int sps, const float *g2, int B, int L, OutF out)
+// Backward through the strided Conv1d fc2 (16 -> 16 channels):  gz[cc][s] = sum_{c, k : (s + p2 - k) % sps == 0} w2u[(k 16 + c) 16 + cc] * g2[c GS + (s + p2 - k) / sps],
+// one polyphase component of s at a time (for each only every sps-th tap contributes).  g2 = dL/dlogits in the ZERO-GUARDED layout of nn_layout (row
+// stride GS, columns -A0 .. 16 ceil(B / 16) + A0 - 1 readable, zeros outside [0, B)): every operand read is unconditional and pinned, the operands of
+// the next tap are in flight while the current tap's 4 TB matrix instructions run, and the epilogue reads what it needs of the old buffer (pre) for
+// all its outputs before it writes any (post) -- round 2's form had each of these reads in a branch of its own behind its own s_waitcnt lgkmcnt(0)
+// (35 exposed LDS round trips per tile group: 4.1 us for 0.8 us of matrix passes).
+template <int NT, int TB, typename PreF, typename PostF>
+__device__ __forceinline__ void mfma_convT16(const float *w2u, int k2, int p2, int sps, const float *g2, int GS, int L, PreF pre, PostF post)
 {
     constexpr int NWV = NT / 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lc = lane & 15, lg = lane >> 4;
@@ -328,29 +376,53 @@ __device__ __forceinline__ void mfma_convT16(const float *w2u, int k2, int p2, i
             f32x4 acc[TB];
 #pragma unroll
             for (int u = 0; u < TB; u++) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int kj = 0; kj < nk; kj++) {
+            const float *gb = g2 + lg * GS + tg * 16 + lc;                          // + 4 cb GS + 16 u + nsh
+            const float *wb = w2u + lg * 16 + lc;                                   // + (k 16 + 4 cb) 16
+            float av[2][4], bv[2][4][TB];
+            auto ld = [&](int kj, float (&a_)[4], float (&b_)[4][TB]) {
                 const int k = kf + kj * sps, nsh = (ph + p2 - k) / sps;             // exact division (may be negative)
-                float av[4], bv[4][TB];
 #pragma unroll
-                for (int cb = 0; cb < 4; cb++) {                                    // all 4 + 4 TB operands first, then the MFMAs
-                    const int c = 4 * cb + lg;
-                    av[cb] = w2u[(k * 16 + c) * 16 + lc];
+                for (int cb = 0; cb < 4; cb++) {
+                    a_[cb] = lds1(wb + (k * 16 + 4 * cb) * 16);
 #pragma unroll
-                    for (int u = 0; u < TB; u++) {
-                        const int n = (tg + u) * 16 + lc + nsh, nc = n < 0 ? 0 : (n < B ? n : B - 1);
-                        const float b_ = g2[c * B + nc];
-                        bv[cb][u] = (n >= 0 && n < B) ? b_ : 0.f;
-                    }
+                    for (int u = 0; u < TB; u++) b_[cb][u] = lds1(gb + 4 * cb * GS + 16 * u + nsh);
                 }
+            };
+            auto mm = [&](const float (&a_)[4], const float (&b_)[4][TB]) {
 #pragma unroll
                 for (int cb = 0; cb < 4; cb++)
 #pragma unroll
-                    for (int u = 0; u < TB; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb], bv[cb][u], acc[u], 0, 0, 0);
+                    for (int u = 0; u < TB; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[cb], b_[cb][u], acc[u], 0, 0, 0);
+            };
+            if (nk > 0) ld(0, av[0], bv[0]);
+            for (int kj = 0; kj < nk; kj += 2) {                                     // two register sets alternate (no copies)
+                if (kj + 1 < nk) ld(kj + 1, av[1], bv[1]);
+                sched_fence();
+                mm(av[0], bv[0]);
+                sched_fence();
+                if (kj + 1 < nk) {
+                    if (kj + 2 < nk) ld(kj + 2, av[0], bv[0]);
+                    sched_fence();
+                    mm(av[1], bv[1]);
+                    sched_fence();
+                }
             }
+            float old[TB][4];
+#pragma unroll
+            for (int u = 0; u < TB; u++) {
+                const int m = (tg + u) * 16 + lc, mc = m < ncols ? m : ncols - 1;
+#pragma unroll
+                for (int t = 0; t < 4; t++) old[u][t] = pre(4 * lg + t, sps * mc + ph);
+            }
+            sched_fence();
 #pragma unroll
             for (int u = 0; u < TB; u++) {
                 const int m = (tg + u) * 16 + lc;
-                if (m < ncols) out(4 * lg, sps * m + ph, acc[u]);
+                const float gg[4] = {acc[u].x, acc[u].y, acc[u].z, acc[u].w};
+                if (m < ncols) {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) post(4 * lg + t, sps * m + ph, gg[t], old[u][t]);
+                }
             }
         }
     }
@@ -509,7 +581,8 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
     const NNLayout l = BK ? nn_layout(300, SPS ? SPS : 2, 25, NLEV, 25, 3, BN) : nn_layout(B, sps, M, NLEV, k1, k2, BN);
     const int L = l.L, p1 = l.p1, p2 = l.p2, Lx = l.Lx, Lz = l.Lz, mh = l.mh, Mh = l.Mh, nm = l.nm, NP = l.NP;
     float *zb = sm + l.zb, *bnst = sm + l.bnst;                // BN ? separate buffers : zb aliases z1
-    float *xs = sm + l.xs, *z1 = sm + l.z1, *a2 = sm + l.a2, *mu = sm + l.mu, *vr = sm + l.vr, *es = sm + l.es, *VS = sm + l.VS;
+    float *xs = sm + l.xs, *z1 = sm + l.z1, *a2 = sm + l.a2 + l.A0, *mu = sm + l.mu, *vr = sm + l.vr, *es = sm + l.es, *VS = sm + l.VS;
+    const int AS = l.AS;                                       // row stride of a2 (C = 16: zero guard columns around the B logits, nn_layout)
     float *th = sm + l.th, *gr = sm + l.gr, *am = sm + l.am, *av = sm + l.av, *ax = sm + l.ax, *w1t = sm + l.w1t, *w2t = sm + l.w2t, *red = sm + l.red;
     float *w2u = sm + l.w2u;
     const float *hs = th + l.oH;                               // h_est[2][M]: re row, im row
@@ -524,6 +597,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
     }
     for (int i = tid; i < 2 * Lx; i += NT) xs[i] = 0.f;        // halos stay zero
     for (int i = tid; i < C * Lz; i += NT) z1[i] = 0.f;
+    for (int i = tid; i < C * AS + 2 * l.A0; i += NT) sm[l.a2 + i] = 0.f;   // guard columns stay zero
     if (BN) {
         for (int i = tid; i < C * Lz; i += NT) zb[i] = 0.f;
         for (int i = tid; i < 2 * C; i += NT) bnst[2 * C + i] = a.bn_running[(size_t)run * 2 * C + i];
@@ -598,7 +672,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
             }
             __syncthreads();
         }
-        nn_fc2<NT, NLEV, BK == 1 && VAEQ_NN_LEAN>(l, sps, k2, B, B, zb, th, w2t, a2);
+        nn_fc2<NT, NLEV, BK == 1 && VAEQ_NN_LEAN>(l, sps, k2, B, AS, zb, th, w2t, a2);
         __syncthreads();
         // ---- P3: per-axis softmax -> q (in place), moments, entropy term; item = (axis, n)
         float klsum = 0.f, vtot = 0.f;
@@ -606,7 +680,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
             const int axq = it / B, n = it - axq * B;
             float z[NLEV], zmax = -3.0e38f;
 #pragma unroll
-            for (int i = 0; i < NLEV; i++) { z[i] = a2[(axq * NLEV + i) * B + n]; zmax = fmaxf(zmax, z[i]); }
+            for (int i = 0; i < NLEV; i++) { z[i] = a2[(axq * NLEV + i) * AS + n]; zmax = fmaxf(zmax, z[i]); }
             float ssum = 0.f;
 #pragma unroll
             for (int i = 0; i < NLEV; i++) { z[i] = __expf(z[i] - zmax); ssum += z[i]; }
@@ -621,7 +695,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
                 const float d = amp[i] - e1;
                 e2 = fmaf(z[i] * d, d, e2);
                 if (inr) klsum = fmaf(z[i], __logf(z[i] + 1e-12f), klsum);
-                a2[(axq * NLEV + i) * B + n] = z[i];
+                a2[(axq * NLEV + i) * AS + n] = z[i];
                 if (qf) qf[(size_t)(axq * NLEV + i) * No + (size_t)s * B + n] = z[i];
             }
             mu[it] = e1; vr[it] = e2;
@@ -704,7 +778,8 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
                 for (int q = 0; q < 4; q++) {
                     const int t = t0 + q, tc = t < 0 ? 0 : (t < nm ? t : nm - 1);
                     const bool ok = t >= 0 && t < nm && j0 + q < M;    // exactly the symbols tap j0 + q sees
-                    const float a_ = ok ? es[tc] : 0.f, b_ = ok ? es[nm + tc] : 0.f;
+                    const float ea = ldsv(es + tc), eb = ldsv(es + nm + tc);   // clamped address: read unconditionally, then select
+                    const float a_ = ok ? ea : 0.f, b_ = ok ? eb : 0.f;
                     acc[2 * q] = fmaf(a_, c_, acc[2 * q]); acc[2 * q] = fmaf(b_, d_, acc[2 * q]);
                     acc[2 * q + 1] = fmaf(b_, c_, acc[2 * q + 1]); acc[2 * q + 1] = fmaf(-a_, d_, acc[2 * q + 1]);
                 }
@@ -733,13 +808,13 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
                 float q[NLEV], gq[NLEV], dot = 0.f;
 #pragma unroll
                 for (int i = 0; i < NLEV; i++) {
-                    q[i] = a2[(axq * NLEV + i) * B + n];
+                    q[i] = a2[(axq * NLEV + i) * AS + n];
                     gq[i] = amp[i] * gmu + amp[i] * amp[i] * gv;
                     if (inr) gq[i] += __logf(q[i] + 1e-12f) + q[i] * __builtin_amdgcn_rcpf(q[i] + 1e-12f);   // (1-ulp reciprocal: the factor is 1 - 1e-12 / q)
                     dot = fmaf(q[i], gq[i], dot);
                 }
 #pragma unroll
-                for (int i = 0; i < NLEV; i++) a2[(axq * NLEV + i) * B + n] = q[i] * (gq[i] - dot);
+                for (int i = 0; i < NLEV; i++) a2[(axq * NLEV + i) * AS + n] = q[i] * (gq[i] - dot);
             }
         }
         __syncthreads();
@@ -747,7 +822,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
         // ---- P7a: fc2 weight / bias gradients: one wave per (input channel, group of 4 taps); pseudo group at the end: the biases
         if constexpr (C == 16) {
             // gw2[c][cc][k] = sum_n g2[c][n] zb[cc][n sps + k]: columns j = cc k2 + k, plus the bias column
-            mfma_wgrad16<NT>(a2, B, B, zb, sps, C * k2, k2, Lz, mu, 4 * B + 2 * nm, [&](int c0, int j, f32x4 acc) {
+            mfma_wgrad16<NT>(a2, AS, B, zb, sps, C * k2, k2, Lz, mu, 4 * B + 2 * nm, [&](int c0, int j, f32x4 acc) {
                 const float av_[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
@@ -760,7 +835,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
             for (int grp = wv; grp <= ngrp; grp += NWV) {
                 const bool bias = grp == ngrp;
                 const int cc = bias ? 0 : grp / nkq, k0 = bias ? 0 : (grp - cc * nkq) * 4;
-                nn_tapgroup_grad<C>(B, zb + cc * Lz + k0, sps, a2, B, bias, lane, [&](int t, int c, float sum) {
+                nn_tapgroup_grad<C>(B, zb + cc * Lz + k0, sps, a2, AS, bias, lane, [&](int t, int c, float sum) {
                     if (bias) { if (t == 0) gr[l.oB2 + c] = sum; }
                     else if (k0 + t < k2) gr[l.oW2 + (c * C + cc) * k2 + k0 + t] = sum;
                 });
@@ -770,18 +845,13 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
         // ---- P7b: dL/dz1 through fc2, times ELU' -> dL/da1 in place of z1; item = (4 input channels, sample): every dL/dlogit read
         //      feeds the 4 channels, whose weights come as one 16-byte read of the [k][c][cc] copy
         if constexpr (C == 16) {
-            mfma_convT16<NT, 3>(w2u, k2, p2, sps, a2, B, L, [&](int cc0, int sx, f32x4 acc) {
-                const float gg[4] = {acc.x, acc.y, acc.z, acc.w};
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int ix = (cc0 + u) * Lz + p2 + sx;
-                    if (BN) zb[ix] = gg[u];
-                    else {
-                        const float z = z1[ix];
-                        z1[ix] = gg[u] * (z > 0.f ? 1.0f : z + 1.0f);
-                    }
-                }
-            });
+            mfma_convT16<NT, 3>(w2u, k2, p2, sps, a2, AS, L,
+                [&](int cc, int sx) { return BN ? 0.f : z1[cc * Lz + p2 + sx]; },
+                [&](int cc, int sx, float g, float z) {
+                    const int ix = cc * Lz + p2 + sx;
+                    if (BN) zb[ix] = g;
+                    else z1[ix] = g * (z > 0.f ? 1.0f : z + 1.0f);
+                });
         } else
         for (int it = tid; it < CQ * L; it += NT) {
             const int ccq = it / L, sx = it - ccq * L;
@@ -794,7 +864,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
                 const float4 *w = reinterpret_cast<const float4 *>(w2u + (k * C) * C + 4 * ccq);
 #pragma unroll
                 for (int c = 0; c < C; c++) {
-                    const float av_ = a2[c * B + n];
+                    const float av_ = a2[c * AS + n];
                     const float4 w4 = w[c * CQ];
                     g0 = fmaf(w4.x, av_, g0); g1 = fmaf(w4.y, av_, g1); g2 = fmaf(w4.z, av_, g2); g3 = fmaf(w4.w, av_, g3);
                 }
@@ -1086,7 +1156,8 @@ __global__ __launch_bounds__(NT, 2) void nn_train_half_kernel(const vaeq_nn_args
                 for (int q = 0; q < 4; q++) {
                     const int t = t0 + q, tc = t < 0 ? 0 : (t < nm ? t : nm - 1);
                     const bool ok = t >= 0 && t < nm && j0 + q < M;
-                    const float a_ = ok ? es[tc] : 0.f, b_ = ok ? es[nm + tc] : 0.f;
+                    const float ea = ldsv(es + tc), eb = ldsv(es + nm + tc);   // clamped address: read unconditionally, then select
+                    const float a_ = ok ? ea : 0.f, b_ = ok ? eb : 0.f;
                     acc[2 * q] = fmaf(a_, c_, acc[2 * q]); acc[2 * q] = fmaf(b_, d_, acc[2 * q]);
                     acc[2 * q + 1] = fmaf(b_, c_, acc[2 * q + 1]); acc[2 * q + 1] = fmaf(-a_, d_, acc[2 * q + 1]);
                 }
