@@ -36,6 +36,7 @@ namespace vaeq {
 struct NNLayout {
     int C, L, p1, p2, Lx, Lz, mh, Mh, nm, NP, NW1, oW1, oB1, oW2, oB2, oG, oBt, oH;
     int AS, A0;                                        // row stride / first column of a2 (training, C = 16: zero guard columns around the B logits of a row)
+    int ES, PH;                                        // row stride of the zero-guarded residual rows; offset of the |h|^2 prefix sums
     int xs, z1, zb, bnst, a2, mu, vr, es, VS, th, gr, am, av, ax, w1t, w2t, w2u, red, total;
 };
 
@@ -72,8 +73,10 @@ __host__ __device__ inline NNLayout nn_layout(int B, int sps, int M, int n, int 
     }
     l.a2 = take(l.C * l.AS + 2 * l.A0);
     l.mu = take(2 * B); l.vr = take(2 * B);
-    l.es = take(2 * l.nm);
+    l.ES = npad4(l.nm + 2 * l.Mh + 4);                 // Mh zeros | nm residual samples | Mh + 4 zeros (nn_train_kernel)
+    l.es = take(2 * l.ES);
     l.VS = take(M);
+    l.PH = take(M + 1);
     l.th = take(l.NP);
     const int NPt = eval ? 0 : l.NP;                   // gradient and AMSGrad state: training only
     l.gr = take(NPt); l.am = take(NPt); l.av = take(NPt); l.ax = take(NPt);
@@ -570,7 +573,8 @@ __device__ __forceinline__ void nn_fc2(const NNLayout &l, int sps, int k2, int B
 // BK = 1 bakes the sweep script's shape (Eval_run_vaenn.py:25-28: batch_len 300, M = 25, k1 = 25, k2 = 3) into the kernel: the LDS layout and
 // every trip count become constants.
 template <int NT, int NLEV, bool BN, int SPS, int BK = 0>
-__global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
+// (4-QAM: at most 128 registers, so that two workgroups stay resident per CU -- the kernel sits at that edge)
+__global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? NT / 256 : 1)) void nn_train_kernel(const vaeq_nn_args a)
 {
     extern __shared__ float4 smem4[];
     float *sm = reinterpret_cast<float *>(smem4);
@@ -583,6 +587,12 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
     float *zb = sm + l.zb, *bnst = sm + l.bnst;                // BN ? separate buffers : zb aliases z1
     float *xs = sm + l.xs, *z1 = sm + l.z1, *a2 = sm + l.a2 + l.A0, *mu = sm + l.mu, *vr = sm + l.vr, *es = sm + l.es, *VS = sm + l.VS;
     const int AS = l.AS;                                       // row stride of a2 (C = 16: zero guard columns around the B logits, nn_layout)
+    // residual rows with Mh zeros in front and Mh + 4 behind (row stride ES): the correlations of dL/dh and dL/dmu read e[t] for t in [-Mh, nm + Mh + 2)
+    // without clamps, selects or per-lane loop bounds (each of which cost a branch and an exposed LDS round trip per read in round 2's kernel)
+    const int ES = l.ES;
+    float *esr = es + Mh, *esi = es + ES + Mh;
+    float *PH = sm + l.PH;                                     // [M + 1] exclusive prefix sums of |h_j|^2 (the G_V term of dL/dq by two lookups)
+    constexpr int UNR_DQ = NLEV == 2 ? 1 : 5;                  // unrolling of dL/dmu's correlation loop (4-QAM: one more register costs a resident workgroup per CU)
     float *th = sm + l.th, *gr = sm + l.gr, *am = sm + l.am, *av = sm + l.av, *ax = sm + l.ax, *w1t = sm + l.w1t, *w2t = sm + l.w2t, *red = sm + l.red;
     float *w2u = sm + l.w2u;
     const float *hs = th + l.oH;                               // h_est[2][M]: re row, im row
@@ -598,6 +608,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
     for (int i = tid; i < 2 * Lx; i += NT) xs[i] = 0.f;        // halos stay zero
     for (int i = tid; i < C * Lz; i += NT) z1[i] = 0.f;
     for (int i = tid; i < C * AS + 2 * l.A0; i += NT) sm[l.a2 + i] = 0.f;   // guard columns stay zero
+    for (int i = tid; i < 2 * ES; i += NT) es[i] = 0.f;
     if (BN) {
         for (int i = tid; i < C * Lz; i += NT) zb[i] = 0.f;
         for (int i = tid; i < 2 * C; i += NT) bnst[2 * C + i] = a.bn_running[(size_t)run * 2 * C + i];
@@ -724,11 +735,11 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
                 }
                 const int t = 2 * tau;
                 const float er0 = xs[p1 + mh + t] - d0r, ei0 = xs[Lx + p1 + mh + t] - d0i;
-                es[t] = er0; es[nm + t] = ei0;
+                esr[t] = er0; esi[t] = ei0;
                 se += er0 * er0 + ei0 * ei0;
                 if (t + 1 < nm) {
                     const float er1 = xs[p1 + mh + t + 1] - d1r, ei1 = xs[Lx + p1 + mh + t + 1] - d1i;
-                    es[t + 1] = er1; es[nm + t + 1] = ei1;
+                    esr[t + 1] = er1; esi[t + 1] = ei1;
                     se += er1 * er1 + ei1 * ei1;
                 }
             }
@@ -742,7 +753,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
                 di = fmaf(c_, b_, di); di = fmaf(d_, a_, di);
             }
             const float er = xs[p1 + mh + t] - dr, ei = xs[Lx + p1 + mh + t] - di;
-            es[t] = er; es[nm + t] = ei;
+            esr[t] = er; esi[t] = ei;
             se += er * er + ei * ei;
         }
         block_reduce3<NT>(se, klsum, vtot, red);              // vtot: this thread's part of sum_n (v_I + v_Q), collected in P3
@@ -756,6 +767,14 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
             hterm = (hs[j] * hs[j] + hs[M + j] * hs[M + j]) * VS[j];
         }
         if (tid < 64) {                                        // sum_j |h_j|^2 VS[j]: M <= 63 taps, all in wave 0
+            float hq = tid < M ? hs[tid] * hs[tid] + hs[M + tid] * hs[M + tid] : 0.f;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {                 // inclusive prefix sum over the lanes (fixed order)
+                const float up = __shfl_up(hq, d, 64);
+                if (tid >= d) hq += up;
+            }
+            if (tid < M) PH[tid + 1] = hq;
+            if (tid == 0) PH[0] = 0.f;
             hterm = wave_sum(hterm);
             if (tid == 0) red[3] = hterm;
         }
@@ -776,10 +795,8 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
                 const float c_ = mu[np], d_ = mu[B + np];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const int t = t0 + q, tc = t < 0 ? 0 : (t < nm ? t : nm - 1);
-                    const bool ok = t >= 0 && t < nm && j0 + q < M;    // exactly the symbols tap j0 + q sees
-                    const float ea = ldsv(es + tc), eb = ldsv(es + nm + tc);   // clamped address: read unconditionally, then select
-                    const float a_ = ok ? ea : 0.f, b_ = ok ? eb : 0.f;
+                    // e[t0 + q]: zero outside [0, nm) by the guard cells -- exactly the symbols tap j0 + q sees (the sums of taps >= M are never read)
+                    const float a_ = esr[t0 + q], b_ = esi[t0 + q];
                     acc[2 * q] = fmaf(a_, c_, acc[2 * q]); acc[2 * q] = fmaf(b_, d_, acc[2 * q]);
                     acc[2 * q + 1] = fmaf(b_, c_, acc[2 * q + 1]); acc[2 * q + 1] = fmaf(-a_, d_, acc[2 * q + 1]);
                 }
@@ -791,16 +808,16 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
         // ---- P6: dL/dmu, dL/drho -> dL/dq -> softmax backward -> dL/dlogits in place of q; item = n (both axes)
         for (int n = tid; n < B; n += NT) {
             const int sx = n * sps;
-            const int jlo = max(0, Mh - sx), jhi = min(Mh, nm - 1 + Mh - sx);
-            const float *er = es + (sx - Mh), *ei = er + nm;
-            float pr = 0.f, pi = 0.f, ph = 0.f;
-            for (int j = jlo; j <= jhi; j++) {
+            const int jlo = max(0, Mh - sx), jhi = max(jlo - 1, min(Mh, nm - 1 + Mh - sx));
+            const float *er = esr + (sx - Mh), *ei = esi + (sx - Mh);
+            float pr = 0.f, pi = 0.f;
+#pragma unroll UNR_DQ
+            for (int j = 0; j <= Mh; j++) {           // (fully unrolled it parks 50 operands in registers: 88 spilled) uniform trip count: terms outside the tap's range meet zero guard cells
                 const float a_ = er[j], b_ = ei[j], c_ = hs[j], d_ = hs[M + j];
                 pr = fmaf(a_, c_, pr); pr = fmaf(b_, d_, pr);
                 pi = fmaf(b_, c_, pi); pi = fmaf(-a_, d_, pi);
-                ph = fmaf(c_, c_, ph); ph = fmaf(d_, d_, ph);
             }
-            const float gv = gC * ph;
+            const float gv = gC * (PH[jhi + 1] - PH[jlo]);
             const bool inr = (n >= mh) && (n < B - mh);
 #pragma unroll
             for (int axq = 0; axq < 2; axq++) {
@@ -822,7 +839,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
         // ---- P7a: fc2 weight / bias gradients: one wave per (input channel, group of 4 taps); pseudo group at the end: the biases
         if constexpr (C == 16) {
             // gw2[c][cc][k] = sum_n g2[c][n] zb[cc][n sps + k]: columns j = cc k2 + k, plus the bias column
-            mfma_wgrad16<NT>(a2, AS, B, zb, sps, C * k2, k2, Lz, mu, 4 * B + 2 * nm, [&](int c0, int j, f32x4 acc) {
+            mfma_wgrad16<NT>(a2, AS, B, zb, sps, C * k2, k2, Lz, mu, 4 * B, [&](int c0, int j, f32x4 acc) {
                 const float av_[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
@@ -903,7 +920,7 @@ __global__ __launch_bounds__(NT) void nn_train_kernel(const vaeq_nn_args a)
         // ---- P8: fc1 weight / bias gradients, same scheme: one wave per (input row, group of 4 taps)
         if constexpr (C == 16) {
             // gw1[c][i][k] = sum_s gz[c][s] x[i][s + k]: columns j = i k1 + k, plus the bias column
-            mfma_wgrad16<NT>(z1 + p2, Lz, L, xs, 1, 2 * k1, k1, Lx, mu, 4 * B + 2 * nm, [&](int c0, int j, f32x4 acc) {
+            mfma_wgrad16<NT>(z1 + p2, Lz, L, xs, 1, 2 * k1, k1, Lx, mu, 4 * B, [&](int c0, int j, f32x4 acc) {
                 const float av_[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
