@@ -824,10 +824,13 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
                 const float gmu = -2.0f * gC * (axq ? pi : pr) - 2.0f * mu[axq * B + n] * gv;   // incl. the -mu^2 part of the variance
                 float q[NLEV], gq[NLEV], dot = 0.f;
 #pragma unroll
+                for (int i = 0; i < NLEV; i++) q[i] = ldsv(a2 + (axq * NLEV + i) * AS + n);   // all reads of the axis first (pinned: the backend otherwise
+                                                                                                // issues each in front of its own branch + s_waitcnt lgkmcnt(0))
+#pragma unroll
                 for (int i = 0; i < NLEV; i++) {
-                    q[i] = a2[(axq * NLEV + i) * AS + n];
                     gq[i] = amp[i] * gmu + amp[i] * amp[i] * gv;
-                    if (inr) gq[i] += __logf(q[i] + 1e-12f) + q[i] * __builtin_amdgcn_rcpf(q[i] + 1e-12f);   // (1-ulp reciprocal: the factor is 1 - 1e-12 / q)
+                    const float ent = __logf(q[i] + 1e-12f) + q[i] * __builtin_amdgcn_rcpf(q[i] + 1e-12f);   // (1-ulp reciprocal: the factor is 1 - 1e-12 / q)
+                    gq[i] += inr ? ent : 0.f;                  // a select, not a branch per level
                     dot = fmaf(q[i], gq[i], dot);
                 }
 #pragma unroll
