@@ -758,7 +758,27 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
         }
         block_reduce3<NT>(se, klsum, vtot, red);              // vtot: this thread's part of sum_n (v_I + v_Q), collected in P3
         float hterm = 0.f;
-        if (tid < M) {                                         // VS[j] = sum over the symbols tap j sees = total - the few it misses at the ends
+        // VS[j] = sum over the symbols tap j sees = total - the few it misses at either end.  Those are prefixes of the first / last symbols: wave 0 scans
+        // them once (lanes 0-31: symbols 0, 1, ...; lanes 32-63: symbols B - 1, B - 2, ...) and every tap picks its two partial sums with a shuffle -- the
+        // per-tap loops of dependent LDS reads (up to 2 x 12 round trips on 25 lanes while seven waves wait at the barrier) cost 1 us of every step
+        const int nmiss = (Mh + sps - 1) / sps;                // most symbols a tap misses at one end
+        if (nmiss < 32 && nmiss < B) {
+            if (tid < 64) {
+                const int e = tid & 31, back = tid >> 5, npv = back ? B - 1 - e : e;
+                float v = e < nmiss ? ldsv(vr + npv) + ldsv(vr + B + npv) : 0.f;
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) {             // inclusive scan inside each 32-lane half (fixed order)
+                    const float up = __shfl_up(v, d, 32);
+                    if (e >= d) v += up;
+                }
+                const int j = tid < M ? tid : 0, lo = (Mh - j + sps - 1) / sps, hi_ = (nm - 1 + Mh - j) / sps, cnt = B - 1 - hi_;
+                const float mf = __shfl(v, lo > 0 ? lo - 1 : 0, 64), mb = __shfl(v, 32 + (cnt > 0 ? cnt - 1 : 0), 64);
+                if (tid < M) {
+                    VS[j] = red[2] - ((lo > 0 ? mf : 0.f) + (cnt > 0 ? mb : 0.f));
+                    hterm = (hs[j] * hs[j] + hs[M + j] * hs[M + j]) * VS[j];
+                }
+            }
+        } else if (tid < M) {
             const int j = tid, lo = (Mh - j + sps - 1) / sps, hi_ = (nm - 1 + Mh - j) / sps;
             float miss = 0.f;
             for (int np = 0; np < lo; np++) miss += vr[np] + vr[B + np];
