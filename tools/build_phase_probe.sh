@@ -6,6 +6,7 @@ set -e
 ROOT=$(cd $(dirname $0)/.. && pwd); C=$ROOT/vae_equalizer_amd/csrc; V=$ROOT/gpurun_variants/$1prof
 rm -rf $V && mkdir -p $V && cp $C/*.hip $C/*.h $V/
 case $1 in dp_wave) f=vaeq_dp_wave_kernel.h;; nn) f=vaeq_nn.hip;; epilogue) f=vaeq_epilogue.hip;; *) echo "dp_wave|nn|epilogue"; exit 1;; esac
-patch -s $V/$f $ROOT/tools/patches/$1_phase_stamps.patch
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I $ROOT/include -I $V $V/*.hip -lhipfft -o $ROOT/gpurun_variants/libvaeq_$1prof.so
+X=""
+if [ $1 = nn ]; then X="-DVAEQ_NN_STAMPS -DVAEQ_NN_HALF_STAMPS"; else patch -s $V/$f $ROOT/tools/patches/$1_phase_stamps.patch; fi   # the VAE-NN kernels carry their stamps as macros
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $X -I $ROOT/include -I $V $V/*.hip -lhipfft -o $ROOT/gpurun_variants/libvaeq_$1prof.so
 ls -la $ROOT/gpurun_variants/libvaeq_$1prof.so | awk '{print $5, $9}'

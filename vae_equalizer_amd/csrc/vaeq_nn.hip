@@ -48,8 +48,8 @@ __host__ __device__ inline NNLayout nn_layout(int B, int sps, int M, int n, int 
     l.C = 2 * n; l.L = B * sps; l.p1 = k1 / 2; l.p2 = k2 / 2;
     l.Lx = npad4(l.L + 2 * l.p1 + 8);                  // zero halo + room for the 4-wide windows of the last quad
     l.Lz = npad4(l.L + 2 * l.p2 + 4);
-    if (n == 8)                                        // C = 16 (MFMA path): rows 4 (mod 64) dwords apart, so that 16 channels x 4
-        while ((l.Lz & 63) != 4) l.Lz += 4;            // consecutive samples (an MFMA operand / result) fall into 64 different banks
+    if (n == 8)                                        // C = 16 (MFMA path): row stride an odd multiple of 4 dwords, so that 16 channels x 4
+        while ((l.Lz & 7) != 4) l.Lz += 4;             // consecutive samples (an MFMA operand / result) fall into 64 different banks
     l.mh = M / 2; l.Mh = 2 * l.mh; l.nm = l.L - l.Mh;
     l.NW1 = l.C * 2 * k1;
     l.oW1 = 0; l.oB1 = l.NW1; l.oW2 = l.oB1 + l.C; l.oB2 = l.oW2 + l.C * l.C * k2;
@@ -57,9 +57,11 @@ __host__ __device__ inline NNLayout nn_layout(int B, int sps, int M, int n, int 
     l.oH = bn ? l.oBt + l.C : l.oG; l.NP = l.oH + 2 * M;
     int o = 0;
     auto take = [&](int cnt) { int r = o; o += npad4(cnt); return r; };
-    l.xs = take(2 * l.Lx);
-    l.z1 = take(l.C * l.Lz);
-    l.zb = bn && !eval ? take(l.C * l.Lz) : l.z1;      // Net_BN: BatchNorm output (fc2's input); z1 then holds the normalised zhat
+    const int one = (n == 8 && !eval) ? 1 : 0;         // training on the MFMA path: a row of ones behind the input rows and behind the channel rows (the
+                                                       // bias columns of the weight-gradient GEMMs read it like any other operand row: mfma_wgrad16, ROW1)
+    l.xs = take((2 + one) * l.Lx);
+    l.z1 = take((l.C + (bn ? 0 : one)) * l.Lz);         // (Net_BN: fc2's input, and with it the row of ones, is zb)
+    l.zb = bn && !eval ? take((l.C + one) * l.Lz) : l.z1;      // Net_BN: BatchNorm output (fc2's input); z1 then holds the normalised zhat
                                                        // (eval mode folds the running statistics into fc1's epilogue: no second buffer)
     l.bnst = take(bn ? 6 * l.C : 0);                   // mean, rstd (batch) | running_mean, running_var | eval scale, shift
     // training on the MFMA path: the backward pass through fc2 reads dL/dlogits at n + shift, shift in [-4, 4], for whole 16-column tiles -- with
@@ -213,6 +215,25 @@ __device__ __forceinline__ void sched_fence()
     __builtin_amdgcn_sched_barrier(0);
 #endif
 }
+#ifndef VAEQ_NN_PIN_WG
+#define VAEQ_NN_PIN_WG 0                               // the same for the weight-gradient loops alone (A/B)
+#endif
+__device__ __forceinline__ float lds1w(const float *p)
+{
+#if VAEQ_NN_PIN_WG
+    return *(lds_cvf *)p;
+#else
+    return lds1(p);
+#endif
+}
+__device__ __forceinline__ void sched_fence_w()
+{
+#if VAEQ_NN_PIN_WG
+    __builtin_amdgcn_sched_barrier(0);
+#else
+    sched_fence();
+#endif
+}
 
 // Conv1d with 16 output channels:  D[c][col] = bias[c] + sum_{kk < K} wt[kk 16 + c] * in[(kk / kd) rstride + kk % kd + col cstep].
 // wt is zero-padded to a multiple of 8 rows.  A wave takes TB column tiles at once: one weight read feeds all of them, and the operands
@@ -289,7 +310,11 @@ __device__ __forceinline__ void mfma_conv16(const float *wt, int K, int kd, int 
 // combined through `scratch` (cap floats; every thread of the block must make this call: it may hold a barrier).  Four k-steps of
 // operands are fetched per trip, four accumulators take them in turn.
 // out(c0, j, acc): the lane's channels c0 .. c0 + 3 of column j <= J.
-template <int NT, typename OutF>
+// ROW1: `in` carries a row of ones as row J / kd (J a multiple of kd) and every operand array may be read up to 16 rows past its end: the bias column is
+// then a column like any other, the pointers advance unconditionally and the trip count is a scalar -- per four matrix instructions two vector
+// instructions instead of twelve (four selects, a guarded pointer advance, an exec-mask loop).  That matters more than it looks: on gfx950 the f32 MFMA
+// runs on the vector FMA pipe, so every vector instruction inside an MFMA loop ADDS to the loop's time instead of hiding behind the matrix passes.
+template <int NT, bool ROW1 = false, typename OutF>
 __device__ __forceinline__ void mfma_wgrad16(const float *g, int gstride, int nrows, const float *in, int rstep, int J, int kd, int rstride,
                                              float *scratch, int cap, OutF out)
 {
@@ -306,30 +331,55 @@ __device__ __forceinline__ void mfma_wgrad16(const float *g, int gstride, int nr
         for (int q = 0; q < 4; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (part < nsplit) {
             const int j = tile * 16 + lc;
-            const int ji = j < J ? j / kd : 0, joff = j < J ? ji * rstride + (j - ji * kd) : 0;
-            const bool ones = j == J;
+            const int ji = (ROW1 || j < J) ? j / kd : 0, joff = (ROW1 || j < J) ? ji * rstride + (j - ji * kd) : 0;
+            const bool ones = !ROW1 && j == J;
             const float *gp = g + lc * gstride;
             const int t1 = min(steps, (part + 1) * sp);
             // main trips: four k-steps whose rows all exist -- plain pointer walks, the next trip's operands are fetched while the
             // current four MFMAs run; the (at most one) ragged trip at the end of the row range takes the clamped path below
             const int t0 = part * sp, tfull = nrows >> 2;
-            const int nmain = max(0, (min(t1, tfull) - t0) >> 2);
+            int nmain = max(0, (min(t1, tfull) - t0) >> 2);
+            if constexpr (ROW1) nmain = __builtin_amdgcn_readfirstlane(nmain);     // (uniform over the wave: part and tile are)
             const float *pa = gp + 4 * t0 + lg, *pb = in + joff + (4 * t0 + lg) * rstep;
             const int sa = 4, sb = 4 * rstep;
             float an[4], bn[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) { an[q] = lds1(pa + q * sa); bn[q] = lds1(pb + q * sb); }       // (in range even when nmain == 0: rows < 4 t0 + 16 <= padded arrays)
+            for (int q = 0; q < 4; q++) { an[q] = lds1w(pa + q * sa); bn[q] = lds1w(pb + q * sb); }       // (in range even when nmain == 0: rows < 4 t0 + 16 <= padded arrays)
+            if constexpr (ROW1) {
+                // two operand sets alternate (no register copies): trip m + 1 is fetched before trip m's matrix instructions, trip m + 2 before those of m + 1
+                float a1[4], b1[4];
+                auto mma = [&](const float (&x)[4], const float (&y)[4]) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[q], y[q], acc[q], 0, 0, 0);
+                };
+                int m = 0;
+                for (; m + 2 <= nmain; m += 2) {
+                    pa += 4 * sa; pb += 4 * sb;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { a1[q] = lds1w(pa + q * sa); b1[q] = lds1w(pb + q * sb); }
+                    sched_fence_w();
+                    mma(an, bn);
+                    sched_fence_w();
+                    pa += 4 * sa; pb += 4 * sb;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { an[q] = lds1w(pa + q * sa); bn[q] = lds1w(pb + q * sb); }   // (past the last trip: read, never used)
+                    sched_fence_w();
+                    mma(a1, b1);
+                    sched_fence_w();
+                }
+                if (m < nmain) mma(an, bn);
+            } else
             for (int m = 0; m < nmain; m++) {
                 float av[4], bv[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) { av[q] = an[q]; bv[q] = ones ? 1.0f : bn[q]; }
                 if (m + 1 < nmain) { pa += 4 * sa; pb += 4 * sb; }
 #pragma unroll
-                for (int q = 0; q < 4; q++) { an[q] = lds1(pa + q * sa); bn[q] = lds1(pb + q * sb); }
-                sched_fence();
+                for (int q = 0; q < 4; q++) { an[q] = lds1w(pa + q * sa); bn[q] = lds1w(pb + q * sb); }
+                sched_fence_w();
 #pragma unroll
                 for (int q = 0; q < 4; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc[q], 0, 0, 0);
-                sched_fence();
+                sched_fence_w();
             }
             for (int t = t0 + 4 * nmain; t < t1; t += 4) {
                 float av[4], bv[4];
@@ -609,6 +659,10 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
     for (int i = tid; i < C * Lz; i += NT) z1[i] = 0.f;
     for (int i = tid; i < C * AS + 2 * l.A0; i += NT) sm[l.a2 + i] = 0.f;   // guard columns stay zero
     for (int i = tid; i < 2 * ES; i += NT) es[i] = 0.f;
+    if constexpr (C == 16) {                                   // the rows of ones (nn_layout)
+        for (int i = tid; i < Lx; i += NT) xs[2 * Lx + i] = 1.0f;
+        for (int i = tid; i < Lz; i += NT) zb[C * Lz + i] = 1.0f;   // (zb aliases z1 without BatchNorm)
+    }
     if (BN) {
         for (int i = tid; i < C * Lz; i += NT) zb[i] = 0.f;
         for (int i = tid; i < 2 * C; i += NT) bnst[2 * C + i] = a.bn_running[(size_t)run * 2 * C + i];
@@ -646,7 +700,14 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
     };
     if constexpr (PREF) { load_minibatch(0); store_minibatch(); __syncthreads(); }
 
+#ifdef VAEQ_NN_STAMPS
+    __shared__ long long tstamp[16];                            // -DVAEQ_NN_STAMPS: wall-clock stamps of run 0's last step (tools/probe_nn_phases.py)
+#define NN_STAMP(i) do { __syncthreads(); if (tid == 0 && run == 0 && s == a.steps - 1) tstamp[i] = wall_clock64(); } while (0)
+#else
+#define NN_STAMP(i) do { } while (0)
+#endif
     for (int s = 0; s < a.steps; s++) {
+        NN_STAMP(0);
         // ---- P0: minibatch -> LDS (:276)
         if constexpr (!PREF) {
             for (int i = tid; i < 2 * L; i += NT) {
@@ -655,6 +716,7 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
             }
             __syncthreads();
         }
+        NN_STAMP(1);
         // ---- P1/P2: fc1 + ELU, fc2
         nn_fc1_elu<NT, NLEV, BK == 1 && VAEQ_NN_LEAN>(l, k1, xs, th, w1t, z1, L, 0, L);
         __syncthreads();
@@ -685,6 +747,7 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
         }
         nn_fc2<NT, NLEV, BK == 1 && VAEQ_NN_LEAN>(l, sps, k2, B, AS, zb, th, w2t, a2);
         __syncthreads();
+        NN_STAMP(2);
         // ---- P3: per-axis softmax -> q (in place), moments, entropy term; item = (axis, n)
         float klsum = 0.f, vtot = 0.f;
         for (int it = tid; it < 2 * B; it += NT) {
@@ -713,6 +776,7 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
             vtot += e2;
         }
         __syncthreads();
+        NN_STAMP(3);
         // ---- P4: residual e = x - D (item t), VS (item j), C
         float se = 0.f;
         if (sps == 2) {
@@ -802,6 +866,7 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
         const float Cc = red[0] + red[3];
         const float gC = (float)nm / Cc;
         if (tid == 0 && a.loss) a.loss[(size_t)run * a.steps + s] = (float)nm * logf(Cc) + red[1];
+        NN_STAMP(4);
         // ---- P5: dL/dh[j] = gC (-2 sum_np e[np sps - Mh + j] conj(mu[np]) + 2 h[j] VS[j]): one wave per group of 4 taps -- a symbol's mu and
         //      4 + 4 adjacent residual samples give 16 FMAs; the 8 partial sums of the group share one reduce-scatter
         for (int jg = wv; 4 * jg < M; jg += NWV) {
@@ -825,6 +890,7 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
             const int idx = wave_reduce_channel<8>(lane), j = j0 + (idx >> 1), im = idx & 1;
             if ((lane & 7) == 0 && j < M) gr[l.oH + im * M + j] = gC * (-2.0f * sum + 2.0f * hs[im * M + j] * VS[j]);
         }
+        NN_STAMP(5);
         // ---- P6: dL/dmu, dL/drho -> dL/dq -> softmax backward -> dL/dlogits in place of q; item = n (both axes)
         for (int n = tid; n < B; n += NT) {
             const int sx = n * sps;
@@ -859,10 +925,11 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
         }
         __syncthreads();
         if constexpr (PREF) { if (s + 1 < a.steps) load_minibatch(s + 1); }
+        NN_STAMP(6);
         // ---- P7a: fc2 weight / bias gradients: one wave per (input channel, group of 4 taps); pseudo group at the end: the biases
         if constexpr (C == 16) {
             // gw2[c][cc][k] = sum_n g2[c][n] zb[cc][n sps + k]: columns j = cc k2 + k, plus the bias column
-            mfma_wgrad16<NT>(a2, AS, B, zb, sps, C * k2, k2, Lz, mu, 4 * B, [&](int c0, int j, f32x4 acc) {
+            mfma_wgrad16<NT, true>(a2, AS, B, zb, sps, C * k2, k2, Lz, mu, 4 * B, [&](int c0, int j, f32x4 acc) {
                 const float av_[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
@@ -882,6 +949,7 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
             }
         }
         __syncthreads();
+        NN_STAMP(7);
         // ---- P7b: dL/dz1 through fc2, times ELU' -> dL/da1 in place of z1; item = (4 input channels, sample): every dL/dlogit read
         //      feeds the 4 channels, whose weights come as one 16-byte read of the [k][c][cc] copy
         if constexpr (C == 16) {
@@ -940,10 +1008,11 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
             }
             __syncthreads();
         }
+        NN_STAMP(8);
         // ---- P8: fc1 weight / bias gradients, same scheme: one wave per (input row, group of 4 taps)
         if constexpr (C == 16) {
             // gw1[c][i][k] = sum_s gz[c][s] x[i][s + k]: columns j = i k1 + k, plus the bias column
-            mfma_wgrad16<NT>(z1 + p2, Lz, L, xs, 1, 2 * k1, k1, Lx, mu, 4 * B, [&](int c0, int j, f32x4 acc) {
+            mfma_wgrad16<NT, true>(z1 + p2, Lz, L, xs, 1, 2 * k1, k1, Lx, mu, 4 * B, [&](int c0, int j, f32x4 acc) {
                 const float av_[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
@@ -964,6 +1033,7 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
             }
         }
         __syncthreads();
+        NN_STAMP(9);
         // ---- P9: Adam(amsgrad) on every parameter (:285)
         step += 1;
         b1t *= 0.9;
@@ -976,6 +1046,10 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
             nn_transpose_weights<NT, NLEV>(l, k1, k2, th, w1t, w2t, w2u);
         }
         __syncthreads();
+        NN_STAMP(10);
+#ifdef VAEQ_NN_STAMPS
+        if (tid < 10 && run == 0 && s == a.steps - 1 && a.loss) a.loss[tid] = (float)(tstamp[tid + 1] - tstamp[tid]);
+#endif
     }
     for (int i = tid; i < NP; i += NT) {
         const size_t g = (size_t)run * NP + i;
