@@ -159,12 +159,29 @@ __device__ __forceinline__ void nn_tapgroup_grad(int n_rows, const float *in, in
     }
 }
 
+// the lane-group walks of the two convolutions (mfma_conv16 below; shared by nn_transpose_weights and the callers)
+__host__ __device__ inline int conv16_fc1_steps(int k1) { return (((k1 + 1) / 2) + 1) & ~1; }      // taps of a half, rounded up to whole trips
+__host__ __device__ inline int conv16_fc2_steps(int k2) { return 4 * k2; }
+
 // ---- transposed weight copies (after every parameter update): w1t[(i k1 + k) C + c], w2t[(cc k2 + k) C + c]
 template <int NT, int NLEV>
 __device__ __forceinline__ void nn_transpose_weights(const NNLayout &l, int k1, int k2, const float *th, float *w1t, float *w2t,
                                                      float *w2u = nullptr)
 {
     constexpr int C = 2 * NLEV;
+    if constexpr (C == 16) {
+        // the walk order of mfma_conv16: w1t[(4 t + lg) 16 + c] = fc1.weight[c][lg >> 1][(lg & 1) Th + t] (0 past the half / past k1),
+        //                                w2t[(4 t + lg) 16 + c] = fc2.weight[c][4 lg + t / k2][t % k2]
+        const int T1 = conv16_fc1_steps(k1), Th = (k1 + 1) / 2;
+        for (int j = threadIdx.x; j < 64 * T1; j += NT) {
+            const int c = j & 15, lg = (j >> 4) & 3, t = j >> 6, i = lg >> 1, k = (lg & 1) * Th + t;
+            w1t[j] = (t < Th && k < k1) ? th[l.oW1 + (c * 2 + i) * k1 + k] : 0.f;
+        }
+        for (int j = threadIdx.x; j < 64 * 4 * k2; j += NT) {
+            const int c = j & 15, lg = (j >> 4) & 3, t = j >> 6, cc = 4 * lg + t / k2, k = t % k2;
+            w2t[j] = th[l.oW2 + (c * C + cc) * k2 + k];
+        }
+    } else {
     for (int j = threadIdx.x; j < l.NW1; j += NT) {
         const int c = j % C, ik = j / C, i = ik / k1, k = ik - i * k1;
         w1t[j] = th[l.oW1 + (c * 2 + i) * k1 + k];
@@ -174,6 +191,7 @@ __device__ __forceinline__ void nn_transpose_weights(const NNLayout &l, int k1, 
         w2t[j] = th[l.oW2 + (c * C + cc) * k2 + k];
     }
     for (int j = threadIdx.x; j < 7 * C; j += NT) w1t[l.NW1 + j] = w2t[C * C * k2 + j] = 0.f;
+    }
     if (w2u)
         for (int j = threadIdx.x; j < C * C * k2; j += NT) {
             const int cc = j % C, r = j / C, c = r % C, k = r / C;
@@ -235,55 +253,50 @@ __device__ __forceinline__ void sched_fence_w()
 #endif
 }
 
-// Conv1d with 16 output channels:  D[c][col] = bias[c] + sum_{kk < K} wt[kk 16 + c] * in[(kk / kd) rstride + kk % kd + col cstep].
-// wt is zero-padded to a multiple of 8 rows.  A wave takes TB column tiles at once: one weight read feeds all of them, and the operands
-// of the next two k-steps are fetched from LDS while the 2 TB MFMAs of the current two run (straight-line code, no division).
+// Conv1d with 16 output channels:  D[c][col] = bias[c] + sum over the (input row, tap) pairs of  w * in[row rstride + tap + col cstep].
+// The 4 k-rows of a v_mfma_f32_16x16x4_f32 (lane group lg = lane >> 4) do NOT take four consecutive (row, tap) pairs: each group WALKS ITS OWN
+// sequence -- fc1 (2 input rows): group lg owns row lg >> 1 and the taps of half lg & 1; fc2 (16 rows): group lg owns rows 4 lg .. 4 lg + 3, tap by tap
+// -- so that the sample offset of k-step t is  lbase(lane) + off(t)  with off(t) THE SAME for all lanes: a scalar (an instruction immediate once the
+// shape is baked) instead of per-lane index arithmetic for every operand read.  On gfx950 the f32 MFMA runs on the vector FMA pipe: a vector
+// instruction inside the loop does not hide behind the matrix passes, it adds to them (round 2's loop: 22 vector instructions per 10 MFMAs).
+//   off(t) walks:  k = t, t + 1, ... ; at k == kdw: k = 0 and the base advances by rstride   (fc1: kdw = INT_MAX: off(t) = t)
+//   wt[(4 t + lg) 16 + c] = weight of channel c for the pair group lg reaches at step t (0 where it has none): nn_transpose_weights
+// T k-steps (even: a trip = two k-steps; the operands of the next trip are fetched while the current 2 TB MFMAs run).  Columns past ncols (the last
+// tile, and tiles past the last one) are READ -- from padded or neighbouring, always finite LDS cells -- and dropped: no clamps.
 // out(c0, col, acc): the lane's channels c0 .. c0 + 3 of column col.
-// LEAN: the k-step loop stays a loop when its trip count is a constant (unrolled it keeps every trip's operands in flight: + 60 registers).
 template <int NT, int TB, bool LEAN = false, typename OutF>
-__device__ __forceinline__ void mfma_conv16(const float *wt, int K, int kd, int rstride, const float *in, int cstep, int ncols, const float *bias,
-                                            OutF out)
+__device__ __forceinline__ void mfma_conv16(const float *wt, int T, int lbase, int kdw, int rstride, const float *in, int cstep, int ncols,
+                                            const float *bias, OutF out)
 {
     constexpr int NWV = NT / 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lc = lane & 15, lg = lane >> 4;
-    const int ntile = (ncols + 15) >> 4, K8 = (K + 7) >> 3;             // trips of two k-steps (wt is padded to 8 rows by its owner)
+    const int ntile = (ncols + 15) >> 4, K8 = T >> 1;
     const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias + 4 * lg);
-    // sample offset of the lane's row kk = 4 t + lg: (kk / kd) rstride + kk % kd, advanced by 4 rows per k-step without a division
-    const int q4 = 4 / kd, r4 = 4 - q4 * kd;                            // 4 = q4 kd + r4
-    const int i0 = lg / kd, k0 = lg - i0 * kd;
-    auto adv = [&](int &i, int &k) {
-        i += q4; k += r4;
-        const bool w = k >= kd;
-        i += w; k -= w ? kd : 0;
-    };
-    auto ld = [&](int t, int i, int k, float &a, float (&b)[TB], const int (&colb)[TB]) {
-        a = lds1(wt + 64 * t + lane);
-        const float *bp = in + (4 * t + lg < K ? i * rstride + k : 0);  // padded rows: weight 0, any finite sample
-#pragma unroll
-        for (int u = 0; u < TB; u++) b[u] = lds1(bp + colb[u]);
-    };
     for (int tg = wv * TB; tg < ntile; tg += NWV * TB) {
         f32x4 acc[TB];
-        int colb[TB];
 #pragma unroll
-        for (int u = 0; u < TB; u++) {
-            acc[u] = b4;
-            const int col = (tg + u) * 16 + lc;
-            colb[u] = (col < ncols ? col : ncols - 1) * cstep;         // clamped columns are computed and dropped
-        }
-        int i = i0, k = k0;
+        for (int u = 0; u < TB; u++) acc[u] = b4;
+        const float *bp = in + lbase + (tg * 16 + lc) * cstep;          // tile u: + 16 u cstep
+        int ob = 0, ok = 0;                                             // off(t) = ob + ok (uniform)
+        auto ld = [&](int t, float &a, float (&b)[TB]) {
+            a = lds1(wt + 64 * t + lane);
+#pragma unroll
+            for (int u = 0; u < TB; u++) b[u] = lds1(bp + ob + ok + 16 * u * cstep);
+            ok++;
+            if (ok == kdw) { ok = 0; ob += rstride; }
+        };
         float a0, a1, b0[TB], b1[TB];
-        ld(0, i, k, a0, b0, colb); adv(i, k);
-        ld(1, i, k, a1, b1, colb); adv(i, k);
+        ld(0, a0, b0);
+        ld(1, a1, b1);
         auto trip = [&](int t2) {
             const float x0 = a0, x1 = a1;
             float y0[TB], y1[TB];
 #pragma unroll
             for (int u = 0; u < TB; u++) { y0[u] = b0[u]; y1[u] = b1[u]; }
-            const int tn = 2 * t2 + 2;                                  // past the end: rows >= K (sample offset 0) and the 128 floats behind
-                                                                        // wt's padding (another LDS array) are fetched and never used
-            ld(tn, i, k, a0, b0, colb); adv(i, k);
-            ld(tn + 1, i, k, a1, b1, colb); adv(i, k);
+            const int tn = 2 * t2 + 2;                                  // past the end: the walk simply continues (finite cells), and the 128 floats
+                                                                        // behind wt (another LDS array) are fetched; neither is used
+            ld(tn, a0, b0);
+            ld(tn + 1, a1, b1);
             sched_fence();
 #pragma unroll
             for (int u = 0; u < TB; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, y0[u], acc[u], 0, 0, 0);
@@ -304,7 +317,6 @@ __device__ __forceinline__ void mfma_conv16(const float *wt, int K, int kd, int 
         }
     }
 }
-
 // Weight gradient of such a convolution:  G[c][j] = sum_{r < nrows} g[c gstride + r] * in[(j / kd) rstride + j % kd + r rstep]  for j < J,
 // and the bias gradient G[c][J] = sum_r g[c gstride + r] as one more column.  Waves = (column tile, part of the row range); parts are
 // combined through `scratch` (cap floats; every thread of the block must make this call: it may hold a barrier).  Four k-steps of
@@ -533,7 +545,8 @@ __device__ __forceinline__ void nn_fc1_elu(const NNLayout &l, int k1, const floa
     // z1p[c][p2 + s] for s in [0, Lvalid); entries whose absolute position (zlo + s) lies outside [0, zhi) are fc2's zero padding
     constexpr int C = 2 * NLEV, CQ = C / 4;
     if constexpr (C == 16) {
-        mfma_conv16<NT, (NT >= 1024 ? 2 : 5), LEAN>(w1t, 2 * k1, k1, l.Lx, xs, 1, Lvalid, th + l.oB1, [&](int c0, int sy, f32x4 acc) {
+        const int lg = (threadIdx.x & 63) >> 4;
+        mfma_conv16<NT, (NT >= 1024 ? 2 : 5), LEAN>(w1t, conv16_fc1_steps(k1), (lg >> 1) * l.Lx + (lg & 1) * ((k1 + 1) / 2), 0x7fffffff, 0, xs, 1, Lvalid, th + l.oB1, [&](int c0, int sy, f32x4 acc) {
             const int pos = zlo + sy;
             const bool in = pos >= 0 && pos < zhi;
             const float av[4] = {acc.x, acc.y, acc.z, acc.w};
@@ -587,7 +600,8 @@ __device__ __forceinline__ void nn_fc2(const NNLayout &l, int sps, int k2, int B
 {
     constexpr int C = 2 * NLEV, CQ = C / 4;
     if constexpr (C == 16) {
-        mfma_conv16<NT, (NT >= 1024 ? 1 : 3), LEAN>(w2t, C * k2, k2, l.Lz, z1, sps, Bt, th + l.oB2, [&](int c0, int n, f32x4 acc) {
+        const int lg = (threadIdx.x & 63) >> 4;
+        mfma_conv16<NT, (NT >= 1024 ? 1 : 3), LEAN>(w2t, conv16_fc2_steps(k2), 4 * lg * l.Lz, k2, l.Lz, z1, sps, Bt, th + l.oB2, [&](int c0, int n, f32x4 acc) {
             a2[(c0 + 0) * astride + n] = acc.x; a2[(c0 + 1) * astride + n] = acc.y;
             a2[(c0 + 2) * astride + n] = acc.z; a2[(c0 + 3) * astride + n] = acc.w;
         });
