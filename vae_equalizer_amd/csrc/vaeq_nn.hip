@@ -735,13 +735,26 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
         nn_fc1_elu<NT, NLEV, BK == 1 && VAEQ_NN_LEAN>(l, k1, xs, th, w1t, z1, L, 0, L);
         __syncthreads();
         if (BN) {                                              // BatchNorm1d in training mode (:203): batch statistics over the L samples
+            constexpr int NVM = 10;                            // a lane's share of a channel row stays in registers when L <= 640 (the three passes
+            const bool inreg = NLEV != 2 && L <= 64 * NVM;     // over the row were three chains of dependent LDS reads; same summation order either way;
+                                                               // not for 4-QAM: its 128-register budget -- two workgroups per CU -- has no room for the row)
             for (int c = wv; c < C; c += NWV) {
                 float *zr = z1 + c * Lz + p2;
-                float sm_ = 0.f;
-                for (int sx = lane; sx < L; sx += 64) sm_ += zr[sx];
+                float zv[NVM];
+                float sm_ = 0.f, sv = 0.f;
+                if (inreg) {
+#pragma unroll
+                    for (int u = 0; u < NVM; u++) { const int sx = lane + 64 * u; zv[u] = ldsv(zr + (sx < L ? sx : L - 1)); }
+#pragma unroll
+                    for (int u = 0; u < NVM; u++) sm_ += lane + 64 * u < L ? zv[u] : 0.f;
+                } else
+                    for (int sx = lane; sx < L; sx += 64) sm_ += zr[sx];
                 const float mean = wave_sum(sm_) / (float)L;
-                float sv = 0.f;
-                for (int sx = lane; sx < L; sx += 64) { const float d = zr[sx] - mean; sv = fmaf(d, d, sv); }
+                if (inreg) {
+#pragma unroll
+                    for (int u = 0; u < NVM; u++) { const float d = zv[u] - mean; sv = lane + 64 * u < L ? fmaf(d, d, sv) : sv; }
+                } else
+                    for (int sx = lane; sx < L; sx += 64) { const float d = zr[sx] - mean; sv = fmaf(d, d, sv); }
                 const float var = wave_sum(sv) / (float)L, rstd = 1.0f / sqrtf(var + 1e-5f);
                 if (lane == 0) {
                     bnst[c] = mean; bnst[C + c] = rstd;
@@ -751,6 +764,14 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
                     }
                 }
                 const float ga = th[l.oG + c], be = th[l.oBt + c];
+                if (inreg) {
+#pragma unroll
+                    for (int u = 0; u < NVM; u++) {
+                        const int sx = lane + 64 * u;
+                        const float zh = (zv[u] - mean) * rstd;
+                        if (sx < L) { zr[sx] = zh; zb[c * Lz + p2 + sx] = fmaf(ga, zh, be); }
+                    }
+                } else
                 for (int sx = lane; sx < L; sx += 64) {
                     const float zh = (zr[sx] - mean) * rstd;
                     zr[sx] = zh;                               // z1 keeps zhat for the backward pass
@@ -1008,11 +1029,34 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
                 float *zr = z1 + c * Lz + p2;
                 const float *gp = zb + c * Lz + p2;
                 float s1 = 0.f, s2 = 0.f;
-                for (int sx = lane; sx < L; sx += 64) { s1 += gp[sx]; s2 = fmaf(gp[sx], zr[sx], s2); }
+                constexpr int NVM = 10;
+                const bool inreg = NLEV != 2 && L <= 64 * NVM; // as in the forward pass: the row's values are read once, into registers
+                float gv[NVM], zv[NVM];
+                if (inreg) {
+#pragma unroll
+                    for (int u = 0; u < NVM; u++) {
+                        const int sx = lane + 64 * u, sc = sx < L ? sx : L - 1;
+                        gv[u] = ldsv(gp + sc); zv[u] = ldsv(zr + sc);
+                    }
+#pragma unroll
+                    for (int u = 0; u < NVM; u++)
+                        if (lane + 64 * u < L) { s1 += gv[u]; s2 = fmaf(gv[u], zv[u], s2); }
+                } else
+                    for (int sx = lane; sx < L; sx += 64) { s1 += gp[sx]; s2 = fmaf(gp[sx], zr[sx], s2); }
                 s1 = wave_sum(s1);
                 s2 = wave_sum(s2);
                 if (lane == 0) { gr[l.oG + c] = s2; gr[l.oBt + c] = s1; }
                 const float mean = bnst[c], rstd = bnst[C + c], gs = th[l.oG + c] * rstd, m1 = s1 / (float)L, m2 = s2 / (float)L;
+                if (inreg) {
+#pragma unroll
+                    for (int u = 0; u < NVM; u++) {
+                        const int sx = lane + 64 * u;
+                        const float zh = zv[u];
+                        const float gz = gs * (gv[u] - m1 - zh * m2);
+                        const float z = zh / rstd + mean;      // ELU output before the normalisation
+                        if (sx < L) zr[sx] = gz * (z > 0.f ? 1.0f : z + 1.0f);
+                    }
+                } else
                 for (int sx = lane; sx < L; sx += 64) {
                     const float zh = zr[sx];
                     const float gz = gs * (gp[sx] - m1 - zh * m2);
