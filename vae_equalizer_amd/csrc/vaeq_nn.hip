@@ -328,7 +328,7 @@ __device__ __forceinline__ void mfma_conv16(const float *wt, int T, int lbase, i
 // runs on the vector FMA pipe, so every vector instruction inside an MFMA loop ADDS to the loop's time instead of hiding behind the matrix passes.
 template <int NT, bool ROW1 = false, typename OutF>
 __device__ __forceinline__ void mfma_wgrad16(const float *g, int gstride, int nrows, const float *in, int rstep, int J, int kd, int rstride,
-                                             float *scratch, int cap, OutF out)
+                                             float *scratch, int cap, OutF out, int zpad = 0)
 {
     constexpr int NWV = NT / 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lc = lane & 15, lg = lane >> 4;
@@ -336,6 +336,12 @@ __device__ __forceinline__ void mfma_wgrad16(const float *g, int gstride, int nr
     int nsplit = NWV / ntw;
     if ((nsplit - 1) * ntw * 256 > cap) nsplit = 1 + cap / (ntw * 256);
     const int tile0 = wv % ntw, part = wv / ntw;
+    // ROW1: g is ZERO in the zpad rows behind nrows (zero halo / guard cells of its array): when that covers it, the row range is rounded up to whole trips
+    // of four k-steps and no part has a ragged last trip (the clamped path below: ~100 instructions and eight serial reads for two or three k-steps)
+    if constexpr (ROW1) {
+        const int up = (nrows + 15) & ~15;
+        if (up - nrows <= zpad) nrows = up;
+    }
     const int steps = (nrows + 3) >> 2, sp = (((steps + nsplit - 1) / nsplit) + 3) & ~3;     // k-steps per part, a multiple of 4
     for (int tile = tile0; tile < ntile; tile += ntw) {            // more than one trip only when ntile > NWV (then nsplit == 1)
         f32x4 acc[4];
@@ -971,7 +977,7 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
                     if (j == C * k2) gr[l.oB2 + c0 + t] = av_[t];
                     else gr[l.oW2 + (c0 + t) * C * k2 + j] = av_[t];
                 }
-            });
+            }, AS - l.A0 - B);
         } else {
             const int nkq = (k2 + 3) / 4, ngrp = C * nkq;
             for (int grp = wv; grp <= ngrp; grp += NWV) {
@@ -1077,7 +1083,7 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
                     if (j == 2 * k1) gr[l.oB1 + c0 + t] = av_[t];
                     else gr[l.oW1 + (c0 + t) * 2 * k1 + j] = av_[t];
                 }
-            });
+            }, Lz - p2 - L);
         } else {
             const int nkq = (k1 + 3) / 4, ngrp = 2 * nkq;
             for (int grp = wv; grp <= ngrp; grp += NWV) {
