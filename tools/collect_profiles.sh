@@ -20,7 +20,7 @@ cp $O/pmc_traffic.json profiles/pmc_traffic.json
 cp $O/traffic/pmc_fetch_dp_wave_kernel.csv $O/traffic/pmc_write_dp_wave_kernel.csv $P/
 cp $O/pmc_dp/summary.txt $P/dp_wave_pmc_summary.txt
 cp $O/pmc_awgn/summary.txt $P/awgn_wave_pmc_summary.txt
-{ head -1 $P/vaenn_pmc_summary.txt 2>/dev/null | grep '^#' || echo "# tools/profile_pmc_nn.sh 2048 (SQ counters of nn_train_kernel, means over the launches)"; grep -v amdgpu.ids $G/${r}_pmc_nn.log | grep 'n=' ; } > $P/vaenn_pmc_summary.txt.new && mv $P/vaenn_pmc_summary.txt.new $P/vaenn_pmc_summary.txt
+{ grep '^#' $P/vaenn_pmc_summary.txt 2>/dev/null || echo "# tools/profile_pmc_nn.sh 2048 (SQ counters of nn_train_kernel, means over the launches)"; grep -v amdgpu.ids $G/${r}_pmc_nn.log | grep 'n=' ; } > $P/vaenn_pmc_summary.txt.new && mv $P/vaenn_pmc_summary.txt.new $P/vaenn_pmc_summary.txt
 {
   echo "# tools/probe_pipeline.py 8192 compact (stage by stage, a synchronisation after each)"
   grep "^R=" $G/${r}_pipeline_probe.txt
