@@ -68,6 +68,17 @@ __device__ __forceinline__ void adam_update_fast(float &p, float &m, float &v, f
     p = fmaf(-step_size * m, __builtin_amdgcn_rcpf(denom), p);
 }
 
+// ... and the AMSGrad form with the hardware reciprocal / square root (the VAE-NN kernel's 1650 parameters per step; rbc2s = 1 / sqrt(1 - beta2^t))
+__device__ __forceinline__ void adam_update_amsgrad_fast(float &p, float &m, float &v, float &vmax, float g, float step_size, float rbc2s)
+{
+    m = fmaf(g - m, 0.1f, m);
+    v = v * 0.999f;
+    v = v + (0.001f * g) * g;
+    vmax = fmaxf(vmax, v);
+    const float denom = fmaf(__builtin_amdgcn_sqrtf(vmax), rbc2s, 1e-8f);
+    p = fmaf(-step_size * m, __builtin_amdgcn_rcpf(denom), p);
+}
+
 __device__ __forceinline__ void adam_update_amsgrad(float &p, float &m, float &v, float &vmax, float g, float step_size, float bc2s)
 {
     m = fmaf(g - m, 0.1f, m);

@@ -797,9 +797,10 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
 #pragma unroll
             for (int i = 0; i < NLEV; i++) { z[i] = a2[(axq * NLEV + i) * AS + n]; zmax = fmaxf(zmax, z[i]); }
             float ssum = 0.f;
+            float zl[NLEV];                                   // logit - max: log q_i = zl_i - log(ssum) (the reference's + 1e-12 inside the log changes q log(.) by < 1e-12)
 #pragma unroll
-            for (int i = 0; i < NLEV; i++) { z[i] = __expf(z[i] - zmax); ssum += z[i]; }
-            const float rs = 1.0f / ssum;
+            for (int i = 0; i < NLEV; i++) { zl[i] = z[i] - zmax; z[i] = __expf(zl[i]); ssum += z[i]; }
+            const float rs = 1.0f / ssum, lss = __logf(ssum);
             float e1 = 0.f;
 #pragma unroll
             for (int i = 0; i < NLEV; i++) { z[i] *= rs; e1 = fmaf(amp[i], z[i], e1); }
@@ -809,7 +810,7 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
             for (int i = 0; i < NLEV; i++) {
                 const float d = amp[i] - e1;
                 e2 = fmaf(z[i] * d, d, e2);
-                if (inr) klsum = fmaf(z[i], __logf(z[i] + 1e-12f), klsum);
+                klsum = inr ? fmaf(z[i], zl[i] - lss, klsum) : klsum;
                 a2[(axq * NLEV + i) * AS + n] = z[i];
                 if (qf) qf[(size_t)(axq * NLEV + i) * No + (size_t)s * B + n] = z[i];
             }
@@ -1104,8 +1105,9 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
         b2t *= 0.999;
         if constexpr (PREF) { if (s + 1 < a.steps) store_minibatch(); }
         if (!a.no_update) {
-            const float bc2s = (float)sqrt(1.0 - b2t), ss = (float)(lr / (1.0 - b1t));
-            for (int i = tid; i < NP; i += NT) adam_update_amsgrad(th[i], am[i], av[i], ax[i], gr[i], ss, bc2s);
+            // (hardware reciprocal / square root, 1 ulp each: the step changes by ~2e-7 relative -- as in the DP wave kernel)
+            const float rbc2s = (float)(1.0 / sqrt(1.0 - b2t)), ss = (float)(lr / (1.0 - b1t));
+            for (int i = tid; i < NP; i += NT) adam_update_amsgrad_fast(th[i], am[i], av[i], ax[i], gr[i], ss, rbc2s);
             __syncthreads();
             nn_transpose_weights<NT, NLEV>(l, k1, k2, th, w1t, w2t, w2u);
         }
