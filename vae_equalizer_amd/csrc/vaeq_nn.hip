@@ -1107,9 +1107,28 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
         if (!a.no_update) {
             // (hardware reciprocal / square root, 1 ulp each: the step changes by ~2e-7 relative -- as in the DP wave kernel)
             const float rbc2s = (float)(1.0 / sqrt(1.0 - b2t)), ss = (float)(lr / (1.0 - b1t));
-            for (int i = tid; i < NP; i += NT) adam_update_amsgrad_fast(th[i], am[i], av[i], ax[i], gr[i], ss, rbc2s);
-            __syncthreads();
-            nn_transpose_weights<NT, NLEV>(l, k1, k2, th, w1t, w2t, w2u);
+            if constexpr (C == 16) {
+                // the owner of a convolution weight also writes it to its places in the transposed copies (the walk order of mfma_conv16, the
+                // [k][c][cc] copy of the backward pass): no separate transposition passes, one barrier less; their zero pads are never touched
+                const int Th = (k1 + 1) / 2;
+                for (int i = tid; i < NP; i += NT) {
+                    float w = th[i];
+                    adam_update_amsgrad_fast(w, am[i], av[i], ax[i], gr[i], ss, rbc2s);
+                    th[i] = w;
+                    if (i < l.NW1) {                            // fc1.weight[c][ii][k]
+                        const int c = i / (2 * k1), r = i - c * 2 * k1, ii = r / k1, k = r - ii * k1, hh = k >= Th, t = k - hh * Th;
+                        w1t[(4 * t + 2 * ii + hh) * 16 + c] = w;
+                    } else if (i >= l.oW2 && i < l.oB2) {       // fc2.weight[c][cc][k]
+                        const int j = i - l.oW2, c = j / (16 * k2), r = j - c * 16 * k2, cc = r / k2, k = r - cc * k2;
+                        w2t[(4 * ((cc & 3) * k2 + k) + (cc >> 2)) * 16 + c] = w;
+                        w2u[(k * 16 + c) * 16 + cc] = w;
+                    }
+                }
+            } else {
+                for (int i = tid; i < NP; i += NT) adam_update_amsgrad_fast(th[i], am[i], av[i], ax[i], gr[i], ss, rbc2s);
+                __syncthreads();
+                nn_transpose_weights<NT, NLEV>(l, k1, k2, th, w1t, w2t, w2u);
+            }
         }
         __syncthreads();
         NN_STAMP(10);
