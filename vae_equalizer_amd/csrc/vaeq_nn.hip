@@ -904,14 +904,12 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
             hterm = wave_sum(hterm);
             if (tid == 0) red[3] = hterm;
         }
-        __syncthreads();
-        const float Cc = red[0] + red[3];
-        const float gC = (float)nm / Cc;
-        if (tid == 0 && a.loss) a.loss[(size_t)run * a.steps + s] = (float)nm * logf(Cc) + red[1];
-        NN_STAMP(4);
         // ---- P5: dL/dh[j] = gC (-2 sum_np e[np sps - Mh + j] conj(mu[np]) + 2 h[j] VS[j]): one wave per group of 4 taps -- a symbol's mu and
-        //      4 + 4 adjacent residual samples give 16 FMAs; the 8 partial sums of the group share one reduce-scatter
-        for (int jg = wv; 4 * jg < M; jg += NWV) {
+        //      4 + 4 adjacent residual samples give 16 FMAs; the 8 partial sums of the group share one reduce-scatter.  The correlation sums need
+        //      neither gC nor VS: waves 1 .. NWV - 1 form them WHILE wave 0 runs the scalar section above (it alone used to keep seven waves at
+        //      the barrier), leave the raw sums in gr, and 2 M threads scale them once C is known
+        constexpr int DHW = NWV > 1 ? NWV - 1 : 1;             // waves that take tap groups
+        for (int jg = NWV > 1 ? wv - 1 : 0; jg >= 0 && 4 * jg < M; jg += DHW) {
             const int j0 = 4 * jg, jl = min(j0 + 3, M - 1);
             const int lo = max(0, (Mh - jl + sps - 1) / sps), hi_ = min(B - 1, (nm - 1 + Mh - j0) / sps);
             float acc[8];
@@ -930,8 +928,17 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
             }
             const float sum = wave_reduce_scatter<8>(acc, lane);
             const int idx = wave_reduce_channel<8>(lane), j = j0 + (idx >> 1), im = idx & 1;
-            if ((lane & 7) == 0 && j < M) gr[l.oH + im * M + j] = gC * (-2.0f * sum + 2.0f * hs[im * M + j] * VS[j]);
+            if ((lane & 7) == 0 && j < M) gr[l.oH + im * M + j] = sum;
         }
+        __syncthreads();
+        const float Cc = red[0] + red[3];
+        const float gC = (float)nm / Cc;
+        if (tid == 0 && a.loss) a.loss[(size_t)run * a.steps + s] = (float)nm * logf(Cc) + red[1];
+        if (tid < 2 * M) {                                     // (gr is not read before the Adam phase: no barrier needed behind this)
+            const int j = tid < M ? tid : tid - M;
+            gr[l.oH + tid] = gC * (-2.0f * gr[l.oH + tid] + 2.0f * hs[tid] * VS[j]);
+        }
+        NN_STAMP(4);
         NN_STAMP(5);
         // ---- P6: dL/dmu, dL/drho -> dL/dq -> softmax backward -> dL/dlogits in place of q; item = n (both axes)
         for (int n = tid; n < B; n += NT) {
