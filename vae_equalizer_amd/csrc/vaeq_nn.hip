@@ -204,6 +204,25 @@ __device__ __forceinline__ void nn_transpose_weights(const NNLayout &l, int k1, 
 // D[m = 4 (lane >> 4) + reg][n = lane & 15].  M is always the 16 channels.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Sum over the 64 lanes on the vector ALU (DPP row operations + four v_readlane; the form of vaeq_wave.h's wave_sum_dpp): vaeq_common.h's wave_sum is
+// a butterfly of six ds_bpermute, i.e. six DEPENDENT LDS round trips -- the BatchNorm statistics take four such sums per channel.  Fixed order.
+template <int CTRL>
+__device__ __forceinline__ float nn_dpp(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_fast(float v)
+{
+    v += nn_dpp<0xB1>(v);                                      // quad_perm:[1,0,3,2]
+    v += nn_dpp<0x4E>(v);                                      // quad_perm:[2,3,0,1]
+    v += nn_dpp<0x141>(v);                                     // row_half_mirror
+    v += nn_dpp<0x140>(v);                                     // row_mirror: every lane of a 16-lane row holds the row's sum
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 // ldsv: a 4-byte LDS read the compiler must leave where the source puts it (volatile, LDS address space -- as lds2 in vaeq_wave.h).  Used wherever a
 // read from a CLAMPED (always valid) address feeds a select: an ordinary load is sunk into a branch of its own behind its own s_waitcnt lgkmcnt(0)
 // (the backend will not speculate it), i.e. one exposed LDS round trip per operand -- the pattern round 3 found in the epilogue kernel and, with the ISA
@@ -755,13 +774,13 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
                     for (int u = 0; u < NVM; u++) sm_ += lane + 64 * u < L ? zv[u] : 0.f;
                 } else
                     for (int sx = lane; sx < L; sx += 64) sm_ += zr[sx];
-                const float mean = wave_sum(sm_) / (float)L;
+                const float mean = wave_sum_fast(sm_) / (float)L;
                 if (inreg) {
 #pragma unroll
                     for (int u = 0; u < NVM; u++) { const float d = zv[u] - mean; sv = lane + 64 * u < L ? fmaf(d, d, sv) : sv; }
                 } else
                     for (int sx = lane; sx < L; sx += 64) { const float d = zr[sx] - mean; sv = fmaf(d, d, sv); }
-                const float var = wave_sum(sv) / (float)L, rstd = 1.0f / sqrtf(var + 1e-5f);
+                const float var = wave_sum_fast(sv) / (float)L, rstd = 1.0f / sqrtf(var + 1e-5f);
                 if (lane == 0) {
                     bnst[c] = mean; bnst[C + c] = rstd;
                     if (!a.no_update) {                        // running statistics: momentum 0.1, unbiased variance
@@ -901,7 +920,7 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
             }
             if (tid < M) PH[tid + 1] = hq;
             if (tid == 0) PH[0] = 0.f;
-            hterm = wave_sum(hterm);
+            hterm = wave_sum_fast(hterm);
             if (tid == 0) red[3] = hterm;
         }
         // ---- P5: dL/dh[j] = gC (-2 sum_np e[np sps - Mh + j] conj(mu[np]) + 2 h[j] VS[j]): one wave per group of 4 taps -- a symbol's mu and
@@ -1057,8 +1076,8 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
                         if (lane + 64 * u < L) { s1 += gv[u]; s2 = fmaf(gv[u], zv[u], s2); }
                 } else
                     for (int sx = lane; sx < L; sx += 64) { s1 += gp[sx]; s2 = fmaf(gp[sx], zr[sx], s2); }
-                s1 = wave_sum(s1);
-                s2 = wave_sum(s2);
+                s1 = wave_sum_fast(s1);
+                s2 = wave_sum_fast(s2);
                 if (lane == 0) { gr[l.oG + c] = s2; gr[l.oBt + c] = s1; }
                 const float mean = bnst[c], rstd = bnst[C + c], gs = th[l.oG + c] * rstd, m1 = s1 / (float)L, m2 = s2 / (float)L;
                 if (inreg) {
