@@ -222,6 +222,24 @@ __device__ __forceinline__ float wave_sum_fast(float v)
     const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
     return (r0 + r1) + (r2 + r3);
 }
+// block_reduce3 (vaeq_common.h) with the wave sums above: results in red[0..2] for every thread; red needs 3 (NT / 64) + 4 floats; ends with a barrier
+template <int NT>
+__device__ __forceinline__ void nn_block_reduce3(float a, float b, float c, float *red)
+{
+    constexpr int NW = NT / 64;
+    a = wave_sum_fast(a);
+    b = wave_sum_fast(b);
+    c = wave_sum_fast(c);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[4 + w * 3 + 0] = a; red[4 + w * 3 + 1] = b; red[4 + w * 3 + 2] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int i = 0; i < NW; i++) { s0 += red[4 + i * 3]; s1 += red[4 + i * 3 + 1]; s2 += red[4 + i * 3 + 2]; }
+        red[0] = s0; red[1] = s1; red[2] = s2;
+    }
+    __syncthreads();
+}
 
 // ldsv: a 4-byte LDS read the compiler must leave where the source puts it (volatile, LDS address space -- as lds2 in vaeq_wave.h).  Used wherever a
 // read from a CLAMPED (always valid) address feeds a select: an ordinary load is sunk into a branch of its own behind its own s_waitcnt lgkmcnt(0)
@@ -881,7 +899,7 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
             esr[t] = er; esi[t] = ei;
             se += er * er + ei * ei;
         }
-        block_reduce3<NT>(se, klsum, vtot, red);              // vtot: this thread's part of sum_n (v_I + v_Q), collected in P3
+        nn_block_reduce3<NT>(se, klsum, vtot, red);           // vtot: this thread's part of sum_n (v_I + v_Q), collected in P3
         float hterm = 0.f;
         // VS[j] = sum over the symbols tap j sees = total - the few it misses at either end.  Those are prefixes of the first / last symbols: wave 0 scans
         // them once (lanes 0-31: symbols 0, 1, ...; lanes 32-63: symbols B - 1, B - 2, ...) and every tap picks its two partial sums with a shuffle -- the
