@@ -255,3 +255,30 @@ def test_nn_half_minibatch_kernel_matches_whole_minibatch_kernel(monkeypatch):
     assert torch.equal(ea.step, eb.step) and int(ea.step[0]) == steps
     ec, c = run(True)
     assert torch.equal(a["loss"], c["loss"]) and torch.equal(ea.theta, ec.theta) and torch.equal(ea.vmax, ec.vmax)   # bitwise reproducible
+
+
+@pytest.mark.parametrize("B,sps,k1,k2,M", [(64, 2, 5, 1, 9), (100, 1, 9, 5, 13), (40, 2, 25, 9, 9), (90, 3, 7, 3, 11), (130, 2, 63, 3, 25), (250, 2, 25, 3, 25), (17, 2, 3, 1, 5)])
+def test_nn_64qam_free_steps_on_ragged_shapes_match_oracle(B, sps, k1, k2, M):
+    """64-QAM `Net`, four FREE steps on ragged shapes against the fp32 oracle: after every update the owner of a convolution weight writes it into the
+    transposed copies the MFMA convolutions read (walk order of the forward pass, [k][c][cc] copy of the backward pass) -- a wrong index there shows from
+    the second step on.  Losses to 2e-5, parameters to 2e-5, AMSGrad vectors to 1e-4 of their maximum."""
+    from vae_equalizer_amd.engine import NNEngine
+    rng = np.random.default_rng(7 * B + k1)
+    n, steps, lr = 8, 4, 2e-3
+    lev = np.arange(-(n - 1), n, 2).astype(np.float32)
+    amp = (lev / np.sqrt(np.mean(lev ** 2) * 2)).astype(np.float32)
+    eng = NNEngine(2, M, k1, k2, amp, DEV, sps)
+    eng.init_parameters()
+    theta0 = (_np(eng.theta) + 0.02 * rng.standard_normal((2, eng.NP))).astype(np.float32)
+    eng.theta.copy_(torch.from_numpy(theta0).to(DEV))
+    x = (0.5 * rng.standard_normal((2, 2, steps * B * sps))).astype(np.float32)
+    r = eng.train(torch.from_numpy(x).to(DEV), B, steps, lr)
+    torch.cuda.synchronize()
+    for i in range(2):
+        st = oracle.NNState(theta0[i], np.float32)
+        lo = oracle.nn_train(st, x[i], steps, B, amp, k1, k2, M, lr, sps, np.float32)
+        assert np.max(np.abs(_np(r["loss"])[i] - lo) / np.abs(lo)) < 2e-5
+        assert np.max(np.abs(_np(eng.theta)[i] - st.theta)) < 2e-5
+        for ours, ref in ((eng.m, st.m), (eng.v, st.v), (eng.vmax, st.vmax)):
+            assert np.max(np.abs(_np(ours)[i] - ref)) < 1e-4 * max(np.max(np.abs(ref)), 1e-12)
+    assert int(eng.step[0]) == steps
