@@ -1644,19 +1644,20 @@ __global__ __launch_bounds__(NT) void nn_validate_kernel(int N, int sps_, int M_
             int d[2];
 #pragma unroll
             for (int axq = 0; axq < 2; axq++) {
-                float best = a2[(axq * NLEV) * NN_TILE + n];
+                float lg_[NLEV];                               // the axis's logits in one batch of pinned reads (an ordinary load is issued in front of
+#pragma unroll                                                 // its own compare behind its own s_waitcnt lgkmcnt(0): eight dependent round trips per axis)
+                for (int i = 0; i < NLEV; i++) lg_[i] = ldsv(a2 + (axq * NLEV + i) * NN_TILE + n);
+                float best = lg_[0];
                 int bi = 0;
 #pragma unroll
-                for (int i = 1; i < NLEV; i++) {
-                    const float v = a2[(axq * NLEV + i) * NN_TILE + n];
-                    if (v > best) { best = v; bi = i; }
-                }
+                for (int i = 1; i < NLEV; i++)
+                    if (lg_[i] > best) { best = lg_[i]; bi = i; }
                 d[axq] = bi;
                 if (axq == 0 && n0 + n < NE) {
                     float ssum = 0.f, e1 = 0.f;
 #pragma unroll
                     for (int i = 0; i < NLEV; i++) {
-                        const float w = __expf(a2[i * NN_TILE + n] - best);
+                        const float w = __expf(lg_[i] - best);
                         ssum += w;
                         e1 = fmaf(amp[i], w, e1);
                     }
