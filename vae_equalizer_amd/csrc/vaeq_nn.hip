@@ -31,7 +31,15 @@
 #define VAEQ_NN_LEAN 0                                 // 1: ... its forward convolutions with the k-step loop kept a loop (measured: -4 %)
 #endif
 
+#ifndef VAEQ_NN_MFMA8
+#define VAEQ_NN_MFMA8 1                                // 16-QAM (8 channels) on the 16-row MFMA path of 64-QAM, rows 8..15 zero (0: the vector-ALU path)
+#endif
+
 namespace vaeq {
+
+// which alphabets run the convolutions on v_mfma_f32_16x16x4_f32, and the channel rows their LDS buffers carry (MFMA rows: 16)
+__host__ __device__ constexpr bool nn_mf(int n) { return n == 8 || (n == 4 && VAEQ_NN_MFMA8); }
+__host__ __device__ constexpr int nn_cp(int n) { return nn_mf(n) ? 16 : 2 * n; }
 
 struct NNLayout {
     int C, L, p1, p2, Lx, Lz, mh, Mh, nm, NP, NW1, oW1, oB1, oW2, oB2, oG, oBt, oH;
@@ -48,7 +56,9 @@ __host__ __device__ inline NNLayout nn_layout(int B, int sps, int M, int n, int 
     l.C = 2 * n; l.L = B * sps; l.p1 = k1 / 2; l.p2 = k2 / 2;
     l.Lx = npad4(l.L + 2 * l.p1 + 8);                  // zero halo + room for the 4-wide windows of the last quad
     l.Lz = npad4(l.L + 2 * l.p2 + 4);
-    if (n == 8)                                        // C = 16 (MFMA path): row stride an odd multiple of 4 dwords, so that 16 channels x 4
+    const bool mf = nn_mf(n);
+    const int CP = nn_cp(n);                           // channel rows in LDS (MFMA path: 16, the rows past C stay zero)
+    if (mf)                                            // MFMA path: row stride an odd multiple of 4 dwords, so that 16 channels x 4
         while ((l.Lz & 7) != 4) l.Lz += 4;             // consecutive samples (an MFMA operand / result) fall into 64 different banks
     l.mh = M / 2; l.Mh = 2 * l.mh; l.nm = l.L - l.Mh;
     l.NW1 = l.C * 2 * k1;
@@ -57,23 +67,23 @@ __host__ __device__ inline NNLayout nn_layout(int B, int sps, int M, int n, int 
     l.oH = bn ? l.oBt + l.C : l.oG; l.NP = l.oH + 2 * M;
     int o = 0;
     auto take = [&](int cnt) { int r = o; o += npad4(cnt); return r; };
-    const int one = (n == 8 && !eval) ? 1 : 0;         // training on the MFMA path: a row of ones behind the input rows and behind the channel rows (the
+    const int one = (mf && !eval) ? 1 : 0;         // training on the MFMA path: a row of ones behind the input rows and behind the channel rows (the
                                                        // bias columns of the weight-gradient GEMMs read it like any other operand row: mfma_wgrad16, ROW1)
     l.xs = take((2 + one) * l.Lx);
-    l.z1 = take((l.C + (bn ? 0 : one)) * l.Lz);         // (Net_BN: fc2's input, and with it the row of ones, is zb)
-    l.zb = bn && !eval ? take((l.C + one) * l.Lz) : l.z1;      // Net_BN: BatchNorm output (fc2's input); z1 then holds the normalised zhat
+    l.z1 = take((CP + (bn ? 0 : one)) * l.Lz);         // (Net_BN: fc2's input, and with it the row of ones, is zb)
+    l.zb = bn && !eval ? take((CP + one) * l.Lz) : l.z1;      // Net_BN: BatchNorm output (fc2's input); z1 then holds the normalised zhat
                                                        // (eval mode folds the running statistics into fc1's epilogue: no second buffer)
     l.bnst = take(bn ? 6 * l.C : 0);                   // mean, rstd (batch) | running_mean, running_var | eval scale, shift
     // training on the MFMA path: the backward pass through fc2 reads dL/dlogits at n + shift, shift in [-4, 4], for whole 16-column tiles -- with
     // A0 zero columns in front, the row padded to whole tiles + A0 behind and a stride = 4 (mod 8) (conflict-free MFMA operand reads) no read needs a
     // clamp or a condition (a conditional LDS read costs a branch and an exposed round trip each: mfma_convT16)
-    l.A0 = (n == 8 && !eval) ? 4 : 0;
+    l.A0 = (mf && !eval) ? 4 : 0;
     l.AS = B;
-    if (n == 8 && !eval) {
+    if (mf && !eval) {
         l.AS = 16 * ((B + 15) / 16) + 2 * l.A0;
         while ((l.AS & 7) != 4) l.AS += 4;
     }
-    l.a2 = take(l.C * l.AS + 2 * l.A0);
+    l.a2 = take(CP * l.AS + 2 * l.A0);
     l.mu = take(2 * B); l.vr = take(2 * B);
     l.ES = npad4(l.nm + 2 * l.Mh + 4);                 // Mh zeros | nm residual samples | Mh + 4 zeros (nn_train_kernel)
     l.es = take(2 * l.ES);
@@ -82,9 +92,10 @@ __host__ __device__ inline NNLayout nn_layout(int B, int sps, int M, int n, int 
     l.th = take(l.NP);
     const int NPt = eval ? 0 : l.NP;                   // gradient and AMSGrad state: training only
     l.gr = take(NPt); l.am = take(NPt); l.av = take(NPt); l.ax = take(NPt);
-    l.w1t = take(l.NW1 + 7 * l.C);                     // fc1.weight as [i][k][c]: the 4 channels of a thread in one 16-byte read
-    l.w2t = take(l.C * l.C * k2 + 7 * l.C);            // fc2.weight as [cc][k][c]   (both zero-padded to a multiple of 8 rows: two MFMA k-steps)
-    l.w2u = take(eval ? 0 : l.C * l.C * k2);           // fc2.weight as [k][c][cc] (backward through fc2: 4 input channels per read)
+    // transposed weight copies: MFMA path = the walk order of mfma_conv16 (16 channel columns, 64 floats per k-step), else [i][k][c] / [cc][k][c]
+    l.w1t = take(mf ? 64 * ((((k1 + 1) / 2) + 1) & ~1) : l.NW1 + 7 * l.C);
+    l.w2t = take(mf ? 256 * k2 : l.C * l.C * k2 + 7 * l.C);
+    l.w2u = take(eval ? 0 : CP * CP * k2);             // fc2.weight as [k][c][cc] (backward through fc2)
     l.red = take(64);
     l.total = o;
     return l;
@@ -169,18 +180,24 @@ __device__ __forceinline__ void nn_transpose_weights(const NNLayout &l, int k1, 
                                                      float *w2u = nullptr)
 {
     constexpr int C = 2 * NLEV;
-    if constexpr (C == 16) {
+    if constexpr (nn_mf(NLEV)) {
         // the walk order of mfma_conv16: w1t[(4 t + lg) 16 + c] = fc1.weight[c][lg >> 1][(lg & 1) Th + t] (0 past the half / past k1),
-        //                                w2t[(4 t + lg) 16 + c] = fc2.weight[c][4 lg + t / k2][t % k2]
+        //                                w2t[(4 t + lg) 16 + c] = fc2.weight[c][4 lg + t / k2][t % k2];  channels / input channels >= C (16-QAM: 8..15): 0
         const int T1 = conv16_fc1_steps(k1), Th = (k1 + 1) / 2;
         for (int j = threadIdx.x; j < 64 * T1; j += NT) {
             const int c = j & 15, lg = (j >> 4) & 3, t = j >> 6, i = lg >> 1, k = (lg & 1) * Th + t;
-            w1t[j] = (t < Th && k < k1) ? th[l.oW1 + (c * 2 + i) * k1 + k] : 0.f;
+            w1t[j] = (t < Th && k < k1 && c < C) ? th[l.oW1 + (c * 2 + i) * k1 + k] : 0.f;
         }
         for (int j = threadIdx.x; j < 64 * 4 * k2; j += NT) {
             const int c = j & 15, lg = (j >> 4) & 3, t = j >> 6, cc = 4 * lg + t / k2, k = t % k2;
-            w2t[j] = th[l.oW2 + (c * C + cc) * k2 + k];
+            w2t[j] = (c < C && cc < C) ? th[l.oW2 + (c * C + cc) * k2 + k] : 0.f;
         }
+        if (w2u)
+            for (int j = threadIdx.x; j < 256 * k2; j += NT) {
+                const int cc = j & 15, c = (j >> 4) & 15, k = j >> 8;
+                w2u[j] = (c < C && cc < C) ? th[l.oW2 + (c * C + cc) * k2 + k] : 0.f;
+            }
+        return;
     } else {
     for (int j = threadIdx.x; j < l.NW1; j += NT) {
         const int c = j % C, ik = j / C, i = ik / k1, k = ik - i * k1;
@@ -303,12 +320,13 @@ __device__ __forceinline__ void sched_fence_w()
 // out(c0, col, acc): the lane's channels c0 .. c0 + 3 of column col.
 template <int NT, int TB, bool LEAN = false, typename OutF>
 __device__ __forceinline__ void mfma_conv16(const float *wt, int T, int lbase, int kdw, int rstride, const float *in, int cstep, int ncols,
-                                            const float *bias, OutF out)
+                                            const float *bias, OutF out, int creal = 16)
 {
     constexpr int NWV = NT / 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lc = lane & 15, lg = lane >> 4;
     const int ntile = (ncols + 15) >> 4, K8 = T >> 1;
-    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias + 4 * lg);
+    // (creal < 16: the channels past it have zero weights and get a zero bias: their outputs are exact zeros)
+    const f32x4 b4 = 4 * lg < creal ? *reinterpret_cast<const f32x4 *>(bias + 4 * lg) : f32x4{0.f, 0.f, 0.f, 0.f};
     for (int tg = wv * TB; tg < ntile; tg += NWV * TB) {
         f32x4 acc[TB];
 #pragma unroll
@@ -365,7 +383,7 @@ __device__ __forceinline__ void mfma_conv16(const float *wt, int T, int lbase, i
 // runs on the vector FMA pipe, so every vector instruction inside an MFMA loop ADDS to the loop's time instead of hiding behind the matrix passes.
 template <int NT, bool ROW1 = false, typename OutF>
 __device__ __forceinline__ void mfma_wgrad16(const float *g, int gstride, int nrows, const float *in, int rstep, int J, int kd, int rstride,
-                                             float *scratch, int cap, OutF out, int zpad = 0)
+                                             float *scratch, int cap, OutF out, int zpad = 0, int onesrow = -1)
 {
     constexpr int NWV = NT / 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lc = lane & 15, lg = lane >> 4;
@@ -386,7 +404,9 @@ __device__ __forceinline__ void mfma_wgrad16(const float *g, int gstride, int nr
         for (int q = 0; q < 4; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (part < nsplit) {
             const int j = tile * 16 + lc;
-            const int ji = (ROW1 || j < J) ? j / kd : 0, joff = (ROW1 || j < J) ? ji * rstride + (j - ji * kd) : 0;
+            // (ROW1: the bias column J -- and the padding columns behind it, whose results are dropped -- read the row of ones, row `onesrow` of `in`)
+            const int jq = j / kd, ji = ROW1 ? (j < J ? jq : (onesrow >= 0 ? onesrow : J / kd)) : (j < J ? jq : 0);
+            const int joff = ROW1 ? ji * rstride + (j < J ? j - jq * kd : j - J) : (j < J ? ji * rstride + (j - ji * kd) : 0);
             const bool ones = !ROW1 && j == J;
             const float *gp = g + lc * gstride;
             const int t1 = min(steps, (part + 1) * sp);
@@ -587,7 +607,7 @@ __device__ __forceinline__ void nn_fc1_elu(const NNLayout &l, int k1, const floa
 {
     // z1p[c][p2 + s] for s in [0, Lvalid); entries whose absolute position (zlo + s) lies outside [0, zhi) are fc2's zero padding
     constexpr int C = 2 * NLEV, CQ = C / 4;
-    if constexpr (C == 16) {
+    if constexpr (nn_mf(NLEV)) {
         const int lg = (threadIdx.x & 63) >> 4;
         mfma_conv16<NT, (NT >= 1024 ? 2 : 5), LEAN>(w1t, conv16_fc1_steps(k1), (lg >> 1) * l.Lx + (lg & 1) * ((k1 + 1) / 2), 0x7fffffff, 0, xs, 1, Lvalid, th + l.oB1, [&](int c0, int sy, f32x4 acc) {
             const int pos = zlo + sy;
@@ -596,10 +616,10 @@ __device__ __forceinline__ void nn_fc1_elu(const NNLayout &l, int k1, const floa
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 float z = av[t] > 0.f ? av[t] : __expf(av[t]) - 1.0f;                     // F.elu, alpha = 1 (:177)
-                if (aff) z = fmaf(aff[c0 + t], z, aff[C + c0 + t]);                       // eval-mode BatchNorm: running statistics folded
-                z1[(c0 + t) * l.Lz + l.p2 + sy] = in ? z : 0.f;
+                if (aff && c0 + t < C) z = fmaf(aff[c0 + t], z, aff[C + c0 + t]);         // eval-mode BatchNorm: running statistics folded
+                z1[(c0 + t) * l.Lz + l.p2 + sy] = in ? z : 0.f;                           // (rows past C: ELU(0) = 0)
             }
-        });
+        }, C);
         return;
     }
     typedef float v2f __attribute__((ext_vector_type(2)));     // channel pairs: every MAC below is a v_pk_fma_f32
@@ -642,12 +662,12 @@ __device__ __forceinline__ void nn_fc2(const NNLayout &l, int sps, int k2, int B
                                        float *a2)
 {
     constexpr int C = 2 * NLEV, CQ = C / 4;
-    if constexpr (C == 16) {
+    if constexpr (nn_mf(NLEV)) {
         const int lg = (threadIdx.x & 63) >> 4;
         mfma_conv16<NT, (NT >= 1024 ? 1 : 3), LEAN>(w2t, conv16_fc2_steps(k2), 4 * lg * l.Lz, k2, l.Lz, z1, sps, Bt, th + l.oB2, [&](int c0, int n, f32x4 acc) {
             a2[(c0 + 0) * astride + n] = acc.x; a2[(c0 + 1) * astride + n] = acc.y;
             a2[(c0 + 2) * astride + n] = acc.z; a2[(c0 + 3) * astride + n] = acc.w;
-        });
+        }, C);
         return;
     }
     typedef float v2f __attribute__((ext_vector_type(2)));
@@ -686,6 +706,8 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
     extern __shared__ float4 smem4[];
     float *sm = reinterpret_cast<float *>(smem4);
     constexpr int C = 2 * NLEV;
+    constexpr bool MF = nn_mf(NLEV);                           // convolutions and their gradients on the 16-row MFMA path
+    constexpr int CP = nn_cp(NLEV);                            // channel rows of z1 / zb / a2 in LDS (MF: 16; rows C .. 15 hold zeros)
     const int tid = threadIdx.x, run = blockIdx.x;
     // BK = 2: only the LDS layout of that shape is constant; the shape itself stays in run-time variables (no unrolling on constant trip counts)
     const int B = BK == 1 ? 300 : a.B, sps = SPS ? SPS : a.sps, M = BK == 1 ? 25 : a.M, k1 = BK == 1 ? 25 : a.k1, k2 = BK == 1 ? 3 : a.k2;
@@ -713,16 +735,16 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
         th[i] = a.theta[g]; am[i] = a.adam_m[g]; av[i] = a.adam_v[g]; ax[i] = a.adam_x[g];
     }
     for (int i = tid; i < 2 * Lx; i += NT) xs[i] = 0.f;        // halos stay zero
-    for (int i = tid; i < C * Lz; i += NT) z1[i] = 0.f;
-    for (int i = tid; i < C * AS + 2 * l.A0; i += NT) sm[l.a2 + i] = 0.f;   // guard columns stay zero
+    for (int i = tid; i < CP * Lz; i += NT) z1[i] = 0.f;
+    for (int i = tid; i < CP * AS + 2 * l.A0; i += NT) sm[l.a2 + i] = 0.f;  // guard columns stay zero
     for (int i = tid; i < 2 * ES; i += NT) es[i] = 0.f;
-    if constexpr (C == 16) {                                   // the rows of ones (nn_layout)
-        for (int i = tid; i < Lx; i += NT) xs[2 * Lx + i] = 1.0f;
-        for (int i = tid; i < Lz; i += NT) zb[C * Lz + i] = 1.0f;   // (zb aliases z1 without BatchNorm)
-    }
     if (BN) {
-        for (int i = tid; i < C * Lz; i += NT) zb[i] = 0.f;
+        for (int i = tid; i < CP * Lz; i += NT) zb[i] = 0.f;
         for (int i = tid; i < 2 * C; i += NT) bnst[2 * C + i] = a.bn_running[(size_t)run * 2 * C + i];
+    }
+    if constexpr (MF) {                                        // the rows of ones (nn_layout)
+        for (int i = tid; i < Lx; i += NT) xs[2 * Lx + i] = 1.0f;
+        for (int i = tid; i < Lz; i += NT) zb[CP * Lz + i] = 1.0f;  // (zb aliases z1 without BatchNorm)
     }
     int step = a.step[run];
     double b1t = pow(0.9, (double)step), b2t = pow(0.999, (double)step);
@@ -1013,16 +1035,17 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
         if constexpr (PREF) { if (s + 1 < a.steps) load_minibatch(s + 1); }
         NN_STAMP(6);
         // ---- P7a: fc2 weight / bias gradients: one wave per (input channel, group of 4 taps); pseudo group at the end: the biases
-        if constexpr (C == 16) {
+        if constexpr (MF) {
             // gw2[c][cc][k] = sum_n g2[c][n] zb[cc][n sps + k]: columns j = cc k2 + k, plus the bias column
             mfma_wgrad16<NT, true>(a2, AS, B, zb, sps, C * k2, k2, Lz, mu, 4 * B, [&](int c0, int j, f32x4 acc) {
                 const float av_[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
+                    if (c0 + t >= C) continue;                 // (16-QAM on the 16-row path: rows 8 .. 15 are padding)
                     if (j == C * k2) gr[l.oB2 + c0 + t] = av_[t];
                     else gr[l.oW2 + (c0 + t) * C * k2 + j] = av_[t];
                 }
-            }, AS - l.A0 - B);
+            }, AS - l.A0 - B, CP);
         } else {
             const int nkq = (k2 + 3) / 4, ngrp = C * nkq;
             for (int grp = wv; grp <= ngrp; grp += NWV) {
@@ -1038,7 +1061,7 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
         NN_STAMP(7);
         // ---- P7b: dL/dz1 through fc2, times ELU' -> dL/da1 in place of z1; item = (4 input channels, sample): every dL/dlogit read
         //      feeds the 4 channels, whose weights come as one 16-byte read of the [k][c][cc] copy
-        if constexpr (C == 16) {
+        if constexpr (MF) {
             mfma_convT16<NT, 3>(w2u, k2, p2, sps, a2, AS, L,
                 [&](int cc, int sx) { return BN ? 0.f : z1[cc * Lz + p2 + sx]; },
                 [&](int cc, int sx, float g, float z) {
@@ -1119,12 +1142,13 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
         }
         NN_STAMP(8);
         // ---- P8: fc1 weight / bias gradients, same scheme: one wave per (input row, group of 4 taps)
-        if constexpr (C == 16) {
+        if constexpr (MF) {
             // gw1[c][i][k] = sum_s gz[c][s] x[i][s + k]: columns j = i k1 + k, plus the bias column
             mfma_wgrad16<NT, true>(z1 + p2, Lz, L, xs, 1, 2 * k1, k1, Lx, mu, 4 * B, [&](int c0, int j, f32x4 acc) {
                 const float av_[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
+                    if (c0 + t >= C) continue;
                     if (j == 2 * k1) gr[l.oB1 + c0 + t] = av_[t];
                     else gr[l.oW1 + (c0 + t) * 2 * k1 + j] = av_[t];
                 }
@@ -1151,7 +1175,7 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
         if (!a.no_update) {
             // (hardware reciprocal / square root, 1 ulp each: the step changes by ~2e-7 relative -- as in the DP wave kernel)
             const float rbc2s = (float)(1.0 / sqrt(1.0 - b2t)), ss = (float)(lr / (1.0 - b1t));
-            if constexpr (C == 16) {
+            if constexpr (MF) {
                 // the owner of a convolution weight also writes it to its places in the transposed copies (the walk order of mfma_conv16, the
                 // [k][c][cc] copy of the backward pass): no separate transposition passes, one barrier less; their zero pads are never touched
                 const int Th = (k1 + 1) / 2;
@@ -1163,7 +1187,7 @@ __global__ __launch_bounds__(NT, (NLEV == 2 && NT <= 512) ? 4 : (NT / 256 > 0 ? 
                         const int c = i / (2 * k1), r = i - c * 2 * k1, ii = r / k1, k = r - ii * k1, hh = k >= Th, t = k - hh * Th;
                         w1t[(4 * t + 2 * ii + hh) * 16 + c] = w;
                     } else if (i >= l.oW2 && i < l.oB2) {       // fc2.weight[c][cc][k]
-                        const int j = i - l.oW2, c = j / (16 * k2), r = j - c * 16 * k2, cc = r / k2, k = r - cc * k2;
+                        const int j = i - l.oW2, c = j / (C * k2), r = j - c * C * k2, cc = r / k2, k = r - cc * k2;
                         w2t[(4 * ((cc & 3) * k2 + k) + (cc >> 2)) * 16 + c] = w;
                         w2u[(k * 16 + c) * 16 + cc] = w;
                     }
