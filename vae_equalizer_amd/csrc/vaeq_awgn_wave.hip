@@ -239,14 +239,17 @@ __global__ __launch_bounds__(64 * NW, 2) void awgn_wave_kernel(const vaeq_awgn_a
     }
 
     // the window of the NEXT step is fetched into registers while the current step computes
+    // (buffer loads: a lane without a symbol pair passes an out-of-range offset and reads zeros.  As `act ? *p : 0` every one of the 2 NR loads sat in an
+    //  exec-masked branch of its own with an s_waitcnt vmcnt(0) directly behind it -- the "prefetch" was 2 NR serial HBM round trips in the middle of the step)
     float4 pf[NR][2];
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.rx + (size_t)run * 2 * (size_t)a.S, (uint32_t)(2 * a.S) * 4u);
     auto fetch = [&](int s) {
-        const float *src = a.rx + (size_t)run * 2 * (size_t)a.S + (size_t)s * L + 4 * l0;
+        const uint32_t vo = ((uint32_t)s * (uint32_t)L + 4u * (uint32_t)l0) * 4u;
 #pragma unroll
         for (int r = 0; r < NR; r++)
 #pragma unroll
             for (int row = 0; row < 2; row++)
-                pf[r][row] = act[r] ? *reinterpret_cast<const float4 *>(src + (size_t)row * a.S + 256 * r) : make_float4(0.f, 0.f, 0.f, 0.f);
+                pf[r][row] = bld128(xr, act[r] ? vo + 1024u * (uint32_t)r : OOB, (uint32_t)row * (uint32_t)a.S * 4u);
     };
     fetch(0);
 #pragma unroll 1
