@@ -526,9 +526,15 @@ __global__ __launch_bounds__(EPI_NT, 3) void dp_epilogue_compact_kernel(int N, i
                              // v sits exactly on a threshold -- then, and for asymmetric thresholds, -v is quantised by itself
                              const float yi = q.u0[p][e] * fac, yq = q.u1[p][e] * fac;
                              int A = 0, Bq = 0;
+                             bool on = false;                   // an output exactly ON a threshold (strictly ascending thresholds: yi == hi[A - 1] <=> yi equals one
+                                                                // of them) -- found by register compares: as `A > 0 && yi == sh.hi[A - 1]` each test was an LDS read in
+                                                                // an exec-masked branch of its own behind its own s_waitcnt (eight per group of four symbols)
 #pragma unroll
-                             for (int i = 0; i < S; i++) { A += (int)(yi >= thr[i]); Bq += (int)(yq >= thr[i]); }
-                             const bool odd = !sym || (A > 0 && yi == sh.hi[max(A - 1, 0)]) || (Bq > 0 && yq == sh.hi[max(Bq - 1, 0)]);
+                             for (int i = 0; i < S; i++) {
+                                 A += (int)(yi >= thr[i]); Bq += (int)(yq >= thr[i]);
+                                 on |= (yi == thr[i]) | (yq == thr[i]);
+                             }
+                             const bool odd = !sym || on;
                              const int dI = min(lI, S), dQ = min(lQ, S);                      // (a level outside the range takes the nearest interval, :270)
                              eb = sh.lut[dI | (dQ << 3) | (A << 6) | (Bq << 9)];
                              if (odd) eb = epi_eb_generic(yi, yq, sh.hi, S, dI, dQ);
