@@ -394,6 +394,32 @@ def extra_configs(R, t, var, frame_rx, device):
                                        "(training loop; q is not materialised, like the reference)",
                            "kernel": name, "kernel_ms": ms, "value": rate, "unit": "symbols/s", "hbm_gbs": 16 * rate / 1e9, "hbm_frac": 16 * rate / 1e9 / HBM_PEAK_GBS,
                            "flop_frac": flop_sym * rate / 1e12 / FP32_PEAK_TFLOPS, "algorithmic_flops_per_symbol": flop_sym, "epoch_pipeline": epoch}
+    # row f3 (AWGN VAE-NN, AWGN_channel/func_VAENN_MQAM.py): the sweep script's shape (Eval_run_vaenn.py:25-28: 64-QAM, batch_len 300, M_est 25, kernel sizes 25 / 3),
+    # one training launch of an epoch (13 minibatch steps of train_len 4000) and the fused validation pass on 15 000 symbols, 2048 runs.  flops: the three GEMM-shaped
+    # passes of each convolution (forward, input gradient, weight gradient), 2 per multiply-add -- what tools/probe_nn.py and DESIGN.md quote
+    from vae_equalizer_amd.engine import NNEngine
+    from vae_equalizer_amd.func_VAENN_MQAM import vaenn_tables
+    tn = vaenn_tables("64-QAM", "h1", 2)
+    Rn, Bn, stepsN, Nv = 2048, 300, 13, 15000
+    engn = NNEngine(Rn, 25, 25, 3, tn["amps"], device, 2)
+    engn.init_parameters()
+    sig = np.full(Rn, np.sqrt(0.5) / 10 ** (24 / 20), np.float32)
+    Pn = np.full(len(tn["amps"]), 1 / len(tn["amps"]))
+    rxn, _ = ch.generate_awgn_batch_hip(Rn, 4000, tn["amps"], Pn, 24.0, tn["h_channel"], 2, device, 1, 0, sigma_fixed=sig)
+    rxv, dv = ch.generate_awgn_batch_hip(Rn, Nv, tn["amps"], Pn, 24.0, tn["h_channel"], 2, device, 1, 1, sigma_fixed=sig)
+
+    def nn_train():
+        engn.train(rxn, Bn, stepsN, 4e-3)
+
+    def nn_valid():
+        engn.validate(rxv, dv, 21)
+    nn_train(); nn_valid()
+    ms_nt, ms_nv = float(np.median(_event_ms(nn_train, 5))), float(np.median(_event_ms(nn_valid, 3)))
+    macs_step = 600 * 16 * 50 * 3 + 300 * 16 * 48 * 3
+    out["vaenn_f3"] = {"workload": f"AWGN VAE-NN `Net`, 64-QAM, batch_len {Bn}, M_est 25, kernel sizes 25 / 3: {stepsN} minibatch steps per launch, {Rn} runs; validation on {Nv} symbols",
+                       "train_ms_per_launch": ms_nt, "us_per_run_step": ms_nt * 1e3 / stepsN / (Rn / 256.0), "value": Rn * stepsN * Bn / (ms_nt * 1e-3), "unit": "symbols/s",
+                       "tflops": 2 * Rn * stepsN * macs_step / (ms_nt * 1e-3) / 1e12, "flop_frac": 2 * Rn * stepsN * macs_step / (ms_nt * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                       "validate_ms": ms_nv, "validate_tflops": 2 * Rn * Nv * (2 * 16 * 50 + 16 * 48) / (ms_nv * 1e-3) / 1e12}
     return out
 
 

@@ -49,6 +49,8 @@ def test_bench_line_contract():
     ep = c2["epoch_pipeline"]
     assert ep["ms_train_part"] > 0 and ep["ms_validation_part"] > ep["ms_train_part"] and ep["run_epochs_per_s_epe2"] > 0
     assert ep["validation_forms_agree_bitwise"] and ep["ms_validation_part"] < ep["ms_validation_part_two_step"]   # noise on load: same SER, no noisy frame in HBM
+    nn = e["configs"]["vaenn_f3"]                                               # row f3: the VAE-NN training launch and validation pass at the script's shape
+    assert nn["unit"] == "symbols/s" and nn["tflops"] > 40.0 and nn["validate_tflops"] > 45.0 and 0.2 < nn["flop_frac"] < 1.0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "2170" in cb["sample"] and cb["reference_dp_symbols_per_s"] == 2170.0
 
