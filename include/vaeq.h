@@ -91,8 +91,8 @@ typedef struct vaeq_dp_args {
                             DP symbol costs in HBM are the materialised q) */
     float *dbg_gW;       /* nullable [R][2][4][M]     gradient of the LAST step (parity tests) */
     float *dbg_gh;       /* nullable [R][2][2][2][M] */
-    int32_t threads;     /* kernel choice: 0 = automatic (wave-per-run fast path when the shape allows -- sps = 2, B <= 1024 even or odd,
-                            M in {9, 13, 17, 21, 25, 31} --, else generic/256);
+    int32_t threads;     /* kernel choice: 0 = automatic: the wave-per-run fast path when the shape allows (sps = 2, B <= 1024 even or
+                            odd, M one of 9 13 17 21 25 31), else the generic kernel with 256 threads per run.
                             1 = wave-per-run only (VAEQ_ERR_SHAPE if unsupported); 64 / 128 / 256 = generic kernel, that
                             many threads per run */
     int32_t no_update;   /* 1: skip the Adam update (forward + loss + gradients only) */
