@@ -368,10 +368,14 @@ def test_eval_run_shaping_vaele_untouched_defaults_are_fast(tmp_path):
     # uniform 64-QAM at 24 dB over h1: a run either locks (SER 0.0088 ... 0.0100 over the last 50 validations) or is still on the blind
     # equaliser's initial plateau (0.867) after 500 epochs -- about one run in ten, different runs every sweep, the same in the two-step form
     # (measured: 1, 3, 1, 4 of 40, 1); the lock statistics themselves are tests/test_ensemble_gpu.py's subject (HIP vs oracle)
-    locked = lvl < 0.1
-    assert locked.sum() >= 12, lvl                                              # P(more than 8 of 20 stuck) < 1e-4 at one in ten
-    assert lvl[locked].max() < 1.25 * np.median(lvl[locked]) and 0.004 < np.median(lvl[locked]) < 0.015, lvl
-    assert (np.abs(lvl[~locked] - 0.867) < 0.02).all(), lvl
+    # a run that locks INSIDE (or shortly before) the 50-validation tail has a tail mean anywhere between the two levels -- unseeded sweep, fresh entropy every
+    # time: such a run is neither "locked" nor "stuck" for the level assertions (this test failed once in ~25 full-suite runs on exactly that)
+    S2 = SER.reshape(20, 250)
+    first = np.where((S2 < 0.1).any(axis=1), (S2 < 0.1).argmax(axis=1), 250)     # first validation below 0.1
+    locked, stuck = first < 160, first == 250                                   # locked with >= 40 validations (80 epochs) to settle before the tail
+    assert locked.sum() >= 12 and (~locked & ~stuck).sum() <= 4, (first, lvl)   # P(more than 8 of 20 not locked by then) < 1e-3
+    assert lvl[locked].max() < 1.25 * np.median(lvl[locked]) and 0.004 < np.median(lvl[locked]) < 0.015, (first, lvl)
+    assert (np.abs(lvl[stuck] - 0.867) < 0.02).all(), (first, lvl)
     assert SER.reshape(20, 250)[:, 0].min() > 0.3                                # and starts unconverged: the curve is a training curve
 
 
