@@ -11,6 +11,7 @@
 // a fixed order, so results are bitwise reproducible.
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -257,6 +258,11 @@ struct KeepWalk4 {
 };
 
 
+// an LDS read the compiler leaves where the source puts it (a plain read that feeds a short-circuit test is sunk into an exec-masked branch of its own
+// behind its own s_waitcnt lgkmcnt(0): tools/scan_isa.py counted 283 such waits for 426 reads in this kernel)
+typedef const volatile __attribute__((address_space(3))) float epi_lds_cvf;
+__device__ __forceinline__ float epi_ldsv(const float *p) { return *(epi_lds_cvf *)p; }
+
 // four consecutive elements of a row: one wide load when the group lies inside the row (and the row is aligned for it), else the kept members one by one
 // (a kept symbol's partner index n + shift never leaves the row: 11 <= n, |shift| <= 10, and the window ends 11 + max|shift| before the row does)
 __device__ __forceinline__ void epi_ld_tx(const __half *row, int n0, bool wide, const bool (&kp)[4], float (&out)[4])
@@ -369,7 +375,11 @@ __global__ __launch_bounds__(EPI_NT, CMA ? EPI_WAVES_CMA : EPI_WAVES) void dp_ep
                 bool kp[4];
                 kw.keep4(n0, kp);
                 if (!(kp[0] || kp[1] || kp[2] || kp[3])) continue;
-                const bool wide = row_wide && n0 >= 12 && n0 + 14 <= (int)N;
+                // the access form (one wide load per row / the kept members one by one) is a compile-time choice of the group's body: as a run-time flag inside
+                // the loaders every load sat in a branch of its own behind its own s_waitcnt vmcnt(0) (182 of the kernel's 186 global loads)
+                const bool wide_g = row_wide && n0 >= 12 && n0 + 14 <= (int)N;
+                auto body = [&](auto wtag) {
+                constexpr bool wide = decltype(wtag)::value;
 #pragma unroll
                 for (int p = 0; p < 2; p++) {
                     const int sp = (p - r) & 1, m0 = n0 + (p ? s1 : s0);
@@ -385,6 +395,8 @@ __global__ __launch_bounds__(EPI_NT, CMA ? EPI_WAVES_CMA : EPI_WAVES) void dp_ep
                             sy += sqrtf(fmaf(yi[e], yi[e], yq[e] * yq[e]));
                         }
                 }
+                };
+                if (wide_g) body(std::true_type{}); else body(std::false_type{});
             }
             block_reduce3<EPI_NT>(st, sy, 0.f, sh.red);
             fac = sh.red[0] / sh.red[1];
@@ -405,7 +417,9 @@ __global__ __launch_bounds__(EPI_NT, CMA ? EPI_WAVES_CMA : EPI_WAVES) void dp_ep
             kw.keep4(n0, kp);
             if (!(kp[0] || kp[1] || kp[2] || kp[3])) continue;
             kept += (int)kp[0] + (int)kp[1] + (int)kp[2] + (int)kp[3];
-            const bool wide = row_wide && n0 >= 12 && n0 + 14 <= (int)N;
+            const bool wide_g = row_wide && n0 >= 12 && n0 + 14 <= (int)N;
+            auto body = [&](auto wtag) {                         // (access form as a compile-time choice: see the radius walk above)
+            constexpr bool wide = decltype(wtag)::value;
 #pragma unroll
             for (int p = 0; p < 2; p++) {
                 const int sp = (p - r) & 1;                     // roll(r, 0): row p comes from row p - r  (:71)
@@ -439,19 +453,22 @@ __global__ __launch_bounds__(EPI_NT, CMA ? EPI_WAVES_CMA : EPI_WAVES) void dp_ep
                     } else {
                         const float yi = u0[e] * fac, yq = u1[e] * fac;
                         const float rI[4] = {yi, -yi, -yq, yq}, rQ[4] = {yq, -yq, yi, -yi};        // :245-262
-                        auto inside = [&](float v, float lev) {     // d_vec0[lev] <= v < d_vec1[lev]   (:267-287)
-                            const int li = min(max((int)lev, 0), NLEV - 1);
-                            return sh.lo[li] <= v && v < sh.hi[li];
-                        };
+                        // d_vec0[lev] <= v < d_vec1[lev] (:267-287): the bounds of the symbol's three TX levels are read ONCE, up front
+                        const int lI = min(max((int)dI, 0), NLEV - 1), lQ = min(max((int)dQ, 0), NLEV - 1), lQi = min(max((int)dQi, 0), NLEV - 1);
+                        const float loI = epi_ldsv(sh.lo + lI), hiI = epi_ldsv(sh.hi + lI), loQ = epi_ldsv(sh.lo + lQ), hiQ = epi_ldsv(sh.hi + lQ);
+                        const float loQi = epi_ldsv(sh.lo + lQi), hiQi = epi_ldsv(sh.hi + lQi);
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            const bool okI = inside(rI[k], dI);
-                            cnt[(2 * k + 0) * 2 + p] += !(okI && inside(rQ[k], dQ));
-                            cnt[(2 * k + 1) * 2 + p] += !(okI && inside(rQ[k], dQi));
+                            const bool okI = (loI <= rI[k]) & (rI[k] < hiI);
+                            const bool okQ = (loQ <= rQ[k]) & (rQ[k] < hiQ), okQi = (loQi <= rQ[k]) & (rQ[k] < hiQi);
+                            cnt[(2 * k + 0) * 2 + p] += !(okI & okQ);
+                            cnt[(2 * k + 1) * 2 + p] += !(okI & okQi);
                         }
                     }
                 }
             }
+            };
+            if (wide_g) body(std::true_type{}); else body(std::false_type{});
         }
 #pragma unroll
         for (int i = 0; i < 16; i++) epi_count_add(&sh.cnt[i], cnt[i]);
